@@ -1,0 +1,10 @@
+"""MI355X-native training and sampling path for the brain-connectome VAE family.
+
+Host side: Python on PyTorch-ROCm (device memory, streams, torch.distributed); compute:
+hand-written gfx950 kernels in lib/libmdnvae_hip.so, reached through a C ABI
+(include/mdnvae_hip.h).  The module surface mirrors the reference scripts'
+(VAE.encode / reparameterize / decode / forward / set_mask, loss_function)."""
+from . import _lib  # noqa: F401
+from .ops import reparameterize, vae_loss, vae_loss_terms, vae_loss_and_grads  # noqa: F401
+
+__all__ = ["reparameterize", "vae_loss", "vae_loss_terms", "vae_loss_and_grads"]

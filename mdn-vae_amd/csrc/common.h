@@ -1,0 +1,82 @@
+// Shared host/device helpers for the connectome-VAE HIP library (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdint>
+
+namespace mdnvae {
+
+// ---- error reporting -------------------------------------------------------
+// Every extern "C" entry point returns 0 on success, a negative MDNVAE_E* code for a
+// rejected argument, or a positive hipError_t when a launch fails.  The message of the
+// last failure on the calling thread is kept for mdnvae_last_error().
+constexpr int E_ARG = -1;      // bad pointer / size / enum
+constexpr int E_SHAPE = -2;    // shape outside what the kernels are built for
+constexpr int E_ALIGN = -3;    // pointer alignment
+
+void set_error(const char* fmt, ...);
+
+#define MV_REQUIRE(cond, code, ...)                \
+    do {                                           \
+        if (!(cond)) {                             \
+            ::mdnvae::set_error(__VA_ARGS__);      \
+            return (code);                         \
+        }                                          \
+    } while (0)
+
+#define MV_LAUNCH_CHECK(name)                                                         \
+    do {                                                                              \
+        hipError_t e_ = hipGetLastError();                                            \
+        if (e_ != hipSuccess) {                                                       \
+            ::mdnvae::set_error("%s: launch failed: %s", name, hipGetErrorString(e_)); \
+            return (int)e_;                                                           \
+        }                                                                             \
+    } while (0)
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// ---- device helpers ----------------------------------------------------------
+constexpr int WAVE = 64;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_sum_all(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max_all(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// Sum over a workgroup of NT threads (multiple of 64); result valid in thread 0.
+// `scratch` must hold NT/64 elements; fixed summation order (deterministic).
+template <int NT, typename T>
+__device__ __forceinline__ T block_sum(T v, T* scratch) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (lane == 0) scratch[wid] = v;
+    __syncthreads();
+    T r = 0;
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < NT / 64; ++i) r += scratch[i];
+    }
+    __syncthreads();
+    return r;
+}
+
+__device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
+
+}  // namespace mdnvae

@@ -1,0 +1,45 @@
+"""CPU checks of the C-ABI boundary: the library loads without a GPU, exports every
+symbol the header declares, and the host wrappers refuse anything but device tensors."""
+import ctypes
+import os
+
+import pytest
+import torch
+
+import mdnvae_amd
+from mdnvae_amd import _lib
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    names = [n for n, _, _ in _lib.declared_functions()]
+    assert len(names) >= 8
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/mdnvae_hip.h but not exported"
+    assert lib.mdnvae_version() >= 100
+    assert lib.mdnvae_loss_workspace_bytes() > 0
+
+
+def test_every_exported_mdnvae_symbol_is_declared():
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if " T " in ln and "mdnvae_" in ln and "_Z" not in ln}
+    declared = {n for n, _, _ in _lib.declared_functions()}
+    assert exported == declared, f"undeclared exports: {exported - declared}; missing: {declared - exported}"
+
+
+def test_argument_rejection_needs_no_gpu():
+    lib = _lib.load()
+    # negative size is refused before anything touches the device
+    rc = lib.mdnvae_reparam_fwd(None, None, None, None, -1, None)
+    assert rc < 0 and b"negative" in lib.mdnvae_last_error()
+    rc = lib.mdnvae_vae_loss_fwd(7, None, None, 0, 0, None, None, 0, None, None, None, None, None)
+    assert rc < 0 and b"mode" in lib.mdnvae_last_error()
+
+
+def test_host_wrappers_refuse_cpu_tensors():
+    a = torch.zeros(2, 4)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        mdnvae_amd.vae_loss(a, a, a, a, "mse")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        mdnvae_amd.reparameterize(a, a, a)

@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Micro-benchmarks of single kernels (algorithmic bytes or flops / HIP-event time)."""
+import argparse
+import json
+import sys
+import os
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import mdnvae_amd as M  # noqa: E402
+
+
+def timeit(fn, iters=20, warmup=3):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    for a, b in evs:
+        a.record()
+        fn()
+        b.record()
+    torch.cuda.synchronize()
+    ts = sorted(a.elapsed_time(b) for a, b in evs)
+    return ts[len(ts) // 2] * 1e-3, ts[0] * 1e-3
+
+
+def bench_loss(B, N, L=68):
+    D = N * N
+    dev = "cuda:0"
+    r = torch.randn(B, D, device=dev) * 0.3
+    x = torch.rand(B, D, device=dev)
+    mu = torch.randn(B, L, device=dev)
+    lv = torch.randn(B, L, device=dev) * 0.3
+    out = []
+    for mode in ("poisson_log", "poisson_rate", "mse"):
+        rr = r.abs() + 0.1 if mode == "poisson_rate" else r
+        med, best = timeit(lambda: M.vae_loss_terms(rr, x, mu, lv, mode))
+        fb = 4 * B * (2 * D + 2 * L)
+        out.append(dict(kernel="loss_fwd", mode=mode, B=B, N=N, ms=med * 1e3, GBps=fb / med / 1e9, best_GBps=fb / best / 1e9))
+        med, best = timeit(lambda: M.vae_loss_and_grads(rr, x, mu, lv, mode))
+        bb = 4 * B * (3 * D + 4 * L)
+        out.append(dict(kernel="loss_fwdbwd", mode=mode, B=B, N=N, ms=med * 1e3, GBps=bb / med / 1e9, best_GBps=bb / best / 1e9))
+    return out
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--what", default="loss")
+    ap.add_argument("--B", type=int, default=8192)
+    ap.add_argument("--N", type=int, default=87)
+    a = ap.parse_args()
+    if a.what == "loss":
+        for row in bench_loss(a.B, a.N):
+            print(json.dumps(row))
