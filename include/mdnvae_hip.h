@@ -64,6 +64,78 @@ int mdnvae_vae_loss_fwdbwd(int mode, const float* recon, const float* x, long B,
                            const float* logvar, long L, float* grad_recon, float* grad_mu,
                            float* grad_logvar, void* workspace, float* loss_out, void* stream);
 
+/* ---- multi-channel chain decoder ---------------------------------------------------------
+ * R channels; channel r maps z [B,L] through NL small dense layers to a node vector g_r [B,N];
+ * out[b, i*N+j] = f( sum_r g_r[b,i]*g_r[b,j] ).  Serves
+ *   - the five-branch rank-1 decoder, plain or masked:  function/VAE_CNN_NN.py:169-189,
+ *     function/VAE-CNN-GCN.py:166-185, function_FC/VAE_CNN_GCN.py:166-191, function_FC/VAE_CNN_NN.py:165-197
+ *   - the multi-channel k-NN GCN decoder:  function/MM_Gate.py:84-93, 104-108, 126-138.
+ * All layer weights are packed into one zero-padded panel: wt[r][l][k][n] (k < fan-in; row
+ * MDNVAE_DEC_KP-1 = bias) and its transpose wn[r][l][n][k]; masks and the k-NN adjacency are
+ * applied by the pack calls.  N <= MDNVAE_DEC_NP-1, L <= MDNVAE_DEC_KP-1, R <= 8, NL <= 4. */
+#define MDNVAE_DEC_NP 96
+#define MDNVAE_DEC_KP 96
+
+enum { MDNVAE_ACT_NONE = 0, MDNVAE_ACT_SIGMOID = 1, MDNVAE_ACT_TANH = 2, MDNVAE_ACT_RELU = 3 };
+
+size_t mdnvae_decoder_panel_floats(int R, int NL);
+
+/* One layer's panel slices (wt, wn point at the [KP][NP] / [NP][KP] slice of layer (r,l)).
+ * Linear or GraphCNN layer: w [n_out,K], optional 0/1 mask [n_out,K] (function/VAE-CNN-GCN.py:62-78),
+ * optional bias [n_out]. */
+int mdnvae_decoder_pack_linear(const float* w, const float* mask, const float* bias, int n_out, int K,
+                               float* wt, float* wn, void* stream);
+/* GCNLayer: w [N,kn], adjacency adj [N,kn] (int32 node ids), bias [N]  (function/MM_Gate.py:75-93). */
+int mdnvae_decoder_pack_gcn(const float* w, const int* adj, const float* bias, int N, int kn, float* wt,
+                            float* wn, void* stream);
+/* Gradient panel slice dwt [KP][NP] (row KP-1 = bias gradient) back to parameter layout. */
+int mdnvae_decoder_unpack_linear_grad(const float* dwt, const float* mask, int n_out, int K, float* dw,
+                                      float* db, void* stream);
+int mdnvae_decoder_unpack_gcn_grad(const float* dwt, const int* adj, int N, int kn, float* dw, float* db,
+                                   void* stream);
+
+/* acts: activation code of layer l in bits [2l, 2l+1]; epi_act: activation applied to the sum of
+ * outer products; icpt_w/icpt_b [N*N] (both or neither): out = out*icpt_w + icpt_b (the GraphCNN
+ * intercept with identity mask, function/VAE-CNN-GCN.py:150,184,219-220); do_exp: out = exp(out);
+ * drop [R,B,N]: optional multiplier on the final node vectors (dropout masks already scaled);
+ * xlat [B,N] = sum of the first xlat_channels node vectors (the reference returns h1+h2+h3+h4). */
+int mdnvae_decoder_fwd(const float* z, const float* wt, int B, int N, int L, int R, int NL, int acts,
+                       int epi_act, const float* icpt_w, const float* icpt_b, int do_exp, const float* drop,
+                       int xlat_channels, float* out, float* xlat, void* stream);
+
+/* floats in each of layer_in / layer_dpre for a batch of B */
+size_t mdnvae_decoder_bwd_rows_floats(int B, int R, int NL);
+/* Backward: grad_out [B,N*N], optional grad_xlat [B,N] -> grad_z [B,L]; per layer the input rows
+ * layer_in [R][NL][B][KP] (column KP-1 = 1) and pre-activation gradients layer_dpre [R][NL][B][NP],
+ * from which the packed weight gradient of layer (r,l) is layer_in^T . layer_dpre (a library GEMM);
+ * with an intercept, grad_times_act [B,N*N] = (grad_out [*out if do_exp]) * act(sum), whose column
+ * sums are the intercept-weight gradient. */
+int mdnvae_decoder_bwd(const float* z, const float* wt, const float* wn, int B, int N, int L, int R, int NL,
+                       int acts, int epi_act, const float* icpt_w, const float* icpt_b, int do_exp,
+                       const float* drop, int xlat_channels, const float* grad_out, const float* grad_xlat,
+                       float* grad_z, float* layer_in, float* layer_dpre, float* grad_times_act, void* stream);
+
+/* out_a[e] = sum_b a[b,e], out_c[e] = sum_b c[b,e] in a fixed order (bias / diagonal-weight gradients). */
+size_t mdnvae_colsum2_workspace_floats(int B, int D);
+int mdnvae_colsum2(const float* a, const float* c, int B, int D, float* workspace, float* out_a, float* out_c,
+                   void* stream);
+
+/* y = exp(x), y = a*b: the `torch.exp` after the dense intercept (function/VAE_CNN_NN.py:188) and its backward. */
+int mdnvae_exp(const float* x, float* y, long n, void* stream);
+int mdnvae_mul(const float* a, const float* b, float* y, long n, void* stream);
+
+/* ---- companions of the library GEMMs for plain dense layers ----------------------------
+ * (FNN towers function/MM_Gate.py:157-162; cVAE function_FC_SC/SC-FC.py:95-113; latent heads
+ * function/VAE_CNN_NN.py:160-161; dense intercept :187).  The matrix products themselves are
+ * rocBLAS calls made by the host; these kernels do the rest of F.linear + activation. */
+/* y[r,c] = act(y[r,c] + bias[c]) in place (bias may be NULL). */
+int mdnvae_bias_act(float* y, const float* bias, long rows, int cols, int act, void* stream);
+/* grad_pre = grad_y * act'(.) expressed through the activation output y. */
+int mdnvae_act_bwd(const float* y, const float* grad_y, float* grad_pre, long n, int act, void* stream);
+/* out[e] = sum_b a[b,e], fixed summation order (bias gradients). */
+size_t mdnvae_colsum_workspace_floats(int B, int D);
+int mdnvae_colsum(const float* a, int B, int D, float* workspace, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -84,3 +84,8 @@ def call(fname, *args):
 
 def workspace_bytes(query):
     return int(getattr(load(), query)())
+
+
+def workspace_bytes_f(query, *args):
+    """Workspace size in FLOATS from a *_workspace_floats(...) query."""
+    return int(getattr(load(), query)(*args))

@@ -1,0 +1,109 @@
+// Elementwise / reduction companions of the library GEMMs used for the plain dense layers
+// (FNN encoder towers function/MM_Gate.py:157-162, cVAE function_FC_SC/SC-FC.py:95-113, the two
+// latent heads function/VAE_CNN_NN.py:160-161 and the dense intercept :187): bias + activation in
+// place after the GEMM, the activation's backward, and fixed-order column sums for bias gradients.
+#include "common.h"
+#include "../../include/mdnvae_hip.h"
+
+namespace mdnvae {
+
+constexpr int A_NONE = 0, A_SIGMOID = 1, A_TANH = 2, A_RELU = 3;
+
+__device__ __forceinline__ float dact(int act, float v) {
+    if (act == A_SIGMOID) return sigmoidf_(v);
+    if (act == A_TANH) return tanhf(v);
+    if (act == A_RELU) return fmaxf(v, 0.0f);
+    return v;
+}
+__device__ __forceinline__ float dslope(int act, float h) {
+    if (act == A_SIGMOID) return h * (1.0f - h);
+    if (act == A_TANH) return 1.0f - h * h;
+    if (act == A_RELU) return h > 0.0f ? 1.0f : 0.0f;
+    return 1.0f;
+}
+
+// y[r][c] = act(y[r][c] + bias[c])
+__global__ __launch_bounds__(256) void bias_act_kernel(float* __restrict__ y, const float* __restrict__ bias, long rows,
+                                                       int cols, int act) {
+    const long n = rows * cols;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % cols);
+        float v = y[i];
+        if (bias) v += bias[c];
+        y[i] = dact(act, v);
+    }
+}
+
+// g[i] *= act'(y[i])   (y = activation output)
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ y, const float* __restrict__ gin,
+                                                      float* __restrict__ gout, long n, int act) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+        gout[i] = gin[i] * dslope(act, y[i]);
+}
+
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ a, int B, int D,
+                                                             int rows_per_block, float* __restrict__ part) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    const int b0 = blockIdx.y * rows_per_block;
+    const int b1 = min(B, b0 + rows_per_block);
+    if (e >= D) return;
+    float s = 0.f;
+    for (int b = b0; b < b1; ++b) s += a[(long)b * D + e];
+    part[(long)blockIdx.y * D + e] = s;
+}
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, int nparts, int D,
+                                                           float* __restrict__ out) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= D) return;
+    float s = 0.f;
+    for (int p = 0; p < nparts; ++p) s += part[(long)p * D + e];
+    out[e] = s;
+}
+
+}  // namespace mdnvae
+using namespace mdnvae;
+
+static int ew_grid(long n) {
+    long g = (n + 255) / 256;
+    return (int)(g > 4096 ? 4096 : (g < 1 ? 1 : g));
+}
+
+extern "C" {
+
+int mdnvae_bias_act(float* y, const float* bias, long rows, int cols, int act, void* stream) {
+    MV_REQUIRE(rows >= 0 && cols >= 1, E_ARG, "mdnvae_bias_act: bad shape");
+    MV_REQUIRE(act >= 0 && act <= MDNVAE_ACT_RELU, E_ARG, "mdnvae_bias_act: unknown activation %d", act);
+    if (rows == 0) return 0;
+    MV_REQUIRE(y, E_ARG, "mdnvae_bias_act: null pointer");
+    hipLaunchKernelGGL(bias_act_kernel, dim3(ew_grid(rows * cols)), dim3(256), 0, (hipStream_t)stream, y, bias, rows,
+                       cols, act);
+    MV_LAUNCH_CHECK("bias_act_kernel");
+    return 0;
+}
+
+int mdnvae_act_bwd(const float* y, const float* grad_y, float* grad_pre, long n, int act, void* stream) {
+    MV_REQUIRE(n >= 0, E_ARG, "mdnvae_act_bwd: negative size");
+    MV_REQUIRE(act >= 0 && act <= MDNVAE_ACT_RELU, E_ARG, "mdnvae_act_bwd: unknown activation %d", act);
+    if (n == 0) return 0;
+    MV_REQUIRE(y && grad_y && grad_pre, E_ARG, "mdnvae_act_bwd: null pointer");
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, y, grad_y, grad_pre, n, act);
+    MV_LAUNCH_CHECK("act_bwd_kernel");
+    return 0;
+}
+
+size_t mdnvae_colsum_workspace_floats(int B, int D) { return (size_t)((B + 63) / 64) * D; }
+
+int mdnvae_colsum(const float* a, int B, int D, float* workspace, float* out, void* stream) {
+    MV_REQUIRE(B >= 1 && D >= 1, E_ARG, "mdnvae_colsum: empty input");
+    MV_REQUIRE(a && workspace && out, E_ARG, "mdnvae_colsum: null pointer");
+    const int rows = 64, nparts = (B + rows - 1) / rows;
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3((D + 255) / 256, nparts), dim3(256), 0, (hipStream_t)stream, a, B, D,
+                       rows, workspace);
+    MV_LAUNCH_CHECK("colsum_partial_kernel");
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((D + 255) / 256), dim3(256), 0, (hipStream_t)stream, workspace, nparts,
+                       D, out);
+    MV_LAUNCH_CHECK("colsum_final_kernel");
+    return 0;
+}
+
+}  // extern "C"

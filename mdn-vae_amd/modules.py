@@ -1,0 +1,378 @@
+"""Module surface of the reference scripts, computing through the HIP library.
+
+Class, attribute and state-dict names follow the reference so that a script can swap its
+own `VAE` / `loss_function` for these:
+    conv-encoder VAEs   function/VAE_CNN_NN.py:100-195, function/VAE-CNN-GCN.py:97-199,
+                        function_FC/VAE_CNN_GCN.py:97-205, function_FC/VAE_CNN_NN.py:95-203
+    GCN-decoder VAE     function/MM_Gate.py:75-177
+    conditional VAE     function_FC_SC/SC-FC.py:79-119
+Submodules are created in the reference's order, so `torch.manual_seed(s); VAE()` draws the
+same initial weights as the reference class does under the same seed.
+"""
+import math
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import ops
+
+
+# ---------------------------------------------------------------------------------------
+# parameter holders
+# ---------------------------------------------------------------------------------------
+class Linear(nn.Linear):
+    """nn.Linear whose forward is a library GEMM plus the HIP bias/activation kernel."""
+
+    def forward(self, x, act=None):
+        return ops.linear_act(x, self.weight, self.bias, act)
+
+
+class GraphCNN(Linear):
+    """Masked linear layer (function/VAE-CNN-GCN.py:62-78): set_mask zeroes the masked
+    weights once, forward multiplies by the mask again."""
+
+    def __init__(self, in_features, out_features, bias=True):
+        super().__init__(in_features, out_features, bias)
+        self.mask_flag = False
+        self.register_buffer("mask", None, persistent=False)
+
+    def set_mask(self, mask):
+        mask = torch.as_tensor(mask, dtype=torch.float32).to(self.weight.device)
+        self.mask = mask.contiguous()
+        with torch.no_grad():
+            self.weight.mul_(self.mask)
+        self.mask_flag = True
+
+    def get_mask(self):
+        return self.mask
+
+    def forward(self, x, act=None):
+        w = ops.mul(self.weight, self.mask) if self.mask_flag else self.weight
+        return ops.linear_act(x, w, self.bias, act)
+
+
+class DiagonalIntercept(nn.Module):
+    """`GraphCNN(D, D)` under an identity mask (function/VAE-CNN-GCN.py:150,219-220) is a
+    per-edge scale and shift; only the diagonal is stored.  A dense [D,D] weight in a
+    state dict is accepted (its diagonal is taken) and `dense_weight()` gives one back."""
+
+    def __init__(self, features):
+        super().__init__()
+        self.features = features
+        # draw what nn.Linear(D, D) would draw, keep the diagonal
+        bound = 1.0 / math.sqrt(features)
+        rows = []
+        for r0 in range(0, features, 512):   # kaiming_uniform(a=sqrt(5)) == U(-1/sqrt(fan_in), +)
+            blk = torch.empty(min(512, features - r0), features).uniform_(-bound, bound)
+            rows.append(torch.diagonal(blk, offset=r0).clone())
+        self.weight = nn.Parameter(torch.cat(rows))
+        self.bias = nn.Parameter(torch.empty(features).uniform_(-bound, bound))
+        self.mask_flag = True
+
+    def set_mask(self, mask):
+        """Accepts the identity mask of the reference scripts (anything else is not a diagonal layer)."""
+        m = torch.as_tensor(mask)
+        if m.dim() == 2:
+            if m.shape != (self.features, self.features) or not bool((m.diagonal() == 1).all()) \
+                    or int(m.sum().item()) != self.features:
+                raise ValueError("DiagonalIntercept only supports the identity mask")
+
+    def dense_weight(self):
+        return torch.diag(self.weight.detach())
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        key = prefix + "weight"
+        if key in state_dict and state_dict[key].dim() == 2:
+            state_dict[key] = torch.diagonal(state_dict[key]).clone()
+        super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+
+    def forward(self, x):
+        return ops.diag_affine(x, self.weight, self.bias)
+
+
+class _Slots(nn.Module):
+    """A container whose children are registered under the given names (keeps the reference's
+    nn.Sequential indices in the state dict without instantiating the parameter-free layers)."""
+
+    def __init__(self, named):
+        super().__init__()
+        for name, mod in named:
+            self.add_module(str(name), mod)
+
+    def __getitem__(self, idx):
+        return self._modules[str(idx)]
+
+
+class _ResBlockParams(nn.Module):
+    def __init__(self, ch):
+        super().__init__()
+        self.block = _Slots([(1, nn.Conv2d(ch, ch, 3)), (5, nn.Conv2d(ch, ch, 3))])
+
+
+def _dev_int(a, device):
+    return torch.as_tensor(np.asarray(a, dtype=np.int32), device=device).contiguous()
+
+
+# ---------------------------------------------------------------------------------------
+# conv-encoder VAE family
+# ---------------------------------------------------------------------------------------
+class ConvVAE(nn.Module):
+    """Conv/ResNet encoder + five-branch rank-1 decoder.
+
+    decoder:  'nn'   plain second layers                          (VAE_CNN_NN scripts)
+              'gcn'  GraphCNN second layers + diagonal intercept  (VAE-CNN-GCN scripts)
+    intercept: 'dense' | 'diag' | 'none';  final: 'exp' | 'none';  dropout: p or 0
+    """
+
+    def __init__(self, decoder="nn", intercept="dense", final="exp", dropout=0.0, n_nodes=68, latent_dim=68,
+                 act="sigmoid"):
+        super().__init__()
+        self.n_nodes, self.latent_dim = n_nodes, latent_dim
+        self.decoder_kind, self.intercept_kind, self.final, self.act = decoder, intercept, final, act
+        init_depth = 48
+        ch = init_depth * 4
+        ec = [(1, nn.Conv2d(1, init_depth, 7)), (4, nn.Conv2d(init_depth, init_depth * 2, 3, stride=2, padding=1)),
+              (7, nn.Conv2d(init_depth * 2, ch, 3, stride=2, padding=1))]
+        ec += [(10 + i, _ResBlockParams(ch)) for i in range(5)]
+        self.ec = _Slots(ec)
+        self.n_res = 5
+        s = (n_nodes + 1) // 2
+        s = (s + 1) // 2
+        pooled = s // 8
+        if pooled < 1:
+            raise ValueError(f"n_nodes={n_nodes} is too small for the 8x8 max pool")
+        flat = ch * pooled * pooled
+        self.fc_mean = Linear(flat, latent_dim)
+        self.fc_log_var = Linear(flat, latent_dim)
+        N = n_nodes
+        for name in ("fc3", "fc32", "fc33", "fc34", "fc35"):
+            setattr(self, name, Linear(latent_dim, N))
+        second = GraphCNN if decoder == "gcn" else Linear
+        for name in ("fc4", "fc5", "fc6", "fc7", "fc8"):
+            setattr(self, name, second(N, N))
+        self.dropout_p = float(dropout)
+        if intercept == "dense":
+            self.fcintercept = Linear(N * N, N * N)
+        elif intercept == "diag":
+            self.fcintercept = DiagonalIntercept(N * N)
+        self._spec = None
+
+    # -- encoder -------------------------------------------------------------------
+    def conv_params(self):
+        p = [self.ec[1], self.ec[4], self.ec[7]]
+        for i in range(self.n_res):
+            blk = self.ec[10 + i].block
+            p += [blk[1], blk[5]]
+        return p
+
+    def encode(self, x):
+        feat = ops.conv_encoder(x.reshape(-1, self.n_nodes * self.n_nodes), self.n_nodes,
+                                [(m.weight, m.bias) for m in self.conv_params()])
+        return self.fc_mean(feat), self.fc_log_var(feat)
+
+    def reparameterize(self, mu, logvar, eps=None):
+        return ops.reparameterize(mu, logvar, eps)
+
+    # -- decoder -------------------------------------------------------------------
+    def set_mask(self, masks):
+        """masks[0..4]: [N,N] 0/1 masks of fc4..fc8, masks[5]: identity for the intercept
+        (function/VAE-CNN-GCN.py:193-199)."""
+        for name, m in zip(("fc4", "fc5", "fc6", "fc7", "fc8"), masks[:5]):
+            getattr(self, name).set_mask(m)
+        if len(masks) > 5 and hasattr(self, "fcintercept") and hasattr(self.fcintercept, "set_mask"):
+            self.fcintercept.set_mask(masks[5])
+        self._spec = None
+
+    def _chain_spec(self):
+        if self._spec is None:
+            firsts = ("fc3", "fc32", "fc33", "fc34", "fc35")
+            seconds = ("fc4", "fc5", "fc6", "fc7", "fc8")
+            masks = [getattr(getattr(self, s), "mask", None) if getattr(getattr(self, s), "mask_flag", False) else None
+                     for s in seconds]
+            if all(m is None for m in masks):
+                mask = None
+            elif all(m is not None and torch.equal(m, masks[0]) for m in masks):
+                mask = masks[0]
+            else:
+                raise NotImplementedError("the fused decoder needs the five second-layer masks to be equal, "
+                                          "as they are in the reference scripts")
+            layers = [dict(kind="linear", act=self.act), dict(kind="linear", act=self.act, mask=mask)]
+            self._spec = ops.ChainSpec(self.n_nodes, self.latent_dim, 5, layers, epi_act=self.act, xlat_channels=4)
+            self._names = list(zip(firsts, seconds))
+        return self._spec
+
+    def decode(self, z):
+        spec = self._chain_spec()
+        params = []
+        for a, b in self._names:
+            ma, mb = getattr(self, a), getattr(self, b)
+            params += [ma.weight, ma.bias, mb.weight, mb.bias]
+        drop = None
+        if self.dropout_p > 0 and self.training:
+            keep = 1.0 - self.dropout_p
+            drop = torch.bernoulli(torch.full((5, z.shape[0], self.n_nodes), keep, device=z.device)).div_(keep)
+        iw = ib = None
+        if self.intercept_kind == "diag":
+            iw, ib = self.fcintercept.weight, self.fcintercept.bias
+        out, xlat = ops.chain_decoder(z, spec, params, iw, ib, drop)
+        if self.intercept_kind == "dense":
+            out = self.fcintercept(out)
+        if self.final == "exp":
+            out = ops.exp(out)
+        return out, xlat
+
+    def forward(self, x, eps=None):
+        mu, logvar = self.encode(x)
+        z = self.reparameterize(mu, logvar, eps)
+        recon, x_latent = self.decode(z)
+        return recon, mu, logvar, x_latent
+
+
+# ---------------------------------------------------------------------------------------
+# GCN-decoder VAE (function/MM_Gate.py)
+# ---------------------------------------------------------------------------------------
+class GCNLayer(nn.Module):
+    def __init__(self, n_nodes=68, k=32):
+        super().__init__()
+        self.n_nodes, self.k = n_nodes, k
+        self.weight = nn.Parameter(torch.zeros(n_nodes, k))
+        nn.init.xavier_uniform_(self.weight)
+        self.bias = nn.Parameter(torch.zeros(n_nodes))
+
+
+class ChannelGCN(nn.Module):
+    def __init__(self, n_nodes=68, k=32, n_layers=3):
+        super().__init__()
+        self.n_layers = n_layers
+        self.layers = nn.ModuleList([GCNLayer(n_nodes, k) for _ in range(n_layers)])
+
+
+class MultiChannelGCNDecoder(nn.Module):
+    """function/MM_Gate.py:113-138 as one fused chain-decoder launch."""
+
+    def __init__(self, R=5, n_nodes=68, k=32, n_layers=3, latent_dim=68):
+        super().__init__()
+        self.R, self.n_nodes, self.k, self.n_layers, self.latent_dim = R, n_nodes, k, n_layers, latent_dim
+        self.init_fc = nn.ModuleList([Linear(latent_dim, n_nodes) for _ in range(R)])
+        self.channel_gcns = nn.ModuleList([ChannelGCN(n_nodes, k, n_layers) for _ in range(R)])
+        self._adj_key = None
+        self._adj = None
+        self._spec = None
+
+    def _adjacency(self, adjacency, device):
+        arr = np.asarray([list(map(int, a)) for a in adjacency], dtype=np.int32) if not isinstance(adjacency, torch.Tensor) \
+            else adjacency.detach().cpu().numpy().astype(np.int32)
+        key = (arr.tobytes(), str(device))
+        if key != self._adj_key:
+            if arr.shape != (self.n_nodes, self.k):
+                raise ValueError(f"adjacency must be [{self.n_nodes},{self.k}], got {arr.shape}")
+            if arr.min() < 0 or arr.max() >= self.n_nodes:
+                raise ValueError("adjacency holds node ids outside [0, n_nodes)")
+            self._adj = torch.from_numpy(arr).to(device).contiguous()
+            self._adj_key = key
+            layers = [dict(kind="linear", act=None)] + [dict(kind="gcn", act="sigmoid", adj=self._adj)
+                                                        for _ in range(self.n_layers)]
+            self._spec = ops.ChainSpec(self.n_nodes, self.latent_dim, self.R, layers, epi_act=None, xlat_channels=0)
+        return self._adj
+
+    def chain_params(self):
+        params = []
+        for r in range(self.R):
+            params += [self.init_fc[r].weight, self.init_fc[r].bias]
+            for ly in self.channel_gcns[r].layers:
+                params += [ly.weight, ly.bias]
+        return params
+
+    def forward(self, z, adjacency):
+        self._adjacency(adjacency, z.device)
+        out, _ = ops.chain_decoder(z, self._spec, self.chain_params())
+        return out
+
+
+class GCNVAE(nn.Module):
+    """`VAE` of function/MM_Gate.py:143-177."""
+
+    def __init__(self, R=5, n_nodes=68, k=32, n_layers=3, latent_dim=68):
+        super().__init__()
+        self.n_nodes = n_nodes
+        D = n_nodes * n_nodes
+        self.fc11 = Linear(D, 1024)
+        self.fc12 = Linear(D, 1024)
+        self.fc111 = Linear(1024, 128)
+        self.fc222 = Linear(1024, 128)
+        self.fc21 = Linear(128, latent_dim)
+        self.fc22 = Linear(128, latent_dim)
+        self.decoder = MultiChannelGCNDecoder(R=R, n_nodes=n_nodes, k=k, n_layers=n_layers, latent_dim=latent_dim)
+
+    def encode(self, x):
+        h11 = self.fc111(self.fc11(x, act="relu"), act="relu")
+        h12 = self.fc222(self.fc12(x, act="relu"), act="relu")
+        return self.fc21(h11), self.fc22(h12)
+
+    def reparameterize(self, mu, logvar, eps=None):
+        return ops.reparameterize(mu, logvar, eps)
+
+    def decode(self, z, adjacency):
+        return self.decoder(z, adjacency)
+
+    def forward(self, x, adjacency, eps=None):
+        x = x.reshape(-1, self.n_nodes * self.n_nodes)
+        mu, logvar = self.encode(x)
+        z = self.reparameterize(mu, logvar, eps)
+        return self.decode(z, adjacency), mu, logvar
+
+
+# ---------------------------------------------------------------------------------------
+# conditional VAE (function_FC_SC/SC-FC.py)
+# ---------------------------------------------------------------------------------------
+class cVAE(nn.Module):
+    def __init__(self, in_dim=68 * 68, latent_dim=64, hidden_dim=1024):
+        super().__init__()
+        self.in_dim, self.latent_dim = in_dim, latent_dim
+        self.fc1 = Linear(in_dim * 2, hidden_dim)
+        self.fc2 = Linear(hidden_dim, hidden_dim)
+        self.fc_mu = Linear(hidden_dim, latent_dim)
+        self.fc_logvar = Linear(hidden_dim, latent_dim)
+        self.fc3 = Linear(latent_dim + in_dim, hidden_dim)
+        self.fc4 = Linear(hidden_dim, hidden_dim)
+        self.fc_out = Linear(hidden_dim, in_dim)
+
+    def encode(self, fc, sc):
+        h = self.fc2(self.fc1(torch.cat([fc, sc], dim=1), act="relu"), act="relu")
+        return self.fc_mu(h), self.fc_logvar(h)
+
+    def reparameterize(self, mu, logvar, eps=None):
+        return ops.reparameterize(mu, logvar, eps)
+
+    def decode(self, z, fc):
+        h = self.fc4(self.fc3(torch.cat([z, fc], dim=1), act="relu"), act="relu")
+        return self.fc_out(h, act="sigmoid")
+
+    def forward(self, fc, sc, eps=None):
+        mu, logvar = self.encode(fc, sc)
+        z = self.reparameterize(mu, logvar, eps)
+        return self.decode(z, fc), mu, logvar
+
+
+# ---------------------------------------------------------------------------------------
+# loss functions with the reference signatures
+# ---------------------------------------------------------------------------------------
+def loss_function_poisson_rate(recon_x, x, mu, logvar):
+    """function/VAE_CNN_NN.py:197-200"""
+    return ops.vae_loss(recon_x, x, mu, logvar, "poisson_rate")
+
+
+def loss_function_poisson_log(recon_x, x, mu, logvar):
+    """function/MM_Gate.py:179-182, function/VAE-CNN-GCN.py:201-204"""
+    return ops.vae_loss(recon_x, x, mu, logvar, "poisson_log")
+
+
+def loss_function_mse(recon_x, x, mu, logvar):
+    """function_FC/VAE_CNN_GCN.py:207-211"""
+    return ops.vae_loss(recon_x, x, mu, logvar, "mse")
+
+
+def loss_function_mse_terms(recon_sc, sc, mu, logvar):
+    """function_FC_SC/SC-FC.py:124-127: (total, reconstruction, KL)."""
+    return ops.vae_loss_terms(recon_sc, sc, mu, logvar, "mse")

@@ -98,3 +98,247 @@ def vae_loss_and_grads(recon, x, mu, logvar, mode):
     call("mdnvae_vae_loss_fwdbwd", RECON_MODES[mode], ptr(recon, "recon"), ptr(x, "x"), B, D, ptr(mu, "mu"),
          ptr(logvar, "logvar"), L, ptr(grecon), ptr(gmu), ptr(glv), ws.data_ptr(), ptr(out), stream())
     return out, grecon, gmu, glv
+
+
+# ---------------------------------------------------------------------------------------
+# dense layers: library GEMM + HIP bias/activation kernels
+# ---------------------------------------------------------------------------------------
+ACTS = {None: 0, "none": 0, "sigmoid": 1, "tanh": 2, "relu": 3}
+
+
+def _colsum(a):
+    B, D = a.shape
+    ws = torch.empty(_lib.workspace_bytes_f("mdnvae_colsum_workspace_floats", B, D), dtype=torch.float32, device=a.device)
+    out = torch.empty(D, dtype=torch.float32, device=a.device)
+    call("mdnvae_colsum", ptr(a), B, D, ptr(ws), ptr(out), stream())
+    return out
+
+
+class _LinearAct(torch.autograd.Function):
+    """act(x @ W^T + b): the product is a rocBLAS GEMM, bias+activation and the backward's
+    elementwise / column-sum parts are HIP kernels."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, act):
+        x, weight = _c(x), _c(weight)
+        ptr(x, "x"), ptr(weight, "weight")
+        y = torch.mm(x, weight.t())
+        call("mdnvae_bias_act", ptr(y), ptr(bias, "bias"), y.shape[0], y.shape[1], act, stream())
+        ctx.save_for_backward(x, weight, y)
+        ctx.act = act
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight, y = ctx.saved_tensors
+        gy = _c(gy)
+        if ctx.act != 0:
+            gpre = torch.empty_like(gy)
+            call("mdnvae_act_bwd", ptr(y), ptr(gy), ptr(gpre), gy.numel(), ctx.act, stream())
+        else:
+            gpre = gy
+        gx = torch.mm(gpre, weight) if ctx.needs_input_grad[0] else None
+        gw = torch.mm(gpre.t(), x) if ctx.needs_input_grad[1] else None
+        gb = _colsum(gpre) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        return gx, gw, gb, None
+
+
+def linear_act(x, weight, bias=None, act=None):
+    return _LinearAct.apply(x, weight, bias, ACTS[act])
+
+
+class _Exp(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _c(x)
+        y = torch.empty_like(x)
+        call("mdnvae_exp", ptr(x, "x"), ptr(y), x.numel(), stream())
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (y,) = ctx.saved_tensors
+        gy = _c(gy)
+        gx = torch.empty_like(gy)
+        call("mdnvae_mul", ptr(gy), ptr(y), ptr(gx), gy.numel(), stream())
+        return gx
+
+
+def exp(x):
+    return _Exp.apply(x)
+
+
+class _Mul(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = _c(a), _c(b)
+        if a.shape != b.shape:
+            raise RuntimeError(f"mul: shapes {tuple(a.shape)} and {tuple(b.shape)} differ")
+        y = torch.empty_like(a)
+        call("mdnvae_mul", ptr(a, "a"), ptr(b, "b"), ptr(y), a.numel(), stream())
+        ctx.save_for_backward(a, b)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        g = _c(g)
+        ga = gb = None
+        if ctx.needs_input_grad[0]:
+            ga = torch.empty_like(g)
+            call("mdnvae_mul", ptr(g), ptr(b), ptr(ga), g.numel(), stream())
+        if ctx.needs_input_grad[1]:
+            gb = torch.empty_like(g)
+            call("mdnvae_mul", ptr(g), ptr(a), ptr(gb), g.numel(), stream())
+        return ga, gb
+
+
+def mul(a, b):
+    return _Mul.apply(a, b)
+
+
+def diag_affine(x, w, b):
+    """x[B,D]*w[D] + b[D] (stand-alone use of the diagonal intercept layer)."""
+    y = mul(x, w.unsqueeze(0).expand_as(x).contiguous())
+    return _LinearBias.apply(y, b)
+
+
+class _LinearBias(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y, bias):
+        y = y.clone()
+        call("mdnvae_bias_act", ptr(y), ptr(_c(bias), "bias"), y.shape[0], y.shape[1], 0, stream())
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _c(g)
+        return g, _colsum(g)
+
+
+# ---------------------------------------------------------------------------------------
+# chain decoder
+# ---------------------------------------------------------------------------------------
+DEC_NP = 96
+DEC_KP = 96
+
+
+class ChainSpec:
+    """Static description of a chain decoder: R channels x NL layers.
+    layers[l] = dict(kind='linear'|'gcn', act=..., mask=Tensor|None, adj=IntTensor|None)."""
+
+    def __init__(self, n_nodes, latent_dim, channels, layers, epi_act=None, xlat_channels=0, do_exp=False):
+        self.N, self.L, self.R = int(n_nodes), int(latent_dim), int(channels)
+        self.layers = layers
+        self.NL = len(layers)
+        self.epi_act = ACTS[epi_act]
+        self.xlat_channels = int(xlat_channels)
+        self.do_exp = bool(do_exp)
+        self.acts = 0
+        for l, ly in enumerate(layers):
+            a = ACTS[ly.get("act")]
+            if a == 3:
+                raise ValueError("chain decoder layers support none/sigmoid/tanh")
+            self.acts |= a << (2 * l)
+
+
+def _pack_panels(spec, params, device):
+    """params: flat list [w(r=0,l=0), b(0,0), w(0,1), b(0,1), ...] -> (wt, wn) panels."""
+    n = spec.R * spec.NL * DEC_KP * DEC_NP
+    wt = torch.empty(n, dtype=torch.float32, device=device)
+    wn = torch.empty(n, dtype=torch.float32, device=device)
+    sl = DEC_KP * DEC_NP * 4
+    st = stream()
+    for r in range(spec.R):
+        for l, ly in enumerate(spec.layers):
+            w, b = params[2 * (r * spec.NL + l)], params[2 * (r * spec.NL + l) + 1]
+            off = (r * spec.NL + l) * sl
+            if ly["kind"] == "linear":
+                n_out, K = w.shape
+                call("mdnvae_decoder_pack_linear", ptr(_c(w), "weight"), ptr(ly.get("mask"), "mask"), ptr(b, "bias"),
+                     n_out, K, wt.data_ptr() + off, wn.data_ptr() + off, st)
+            else:
+                N, kn = w.shape
+                call("mdnvae_decoder_pack_gcn", ptr(_c(w), "weight"), ptr(ly["adj"], "adjacency", torch.int32),
+                     ptr(b, "bias"), N, kn, wt.data_ptr() + off, wn.data_ptr() + off, st)
+    return wt, wn
+
+
+class _ChainDecoder(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z, spec, icpt_w, icpt_b, drop, *params):
+        z = _c(z)
+        B = z.shape[0]
+        if z.shape[1] != spec.L:
+            raise RuntimeError(f"decoder: z has {z.shape[1]} columns, expected latent_dim {spec.L}")
+        dev = z.device
+        wt, wn = _pack_panels(spec, params, dev)
+        D = spec.N * spec.N
+        out = torch.empty(B, D, dtype=torch.float32, device=dev)
+        xlat = torch.empty(B, spec.N, dtype=torch.float32, device=dev) if spec.xlat_channels else None
+        call("mdnvae_decoder_fwd", ptr(z, "z"), ptr(wt), B, spec.N, spec.L, spec.R, spec.NL, spec.acts, spec.epi_act,
+             ptr(icpt_w, "icpt_w"), ptr(icpt_b, "icpt_b"), int(spec.do_exp), ptr(drop, "drop"), spec.xlat_channels,
+             ptr(out), ptr(xlat), stream())
+        ctx.spec = spec
+        ctx.save_for_backward(z, wt, wn, icpt_w, icpt_b, drop)
+        ctx.param_shapes = [tuple(p.shape) if p is not None else None for p in params]
+        if xlat is None:
+            xlat = torch.zeros(B, 0, dtype=torch.float32, device=dev)
+            ctx.mark_non_differentiable(xlat)
+        return out, xlat
+
+    @staticmethod
+    def backward(ctx, gout, gxlat):
+        spec = ctx.spec
+        z, wt, wn, icpt_w, icpt_b, drop = ctx.saved_tensors
+        B = z.shape[0]
+        dev = z.device
+        gout = _c(gout)
+        if spec.xlat_channels and gxlat is not None:
+            gxlat = _c(gxlat)
+        else:
+            gxlat = None
+        RL = spec.R * spec.NL
+        hin = torch.empty(RL, B, DEC_KP, dtype=torch.float32, device=dev)
+        dp = torch.empty(RL, B, DEC_NP, dtype=torch.float32, device=dev)
+        gz = torch.empty_like(z)
+        ga = torch.empty_like(gout) if icpt_w is not None else None
+        call("mdnvae_decoder_bwd", ptr(z), ptr(wt), ptr(wn), B, spec.N, spec.L, spec.R, spec.NL, spec.acts,
+             spec.epi_act, ptr(icpt_w), ptr(icpt_b), int(spec.do_exp), ptr(drop), spec.xlat_channels, ptr(gout),
+             ptr(gxlat), ptr(gz), ptr(hin), ptr(dp), ptr(ga), stream())
+        # weight (+bias, last row) gradient of every layer: [KP x B] . [B x NP] library GEMMs
+        dwt = torch.bmm(hin.transpose(1, 2), dp)
+        grads = []
+        sl = DEC_KP * DEC_NP * 4
+        st = stream()
+        for r in range(spec.R):
+            for l, ly in enumerate(spec.layers):
+                idx = r * spec.NL + l
+                shape_w = ctx.param_shapes[2 * idx]
+                gw = torch.empty(shape_w, dtype=torch.float32, device=dev)
+                has_b = ctx.param_shapes[2 * idx + 1] is not None
+                gb = torch.empty(shape_w[0], dtype=torch.float32, device=dev) if has_b else None
+                src = dwt.data_ptr() + idx * sl
+                if ly["kind"] == "linear":
+                    call("mdnvae_decoder_unpack_linear_grad", src, ptr(ly.get("mask")), shape_w[0], shape_w[1],
+                         ptr(gw), ptr(gb), st)
+                else:
+                    call("mdnvae_decoder_unpack_gcn_grad", src, ptr(ly["adj"], "adjacency", torch.int32), shape_w[0],
+                         shape_w[1], ptr(gw), ptr(gb), st)
+                grads += [gw, gb]
+        g_iw = g_ib = None
+        if icpt_w is not None:
+            D = spec.N * spec.N
+            ws = torch.empty(_lib.workspace_bytes_f("mdnvae_colsum2_workspace_floats", B, D), dtype=torch.float32, device=dev)
+            g_ib = torch.empty(D, dtype=torch.float32, device=dev)
+            g_iw = torch.empty(D, dtype=torch.float32, device=dev)
+            call("mdnvae_colsum2", ptr(gout), ptr(ga), B, D, ptr(ws), ptr(g_ib), ptr(g_iw), st)
+        return (gz, None, g_iw, g_ib, None, *grads)
+
+
+def chain_decoder(z, spec, params, icpt_w=None, icpt_b=None, drop=None):
+    """params: flat list of (weight, bias) per (channel, layer).
+    Returns (out [B,N*N], x_latent [B,N]; empty when the spec asks for none)."""
+    return _ChainDecoder.apply(z, spec, icpt_w, icpt_b, drop, *params)
