@@ -136,6 +136,58 @@ int mdnvae_act_bwd(const float* y, const float* grad_y, float* grad_pre, long n,
 size_t mdnvae_colsum_workspace_floats(int B, int D);
 int mdnvae_colsum(const float* a, int B, int D, float* workspace, float* out, void* stream);
 
+/* ---- conv / ResNet encoder ---------------------------------------------------------------
+ * The ATen conv2d / instance_norm / relu / max_pool2d calls (and their autograd) of the encoder
+ * stack, function/VAE_CNN_NN.py:83-98 (ResidualBlock), :110-137 (ec, max_pool), :155-159 (encode).
+ * Tensors are NCHW fp32.  Convolutions run on the fp32 matrix cores; the instance norm + ReLU of
+ * the producing layer can be applied while a convolution loads its input (in_stats / relu_in),
+ * so normalised activations are only materialised where a residual skip needs them. */
+
+/* floats of the packed weight buffers of one conv layer (transposed = the data-gradient copy) */
+size_t mdnvae_conv_packed_floats(int Cout, int Cin, int KS, int transposed);
+/* w [Cout,Cin,KS,KS] -> packed_fwd ([tap][cin][cout padded]) and, if not NULL, packed_bwd
+ * ([flipped tap][cout][cin padded]) used by the data gradient.  Cin == 1: forward copy only. */
+int mdnvae_conv_pack_weights(const float* w, int Cout, int Cin, int KS, float* packed_fwd, float* packed_bwd,
+                             void* stream);
+/* transposed = 0: out [B,Cout,OH,OW] = conv(pad(act(x))) + bias, x [B,Cin,H,W]; padding zero or
+ *   reflection (nn.ReflectionPad2d, stride 1 only); in_stats [B*Cin][2] = {mean, rstd} (optional)
+ *   normalises x on load and relu_in applies ReLU after it.
+ * transposed = 1: data gradient of the convolution with (KS, stride, pad): x is the gradient
+ *   w.r.t. the conv output [B,Cin,H,W], packed_w the packed_bwd buffer, out [B,Cout,OH,OW] the
+ *   gradient w.r.t. the conv input (for a reflection-padded layer pass pad = 0 and the padded plane
+ *   size; fold it with mdnvae_inorm_bwd(folded=1) / mdnvae_fold_add).
+ * KS in {3,7}; stride in {1,2}; Cin == 1 (7x7 stem) or a multiple of 8. */
+int mdnvae_conv2d(const float* x, const float* in_stats, int relu_in, const float* packed_w, const float* bias,
+                  float* out, int B, int Cin, int H, int W, int Cout, int OH, int OW, int KS, int stride, int pad,
+                  int reflect, int transposed, void* stream);
+size_t mdnvae_conv_wgrad_workspace_floats(int B, int Cout, int Cin, int KS);
+/* grad_w [Cout,Cin,KS,KS] = sum_{b,pixels} grad_out x pad(act(x)); same x / in_stats / relu_in
+ * / padding conventions as the forward call.  3x3 multi-channel or the 7x7 single-channel stem. */
+int mdnvae_conv2d_wgrad(const float* x, const float* in_stats, int relu_in, const float* grad_out,
+                        float* workspace, float* grad_w, int B, int Cin, int H, int W, int Cout, int OH, int OW,
+                        int KS, int stride, int pad, int reflect, void* stream);
+
+/* stats[plane] = {mean, 1/sqrt(biased var + 1e-5)} of each of nplanes planes of P <= 8192 floats. */
+int mdnvae_plane_stats(const float* x, long nplanes, int P, float* stats, void* stream);
+/* out = (skip ? skip : 0) + [relu]((raw - mean)*rstd): the materialised activation
+ * (x + block(x) of the ResidualBlock when skip is given). */
+int mdnvae_norm_act_add(const float* raw, const float* stats, const float* skip, int relu, long nplanes, int P,
+                        float* out, void* stream);
+/* Backward of [relu](instance_norm(raw)): grad_raw from grad_act.  folded = 1: grad_act lives on
+ * the reflection-padded (pad 1) plane [(H+2)x(W+2)] and is folded back while loading.
+ * plane_gsum [nplanes] (optional) = per-plane sum of grad_raw (summed over the batch it is the
+ * bias gradient of the convolution that produced raw). */
+int mdnvae_inorm_bwd(const float* raw, const float* stats, const float* grad_act, int relu, int folded,
+                     long nplanes, int H, int W, float* grad_raw, float* plane_gsum, void* stream);
+/* out = (base ? base : 0) + fold(grad_padded): gradient reaching a residual block's input. */
+int mdnvae_fold_add(const float* base, const float* grad_padded, long nplanes, int H, int W, float* out,
+                    void* stream);
+/* K x K / stride K max pool over planes [H,W] -> feat [nplanes, (H/K)*(W/K)], argmax = flat
+ * position inside the plane; and its backward. */
+int mdnvae_maxpool_fwd(const float* x, long nplanes, int H, int W, int K, float* feat, int* argmax, void* stream);
+int mdnvae_maxpool_bwd(const float* grad_feat, const int* argmax, long nplanes, int H, int W, int K, float* grad_x,
+                       void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -342,3 +342,179 @@ def chain_decoder(z, spec, params, icpt_w=None, icpt_b=None, drop=None):
     """params: flat list of (weight, bias) per (channel, layer).
     Returns (out [B,N*N], x_latent [B,N]; empty when the spec asks for none)."""
     return _ChainDecoder.apply(z, spec, icpt_w, icpt_b, drop, *params)
+
+
+# ---------------------------------------------------------------------------------------
+# conv / ResNet encoder
+# ---------------------------------------------------------------------------------------
+def _conv_out(n, ks, stride, pad):
+    return (n + 2 * pad - ks) // stride + 1
+
+
+class _ConvLayer:
+    """Geometry of one encoder convolution and the calls that use it."""
+
+    def __init__(self, cin, cout, ks, stride, pad, reflect, h):
+        self.cin, self.cout, self.ks, self.stride, self.pad, self.reflect = cin, cout, ks, stride, pad, reflect
+        self.h = h
+        self.oh = _conv_out(h, ks, stride, pad)
+
+    def pack(self, w, dev, need_bwd):
+        lib = _lib.load()
+        wf = torch.empty(lib.mdnvae_conv_packed_floats(self.cout, self.cin, self.ks, 0), dtype=torch.float32, device=dev)
+        wb = None
+        if need_bwd and self.cin > 1:
+            wb = torch.empty(lib.mdnvae_conv_packed_floats(self.cout, self.cin, self.ks, 1), dtype=torch.float32, device=dev)
+        call("mdnvae_conv_pack_weights", ptr(_c(w), "conv weight"), self.cout, self.cin, self.ks, ptr(wf), ptr(wb), stream())
+        return wf, wb
+
+    def fwd(self, x, stats, relu_in, wf, bias, B):
+        out = torch.empty(B, self.cout, self.oh, self.oh, dtype=torch.float32, device=x.device)
+        call("mdnvae_conv2d", ptr(x), ptr(stats), int(relu_in), ptr(wf), ptr(bias, "conv bias"), ptr(out), B, self.cin,
+             self.h, self.h, self.cout, self.oh, self.oh, self.ks, self.stride, self.pad, int(self.reflect), 0, stream())
+        return out
+
+    def dgrad(self, gout, wb, B):
+        """Gradient w.r.t. the conv input; for reflection-padded layers on the padded plane."""
+        if self.reflect:
+            oh, pad = self.h + 2 * self.pad, 0
+        else:
+            oh, pad = self.h, self.pad
+        gin = torch.empty(B, self.cin, oh, oh, dtype=torch.float32, device=gout.device)
+        call("mdnvae_conv2d", ptr(gout), None, 0, ptr(wb), None, ptr(gin), B, self.cout, self.oh, self.oh, self.cin, oh,
+             oh, self.ks, self.stride, pad, 0, 1, stream())
+        return gin
+
+    def wgrad(self, x, stats, relu_in, gout, B):
+        lib = _lib.load()
+        ws = torch.empty(lib.mdnvae_conv_wgrad_workspace_floats(B, self.cout, self.cin, self.ks), dtype=torch.float32,
+                         device=x.device)
+        gw = torch.empty(self.cout, self.cin, self.ks, self.ks, dtype=torch.float32, device=x.device)
+        call("mdnvae_conv2d_wgrad", ptr(x), ptr(stats), int(relu_in), ptr(gout), ptr(ws), ptr(gw), B, self.cin, self.h,
+             self.h, self.cout, self.oh, self.oh, self.ks, self.stride, self.pad, int(self.reflect), stream())
+        return gw
+
+
+def _plane_stats(x):
+    B, C, H, W = x.shape
+    st = torch.empty(B * C, 2, dtype=torch.float32, device=x.device)
+    call("mdnvae_plane_stats", ptr(x), B * C, H * W, ptr(st), stream())
+    return st
+
+
+def _norm_act_add(raw, stats, skip, relu):
+    B, C, H, W = raw.shape
+    out = torch.empty_like(raw)
+    call("mdnvae_norm_act_add", ptr(raw), ptr(stats), ptr(skip), int(relu), B * C, H * W, ptr(out), stream())
+    return out
+
+
+def _inorm_bwd(raw, stats, gact, relu, folded):
+    B, C, H, W = raw.shape
+    graw = torch.empty_like(raw)
+    gsum = torch.empty(B, C, dtype=torch.float32, device=raw.device)
+    call("mdnvae_inorm_bwd", ptr(raw), ptr(stats), ptr(gact), int(relu), int(folded), B * C, H, W, ptr(graw),
+         ptr(gsum), stream())
+    return graw, _colsum(gsum)
+
+
+def encoder_layers(n_nodes, n_res=5):
+    l1 = _ConvLayer(1, 48, 7, 1, 3, True, n_nodes)
+    l2 = _ConvLayer(48, 96, 3, 2, 1, False, l1.oh)
+    l3 = _ConvLayer(96, 192, 3, 2, 1, False, l2.oh)
+    res = [_ConvLayer(192, 192, 3, 1, 1, True, l3.oh) for _ in range(2 * n_res)]
+    return [l1, l2, l3] + res
+
+
+class _ConvEncoder(torch.autograd.Function):
+    """x [B, n*n] -> pooled features [B, 192*(h/8)^2]; every arithmetic step is a HIP kernel."""
+
+    @staticmethod
+    def forward(ctx, x, n_nodes, *wb):
+        x = _c(x)
+        B = x.shape[0]
+        dev = x.device
+        ptr(x, "x")
+        layers = encoder_layers(n_nodes, (len(wb) // 2 - 3) // 2)
+        need_bwd = any(ctx.needs_input_grad[2:])
+        ws = [w for w in wb[0::2]]
+        bs = [b for b in wb[1::2]]
+        packed = [ly.pack(w, dev, need_bwd) for ly, w in zip(layers, ws)]
+        raw1 = layers[0].fwd(x, None, 0, packed[0][0], bs[0], B)
+        st1 = _plane_stats(raw1)
+        raw2 = layers[1].fwd(raw1, st1, 1, packed[1][0], bs[1], B)
+        st2 = _plane_stats(raw2)
+        raw3 = layers[2].fwd(raw2, st2, 1, packed[2][0], bs[2], B)
+        st3 = _plane_stats(raw3)
+        xk = _norm_act_add(raw3, st3, None, 1)
+        saved = [x, raw1, st1, raw2, st2, raw3, st3, xk]
+        nres = (len(layers) - 3) // 2
+        for k in range(nres):
+            la, lb = layers[3 + 2 * k], layers[4 + 2 * k]
+            ra = la.fwd(xk, None, 0, packed[3 + 2 * k][0], bs[3 + 2 * k], B)
+            sa = _plane_stats(ra)
+            rb = lb.fwd(ra, sa, 1, packed[4 + 2 * k][0], bs[4 + 2 * k], B)
+            sb = _plane_stats(rb)
+            xk = _norm_act_add(rb, sb, xk, 0)
+            saved += [ra, sa, rb, sb, xk]
+        H = layers[-1].oh
+        K = 8
+        PH = H // K
+        feat = torch.empty(B, 192 * PH * PH, dtype=torch.float32, device=dev)
+        argmax = torch.empty(B, 192 * PH * PH, dtype=torch.int32, device=dev)
+        call("mdnvae_maxpool_fwd", ptr(xk), B * 192, H, H, K, ptr(feat), ptr(argmax, "argmax", torch.int32), stream())
+        if need_bwd:
+            ctx.save_for_backward(*saved, argmax, *[p[1] for p in packed[1:]])
+            ctx.n_nodes, ctx.nres = n_nodes, nres
+        return feat
+
+    @staticmethod
+    def backward(ctx, gfeat):
+        sv = ctx.saved_tensors
+        nres = ctx.nres
+        layers = encoder_layers(ctx.n_nodes, nres)
+        x, raw1, st1, raw2, st2, raw3, st3, x0 = sv[:8]
+        blocks = [sv[8 + 5 * k: 13 + 5 * k] for k in range(nres)]
+        argmax = sv[8 + 5 * nres]
+        wbwd = sv[9 + 5 * nres:]          # packed data-gradient weights of layers 1..
+        B = x.shape[0]
+        H = layers[-1].oh
+        gfeat = _c(gfeat)
+        G = torch.empty(B, 192, H, H, dtype=torch.float32, device=x.device)
+        call("mdnvae_maxpool_bwd", ptr(gfeat), ptr(argmax, "argmax", torch.int32), B * 192, H, H, 8, ptr(G), stream())
+        gw = [None] * len(layers)
+        gb = [None] * len(layers)
+        for k in range(nres - 1, -1, -1):
+            ra, sa, rb, sb, _ = blocks[k]
+            xin = x0 if k == 0 else blocks[k - 1][4]
+            ia, ib = 3 + 2 * k, 4 + 2 * k
+            g_rb, gb[ib] = _inorm_bwd(rb, sb, G, 0, 0)
+            gw[ib] = layers[ib].wgrad(ra, sa, 1, g_rb, B)
+            gp_a = layers[ib].dgrad(g_rb, wbwd[ib - 1], B)
+            g_ra, gb[ia] = _inorm_bwd(ra, sa, gp_a, 1, 1)
+            gw[ia] = layers[ia].wgrad(xin, None, 0, g_ra, B)
+            gp_x = layers[ia].dgrad(g_ra, wbwd[ia - 1], B)
+            Gn = torch.empty_like(G)
+            call("mdnvae_fold_add", ptr(G), ptr(gp_x), B * 192, H, H, ptr(Gn), stream())
+            G = Gn
+        g_r3, gb[2] = _inorm_bwd(raw3, st3, G, 1, 0)
+        gw[2] = layers[2].wgrad(raw2, st2, 1, g_r3, B)
+        g_a2 = layers[2].dgrad(g_r3, wbwd[1], B)
+        g_r2, gb[1] = _inorm_bwd(raw2, st2, g_a2, 1, 0)
+        gw[1] = layers[1].wgrad(raw1, st1, 1, g_r2, B)
+        g_a1 = layers[1].dgrad(g_r2, wbwd[0], B)
+        g_r1, gb[0] = _inorm_bwd(raw1, st1, g_a1, 1, 0)
+        gw[0] = layers[0].wgrad(x.view(B, 1, ctx.n_nodes, ctx.n_nodes), None, 0, g_r1, B)
+        grads = []
+        for w_, b_ in zip(gw, gb):
+            grads += [w_, b_]
+        return (None, None, *grads)
+
+
+def conv_encoder(x, n_nodes, weights_and_biases):
+    """weights_and_biases: [(weight, bias)] for the stem, the two stride-2 convs and the residual
+    block convs, in network order."""
+    flat = []
+    for w, b in weights_and_biases:
+        flat += [w, b]
+    return _ConvEncoder.apply(x, n_nodes, *flat)

@@ -104,10 +104,10 @@ def meta_arrays(shapes, bounds):
     }
 
 
-def grads_of(model, prefix=""):
+def grads_of(model, prefix="", tag="g"):
     out = {}
     for name, p in model.named_parameters():
-        out.update(recipe.pack_grad(prefix + name, p.grad))
+        out.update(recipe.pack_grad(prefix + name, p.grad, tag))
     return out
 
 
@@ -157,6 +157,9 @@ def conv_vae_fixture(tag, relpath, x, masks=None, eval_mode=False):
     r64, _ = model64.decode(z64)
     loss64 = ns["loss_function"](r64.view(x.shape[0], -1), xt.double(), m64, lv64)
     arrays["loss64"] = np.float64(loss64.item())
+    model64.zero_grad()
+    loss64.backward()
+    arrays.update(grads_of(model64, tag="h"))
     if masks is not None:
         arrays["mask"] = np.float32(masks[0])
     save(tag, **arrays)
@@ -272,6 +275,15 @@ def make_ec87():
     for name, p in model.named_parameters():
         if name in keep:
             arrays.update(recipe.pack_grad(name, p.grad))
+    model64 = ns["VAE"]().double()
+    with torch.no_grad():
+        for n, p in model64.named_parameters():
+            p.copy_(recipe.fill_param(n, p.shape, bounds[n], torch.float64))
+    feat64 = model64.max_pool(model64.ec(xt.double())).reshape(2, -1)
+    ((model64.fc_mean(feat64) * cot_mu.double()).sum() + (model64.fc_log_var(feat64) * cot_lv.double()).sum()).backward()
+    for name, p in model64.named_parameters():
+        if name in keep:
+            arrays.update(recipe.pack_grad(name, p.grad, "h"))
     save("ec87", **arrays)
 
 

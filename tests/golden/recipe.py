@@ -36,31 +36,52 @@ def sample_index(name: str, numel: int) -> np.ndarray:
     return np.sort(rng.choice(numel, size=SAMPLE_COUNT, replace=False)).astype(np.int64)
 
 
-def pack_grad(name: str, g: torch.Tensor) -> dict:
-    """Fixture entries for one gradient tensor (float64 numpy)."""
+def pack_grad(name: str, g: torch.Tensor, tag: str = "g") -> dict:
+    """Fixture entries for one gradient tensor.  tag 'g' = the reference's fp32 run,
+    tag 'h' = the same classes run in float64 (the noise-floor reference)."""
     flat = g.detach().reshape(-1).double().numpy()
-    out = {f"gsum/{name}": np.float64(flat.sum()), f"gnorm/{name}": np.float64(np.linalg.norm(flat))}
+    out = {f"{tag}sum/{name}": np.float64(flat.sum()), f"{tag}norm/{name}": np.float64(np.linalg.norm(flat))}
+    store = np.float32 if tag == "g" else np.float64
     if flat.size <= FULL_GRAD_LIMIT:
-        out[f"gfull/{name}"] = flat.astype(np.float32)
+        out[f"{tag}full/{name}"] = flat.astype(store)
     else:
-        out[f"gsamp/{name}"] = flat[sample_index(name, flat.size)].astype(np.float32)
+        out[f"{tag}samp/{name}"] = flat[sample_index(name, flat.size)].astype(store)
     return out
 
 
 def check_grad(fix, name: str, g: torch.Tensor, rtol: float, what: str = ""):
-    """Compare a gradient tensor with the fixture entries; tolerance is relative
-    to the gradient's own L2 norm scaled to one element (plus elementwise rtol)."""
+    """Compare a gradient tensor with the fixture.
+
+    Without a float64 entry: every kept entry within rtol*(|ref| + rms(ref)) of the
+    reference's fp32 value.  With one: the reference's own fp32 run sits some distance
+    (`noise`) from the float64 run of the same classes -- for gradients that have crossed
+    the whole conv stack that distance is well above rtol -- so the bar becomes: no further
+    from the float64 gradient than rtol or 3x that fp32 noise, whichever is larger
+    (L2 over the kept entries), and no single entry further than rtol*(|ref|+rms) + 4x the
+    largest fp32 deviation."""
     flat = g.detach().reshape(-1).double().cpu().numpy()
     norm = float(fix[f"gnorm/{name}"])
     scale = norm / np.sqrt(flat.size) if norm > 0 else 1.0
-    if f"gfull/{name}" in fix:
-        ref = fix[f"gfull/{name}"].astype(np.float64)
-        got = flat
-    else:
-        ref = fix[f"gsamp/{name}"].astype(np.float64)
-        got = flat[sample_index(name, flat.size)]
-    err = np.abs(got - ref)
-    tol = rtol * (np.abs(ref) + scale)
+    full = f"gfull/{name}" in fix
+    ref32 = fix[f"gfull/{name}" if full else f"gsamp/{name}"].astype(np.float64)
+    got = flat if full else flat[sample_index(name, flat.size)]
+    key64 = f"hfull/{name}" if full else f"hsamp/{name}"
+    if key64 in fix:
+        ref = fix[key64].astype(np.float64)
+        noise = np.abs(ref32 - ref)
+        err = np.abs(got - ref)
+        l2_bar = max(rtol * np.linalg.norm(ref), 3.0 * np.linalg.norm(noise))
+        assert np.linalg.norm(err) <= l2_bar + 1e-30, (
+            f"{what} grad {name}: L2 distance to the float64 gradient {np.linalg.norm(err):.3e} > bar {l2_bar:.3e} "
+            f"(reference fp32 distance {np.linalg.norm(noise):.3e})")
+        tol = rtol * (np.abs(ref) + scale) + 4.0 * noise.max()
+        bad = err > tol
+        assert not bad.any(), (
+            f"{what} grad {name}: {bad.sum()}/{bad.size} entries off, max err {err.max():.3e} "
+            f"(scale {scale:.3e}, reference fp32 max deviation {noise.max():.3e})")
+        return
+    err = np.abs(got - ref32)
+    tol = rtol * (np.abs(ref32) + scale)
     bad = err > tol
     assert not bad.any(), (
         f"{what} grad {name}: {bad.sum()}/{bad.size} entries off, max err {err.max():.3e} "

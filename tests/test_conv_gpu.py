@@ -1,0 +1,182 @@
+"""Conv/ResNet encoder kernels: unit checks of every kernel against eager PyTorch on the CPU
+(float64), then the whole encoder and the whole conv VAEs against the reference fixtures.
+Bars: outputs 1e-5 relative (max-norm), loss 1e-5, gradients 1e-4."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import recipe
+from conftest import load_fixture, fixture_params
+from oracle import ref_eager as R
+import mdnvae_amd as M
+from mdnvae_amd import ops
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _rel(a, b):
+    a = torch.as_tensor(a).detach().double().cpu()
+    b = torch.as_tensor(b).detach().double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+GEOMS = [  # cin, cout, ks, stride, pad, reflect, h
+    (1, 48, 7, 1, 3, True, 68), (1, 48, 7, 1, 3, True, 87),
+    (48, 96, 3, 2, 1, False, 68), (48, 96, 3, 2, 1, False, 87),
+    (96, 192, 3, 2, 1, False, 34), (96, 192, 3, 2, 1, False, 44),
+    (192, 192, 3, 1, 1, True, 17), (192, 192, 3, 1, 1, True, 22),
+]
+
+
+def _ref_conv(x, w, b, ks, stride, pad, reflect):
+    if reflect:
+        return F.conv2d(F.pad(x, (pad,) * 4, mode="reflect"), w, b, stride=stride)
+    return F.conv2d(x, w, b, stride=stride, padding=pad)
+
+
+@pytest.mark.parametrize("cin,cout,ks,stride,pad,reflect,h", GEOMS)
+@pytest.mark.parametrize("B", [1, 3])
+def test_conv_forward_dgrad_wgrad(cin, cout, ks, stride, pad, reflect, h, B):
+    g = torch.Generator().manual_seed(cin * 7 + h + B)
+    x = torch.randn(B, cin, h, h, generator=g)
+    w = torch.randn(cout, cin, ks, ks, generator=g) / (cin * ks * ks) ** 0.5
+    b = torch.randn(cout, generator=g)
+    norm = cin > 1
+    xd, wd, bd = x.double().requires_grad_(True), w.double().requires_grad_(True), b.double()
+    act = F.relu(F.instance_norm(xd, eps=1e-5)) if norm else xd
+    act.retain_grad()
+    want = _ref_conv(act, wd, bd, ks, stride, pad, reflect)
+    cot = torch.randn(want.shape, generator=g)
+    (want * cot.double()).sum().backward()
+
+    ly = ops._ConvLayer(cin, cout, ks, stride, pad, reflect, h)
+    xg, cg = x.to(DEV), cot.to(DEV)
+    wf, wb = ly.pack(w.to(DEV), DEV, True)
+    st = ops._plane_stats(xg) if norm else None
+    out = ly.fwd(xg, st, norm, wf, b.to(DEV), B)
+    assert out.shape == want.shape
+    assert _rel(out, want) <= 1e-5
+    gw = ly.wgrad(xg, st, norm, cg, B)
+    assert _rel(gw, wd.grad) <= 1e-5
+    if cin > 1:
+        gin = ly.dgrad(cg, wb, B)
+        if reflect:
+            folded = torch.empty(B, cin, h, h, device=DEV)
+            ops.call("mdnvae_fold_add", None, ops.ptr(gin), B * cin, h, h, ops.ptr(folded), ops.stream())
+            gin = folded
+        assert _rel(gin, act.grad) <= 1e-5
+
+
+@pytest.mark.parametrize("C,H,relu,folded", [(5, 17, True, True), (3, 22, False, False), (2, 44, True, False),
+                                             (2, 87, True, False), (4, 22, True, True), (3, 3, True, True)])
+def test_instance_norm_kernels(C, H, relu, folded):
+    g = torch.Generator().manual_seed(C * H)
+    B = 3
+    raw = torch.randn(B, C, H, H, generator=g) * 2 + 0.5
+    rd = raw.double().requires_grad_(True)
+    y = F.instance_norm(rd, eps=1e-5)
+    a = F.relu(y) if relu else y
+    if folded:
+        ap = F.pad(a, (1, 1, 1, 1), mode="reflect")
+        cot = torch.randn(ap.shape, generator=g)
+        (ap * cot.double()).sum().backward()
+    else:
+        cot = torch.randn(a.shape, generator=g)
+        (a * cot.double()).sum().backward()
+    rg = raw.to(DEV)
+    st = ops._plane_stats(rg)
+    mean = raw.double().mean(dim=(2, 3)).reshape(-1)
+    rstd = 1.0 / torch.sqrt(raw.double().var(dim=(2, 3), unbiased=False) + 1e-5).reshape(-1)
+    assert _rel(st[:, 0], mean) <= 1e-6 and _rel(st[:, 1], rstd) <= 1e-6
+    act = ops._norm_act_add(rg, st, None, relu)
+    assert _rel(act, a) <= 1e-6
+    skip = torch.randn(B, C, H, H, generator=g)
+    act2 = ops._norm_act_add(rg, st, skip.to(DEV), relu)
+    assert _rel(act2, a + skip.double()) <= 1e-6
+    graw, gsum = ops._inorm_bwd(rg, st, cot.to(DEV).contiguous(), relu, folded)
+    assert _rel(graw, rd.grad) <= 2e-5
+    assert float(gsum.abs().max()) <= 1e-3 * float(rd.grad.abs().sum())   # sums to zero up to rounding
+
+
+def test_maxpool_forward_backward():
+    g = torch.Generator().manual_seed(8)
+    for H in (17, 22):
+        x = torch.randn(2, 192, H, H, generator=g)
+        xd = x.double().requires_grad_(True)
+        want = F.max_pool2d(xd, 8, 8)
+        cot = torch.randn(want.shape, generator=g)
+        (want * cot.double()).sum().backward()
+        PH = H // 8
+        feat = torch.empty(2, 192 * PH * PH, device=DEV)
+        arg = torch.empty(2, 192 * PH * PH, dtype=torch.int32, device=DEV)
+        xg = x.to(DEV)
+        ops.call("mdnvae_maxpool_fwd", ops.ptr(xg), 2 * 192, H, H, 8, ops.ptr(feat), arg.data_ptr(), ops.stream())
+        assert torch.equal(feat.cpu().view_as(want), want.detach().float())
+        gx = torch.empty_like(xg)
+        ops.call("mdnvae_maxpool_bwd", ops.ptr(cot.to(DEV).reshape(2, -1).contiguous()), arg.data_ptr(), 2 * 192, H, H,
+                 8, ops.ptr(gx), ops.stream())
+        assert torch.equal(gx.cpu(), xd.grad.float())
+
+
+def _check_grads(fix, model, skip_prefix=()):
+    for name, p in model.named_parameters():
+        if any(name.startswith(s) for s in skip_prefix):
+            continue
+        assert p.grad is not None, name
+        if name.startswith("ec.") and name.endswith(".bias"):
+            wn = float(fix["gnorm/" + name[:-4] + "weight"])
+            assert float(p.grad.norm()) <= 1e-5 * wn, name      # exactly zero in exact arithmetic
+            continue
+        g = p.grad
+        if name == "fcintercept.weight" and g.dim() == 1:
+            full = torch.zeros(g.numel(), g.numel())
+            full.diagonal().copy_(g.cpu())
+            g = full
+        recipe.check_grad(fix, name, g, 1e-4, "hip")
+
+
+def test_encoder_87_against_reference_fixture():
+    fix = load_fixture("ec87")
+    params = fixture_params(fix)
+    model = M.ConvVAE(decoder="nn", intercept="none", final="none", n_nodes=87)
+    model.load_state_dict(params, strict=False)
+    model = model.to(DEV)
+    x = torch.from_numpy(fix["x"]).reshape(2, -1).to(DEV)
+    mu, lv = model.encode(x)
+    ((mu * torch.from_numpy(fix["cot_mu"]).to(DEV)).sum() + (lv * torch.from_numpy(fix["cot_lv"]).to(DEV)).sum()).backward()
+    assert _rel(mu, fix["mu"]) <= 1e-5 and _rel(lv, fix["logvar"]) <= 1e-5
+    for name, p in model.named_parameters():
+        if f"gnorm/{name}" not in fix.files:
+            continue
+        if name.startswith("ec.") and name.endswith(".bias"):
+            assert float(p.grad.norm()) <= 1e-5 * float(fix["gnorm/" + name[:-4] + "weight"]), name
+            continue
+        recipe.check_grad(fix, name, p.grad, 1e-4, "hip")
+
+
+VARIANT_CTOR = {
+    "cnn_nn_sc": dict(decoder="nn", intercept="dense", final="exp"),
+    "cnn_gcn_sc": dict(decoder="gcn", intercept="diag", final="none"),
+    "cnn_gcn_fc": dict(decoder="gcn", intercept="diag", final="none"),
+    "cnn_nn_fc": dict(decoder="nn", intercept="none", final="none", dropout=0.5),
+}
+
+
+@pytest.mark.parametrize("variant", list(VARIANT_CTOR))
+def test_conv_vae_against_reference_fixture(variant):
+    fix = load_fixture(variant)
+    model = M.ConvVAE(**VARIANT_CTOR[variant]).eval()
+    model.load_state_dict(fixture_params(fix), strict=False)
+    model = model.to(DEV)
+    if "mask" in fix.files:
+        model.set_mask([torch.from_numpy(fix["mask"])] * 5 + [torch.eye(68 * 68)])
+    x = torch.from_numpy(fix["x"]).to(DEV)
+    recon, mu, logvar, x_latent = model(x, eps=torch.from_numpy(fix["eps"]).to(DEV))
+    loss = M.vae_loss(recon, x, mu, logvar, R.loss_mode(variant))
+    loss.backward()
+    assert _rel(mu, fix["mu"]) <= 1e-5 and _rel(logvar, fix["logvar"]) <= 1e-5
+    assert _rel(recon, fix["recon"]) <= 1e-5 and _rel(x_latent, fix["x_latent"]) <= 1e-5
+    assert abs(loss.item() - float(fix["loss"])) <= 1e-5 * abs(float(fix["loss"]))
+    _check_grads(fix, model)
