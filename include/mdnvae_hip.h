@@ -188,6 +188,13 @@ int mdnvae_maxpool_fwd(const float* x, long nplanes, int H, int W, int K, float*
 int mdnvae_maxpool_bwd(const float* grad_feat, const int* argmax, long nplanes, int H, int W, int K, float* grad_x,
                        void* stream);
 
+/* ---- optimiser ---------------------------------------------------------------------------
+ * torch.optim.Adam(lr=1e-3) of function/VAE_CNN_NN.py:204,219 over one flat buffer of n floats
+ * (all parameters / gradients / moments concatenated); step counts from 1; grad_scale multiplies
+ * the gradient first (1 for a SUM-reduced data-parallel gradient). */
+int mdnvae_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n, int step, float lr,
+                     float beta1, float beta2, float eps, float grad_scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

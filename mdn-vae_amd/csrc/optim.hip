@@ -1,0 +1,62 @@
+// Adam over one flat parameter buffer (torch.optim.Adam defaults as used by the reference:
+// function/VAE_CNN_NN.py:204, lr 1e-3, betas (0.9, 0.999), eps 1e-8, no weight decay, no
+// amsgrad), same operation order as torch's single-tensor update:
+//   m <- m + (1-b1)(g-m);  v <- b2*v + (1-b2) g*g;  p <- p - (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
+#include "common.h"
+#include "../../include/mdnvae_hip.h"
+
+namespace mdnvae {
+
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, long n, float b1,
+                                                   float b2, float eps, float step_size, float bc2_sqrt,
+                                                   float grad_scale) {
+    const long n4 = n >> 2;
+    float4* p4 = reinterpret_cast<float4*>(p);
+    const float4* g4 = reinterpret_cast<const float4*>(g);
+    float4* m4 = reinterpret_cast<float4*>(m);
+    float4* v4 = reinterpret_cast<float4*>(v);
+    const long stride = (long)gridDim.x * 256;
+    auto upd = [&](float& pp, float gg, float& mm, float& vv) {
+        gg *= grad_scale;
+        mm = mm + (1.0f - b1) * (gg - mm);
+        vv = vv * b2 + (1.0f - b2) * gg * gg;
+        const float denom = sqrtf(vv) / bc2_sqrt + eps;
+        pp = pp - step_size * (mm / denom);
+    };
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+        float4 pv = p4[i], mv = m4[i], vv = v4[i];
+        const float4 gv = g4[i];
+        upd(pv.x, gv.x, mv.x, vv.x);
+        upd(pv.y, gv.y, mv.y, vv.y);
+        upd(pv.z, gv.z, mv.z, vv.z);
+        upd(pv.w, gv.w, mv.w, vv.w);
+        p4[i] = pv;
+        m4[i] = mv;
+        v4[i] = vv;
+    }
+    const long t = (n4 << 2) + (long)blockIdx.x * 256 + threadIdx.x;
+    if (t < n) upd(p[t], g[t], m[t], v[t]);
+}
+
+}  // namespace mdnvae
+using namespace mdnvae;
+
+extern "C" int mdnvae_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n, int step,
+                                float lr, float beta1, float beta2, float eps, float grad_scale, void* stream) {
+    MV_REQUIRE(n >= 0 && step >= 1, E_ARG, "mdnvae_adam_step: bad size or step");
+    if (n == 0) return 0;
+    MV_REQUIRE(param && grad && exp_avg && exp_avg_sq, E_ARG, "mdnvae_adam_step: null pointer");
+    MV_REQUIRE(aligned16(param) && aligned16(grad) && aligned16(exp_avg) && aligned16(exp_avg_sq), E_ALIGN,
+               "mdnvae_adam_step: buffers must be 16-byte aligned");
+    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    const float step_size = (float)((double)lr / bc1);
+    const float bc2_sqrt = (float)sqrt(bc2);
+    long grid = ((n >> 2) + 255) / 256;
+    if (grid < 1) grid = 1;
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
+                       exp_avg_sq, n, beta1, beta2, eps, step_size, bc2_sqrt, grad_scale);
+    MV_LAUNCH_CHECK("adam_kernel");
+    return 0;
+}

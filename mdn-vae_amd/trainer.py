@@ -1,0 +1,96 @@
+"""Data-parallel training step: zero_grad -> forward -> loss -> backward -> SUM all-reduce of
+one flat gradient buffer -> Adam, mirroring train_epoch of the reference
+(function/VAE_CNN_NN.py:209-222, function/MM_Gate.py:195-208).
+
+One process per GPU.  Parameters, gradients and Adam moments each live in one flat fp32
+buffer; the parameters of the module are views into it, so a step issues one RCCL all-reduce
+(torch.distributed backend "nccl") and one Adam launch.  The reduction is a SUM, not a mean:
+the reference loss is sum-reduced, so G ranks with local batch b take exactly the step a
+single process would take on the G*b batch.
+"""
+import torch
+import torch.distributed as dist
+
+from . import ops
+from ._lib import call, ptr, stream
+
+
+class FlatBuffers:
+    """Re-homes a module's parameters (and their .grad) into two flat fp32 buffers."""
+
+    def __init__(self, module):
+        self.params = [p for p in module.parameters() if p.requires_grad]
+        if not self.params:
+            raise ValueError("module has no trainable parameters")
+        dev = self.params[0].device
+        sizes = [p.numel() for p in self.params]
+        self.offsets = [0]
+        for s in sizes:
+            self.offsets.append(self.offsets[-1] + s)
+        total = self.offsets[-1]
+        self.flat_p = torch.empty(total, dtype=torch.float32, device=dev)
+        self.flat_g = torch.zeros(total, dtype=torch.float32, device=dev)
+        for p, o in zip(self.params, self.offsets):
+            n = p.numel()
+            self.flat_p[o:o + n].copy_(p.data.reshape(-1))
+            p.data = self.flat_p[o:o + n].view(p.shape)
+            p.grad = self.flat_g[o:o + n].view(p.shape)
+
+    @property
+    def numel(self):
+        return self.offsets[-1]
+
+    def zero_grad(self):
+        self.flat_g.zero_()
+        for p, o in zip(self.params, self.offsets):      # re-attach views if something reset .grad
+            if p.grad is None or p.grad.data_ptr() != self.flat_g.data_ptr() + 4 * o:
+                p.grad = self.flat_g[o:o + p.numel()].view(p.shape)
+
+
+def allreduce_sum(flat, group=None, bucket_floats=8 << 20):
+    """In-place SUM all-reduce of a flat buffer in buckets of `bucket_floats` (32 MiB): large
+    enough that each xGMI ring step moves megabytes, small enough to pipeline."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return
+    works = []
+    for o in range(0, flat.numel(), bucket_floats):
+        works.append(dist.all_reduce(flat[o:o + bucket_floats], op=dist.ReduceOp.SUM, group=group, async_op=True))
+    for w in works:
+        w.wait()
+
+
+class Trainer:
+    def __init__(self, model, loss_mode, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, group=None, fused_loss=True):
+        self.model, self.loss_mode, self.group = model, loss_mode, group
+        self.lr, self.betas, self.eps = lr, betas, eps
+        self.buf = FlatBuffers(model)
+        self.exp_avg = torch.zeros_like(self.buf.flat_p)
+        self.exp_avg_sq = torch.zeros_like(self.buf.flat_p)
+        self.steps = 0
+        self.fused_loss = fused_loss
+
+    def forward_backward(self, inputs, target, eps=None):
+        """inputs: positional arguments of model.forward; returns the detached loss (0-dim)."""
+        self.buf.zero_grad()
+        out = self.model(*inputs, eps=eps)
+        recon, mu, logvar = out[0], out[1], out[2]
+        if self.fused_loss:
+            terms, g_recon, g_mu, g_lv = ops.vae_loss_and_grads(recon.detach(), target, mu.detach(), logvar.detach(),
+                                                                self.loss_mode)
+            torch.autograd.backward([recon, mu, logvar], [g_recon, g_mu, g_lv])
+            return terms[0]
+        loss = ops.vae_loss(recon, target, mu, logvar, self.loss_mode)
+        loss.backward()
+        return loss.detach()
+
+    def optimizer_step(self):
+        allreduce_sum(self.buf.flat_g, self.group)
+        self.steps += 1
+        call("mdnvae_adam_step", ptr(self.buf.flat_p), ptr(self.buf.flat_g), ptr(self.exp_avg), ptr(self.exp_avg_sq),
+             self.buf.numel, self.steps, float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps),
+             1.0, stream())
+
+    def step(self, inputs, target, eps=None):
+        loss = self.forward_backward(inputs, target, eps)
+        self.optimizer_step()
+        return loss
