@@ -3,58 +3,61 @@
 // Replaces the ATen conv2d / convolution_backward calls of the encoder stack
 //   function/VAE_CNN_NN.py:110-134 (stem 7x7 reflect-3, two stride-2 3x3, ten 3x3 reflect-1 convs)
 // Activations stay NCHW fp32.  One workgroup owns one sample, a tile of PT consecutive output
-// pixels and a tile of output channels; per chunk of CK input channels it stages
-//   * the input rows that tile needs, with padding (zero / reflection), optional instance-norm
-//     + ReLU of the producer layer, and optional zero-insertion (transposed stride-2 conv)
-//     already applied, as slab[c][row][col] in LDS, and
+// pixels and a tile of 96 output channels; per chunk of CK input channels it stages
+//   * the input rows that tile needs, with padding (zero / reflection) and, optionally, the
+//     instance norm + ReLU of the producer layer already applied, as slab[c][row][col] in LDS,
 //   * the weights of the chunk as wl[tap][c][n] in LDS,
-// and then runs a tap loop of 32x32x2 MFMAs: A = 32 output pixels x 2 input channels read from
-// the slab at a per-lane base + a per-tap scalar offset, B = 2 input channels x 32 output
-// channels.  The same kernel computes the data gradient (correlation of the zero-padded,
-// zero-inserted output gradient with the flipped, transposed weights).
+// and runs a tap loop of 32x32x2 MFMAs: A = 32 output pixels x 2 input channels read from the
+// slab at a per-lane base + a per-tap scalar offset, B = 2 input channels x 32 output channels.
+// Operands of tap t+1 are read from LDS while the MFMAs of tap t run.
 //
-// The weight gradient is its own kernel: D[n][c] per tap accumulates over pixels
-// (A = grad_out[n][pixel], B = slab[c][pixel+tap]); sample groups write partial sums that a
+// The data gradient is the same kernel over the output gradient: stride 1 = correlation with
+// the flipped weights over a zero-padded plane; stride 2 = four launches, one per parity class of
+// the input pixel, each using only the 1, 2, 2 or 4 taps that reach that class (no zero-inserted
+// work).  The weight gradient is its own kernel: D[n][c] per tap accumulates over pixels
+// (A = grad_out[n][pixel], B = slab[c][pixel + tap]); sample groups write partial sums that a
 // second kernel adds in a fixed order.
 #include "common.h"
 #include "../../include/mdnvae_hip.h"
+#include <cstdlib>
 
 namespace mdnvae {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
+constexpr int MAX_TAPS = 9;
 
 struct ConvGeom {
-    int B, Cin, H, W;      // input tensor [B,Cin,H,W]
-    int Cout, OH, OW;      // output tensor [B,Cout,OH,OW]
-    int KS, S;             // kernel size; stride from output pixel to virtual-input pixel
-    int pad, reflect;      // padding of the virtual input (reflect: 1 = reflection, 0 = zeros)
-    int dil;               // virtual input = input with (dil-1) zeros inserted between pixels
-    int VH, VW;            // virtual input size (>= (H-1)*dil+1; extra rows/cols read as zero)
-    int CoutP;             // padded output-channel count of the packed weights
-    int CK;                // input channels per chunk (even)
-    int relu_in;           // apply ReLU after the (optional) normalisation on load
-    int IWp;               // slab row length  = (OW-1)*S + KS
-    int slab_stride;       // floats per channel in the slab
+    int B, Cin, H, W;        // input tensor [B,Cin,H,W]
+    int Cout, OHf, OWf;      // output tensor [B,Cout,OHf,OWf]
+    int SH, SW;              // grid of output pixels computed by this launch
+    int osy, osx, oy0, ox0;  // grid pixel (a,b) is output pixel (a*osy+oy0, b*osx+ox0)
+    int S;                   // slab step per grid pixel
+    int pad, reflect;        // padding of the input seen through the slab
+    int KHe;                 // slab rows needed beyond the first row of a grid row
+    int IWp;                 // slab row length
+    int slab_stride;         // floats per channel in the slab
+    int CoutP;               // padded output-channel count of the packed weights
+    int ntaps;
+    int tap_off[MAX_TAPS];   // slab offset of tap t
+    int tap_w[MAX_TAPS];     // index of tap t in the packed weights
+    int relu_in;             // ReLU after the (optional) normalisation on load
+    unsigned m_iwp, m_sw;    // magic multipliers: x / d == umulhi(x, m)  (x*d < 2^32)
 };
 
-// value of the (padded, dilated, normalised) virtual input at padded coords (pr, pc)
+__host__ __device__ inline unsigned magic_of(unsigned d) { return (unsigned)(0x100000000ull / d) + 1u; }
+__device__ __forceinline__ int fdiv(int x, unsigned magic) { return (int)__umulhi((unsigned)x, magic); }
+
+// value of the padded (and optionally normalised) input at slab coordinates (pr, pc)
 __device__ __forceinline__ float virt_input(const ConvGeom& g, const float* __restrict__ plane, int pr, int pc,
                                             float mean, float rstd, bool norm) {
     int vy = pr - g.pad, vx = pc - g.pad;
-    bool ok;
+    bool ok = true;
     if (g.reflect) {
-        vy = vy < 0 ? -vy : (vy >= g.VH ? 2 * (g.VH - 1) - vy : vy);
-        vx = vx < 0 ? -vx : (vx >= g.VW ? 2 * (g.VW - 1) - vx : vx);
-        ok = true;
+        vy = vy < 0 ? -vy : (vy >= g.H ? 2 * (g.H - 1) - vy : vy);
+        vx = vx < 0 ? -vx : (vx >= g.W ? 2 * (g.W - 1) - vx : vx);
     } else {
-        ok = vy >= 0 && vy < g.VH && vx >= 0 && vx < g.VW;
+        ok = vy >= 0 && vy < g.H && vx >= 0 && vx < g.W;
     }
-    if (g.dil == 2) {
-        ok = ok && !((vy | vx) & 1);
-        vy >>= 1;
-        vx >>= 1;
-    }
-    ok = ok && vy < g.H && vx < g.W;
     float v = 0.0f;
     if (ok) {
         v = plane[vy * g.W + vx];
@@ -64,38 +67,144 @@ __device__ __forceinline__ float virt_input(const ConvGeom& g, const float* __re
     return v;
 }
 
+// Stage `nch` channel slabs (rows pr0.., all IWp columns) of sample b, channels c_first.. into LDS.
+// Loads are issued E at a time per thread before any of them is consumed.
+template <int NT, int E>
+__device__ __forceinline__ void stage_slab(const ConvGeom& g, const float* __restrict__ x,
+                                           const float* __restrict__ stats, int b, int c_first, int nch, int c_limit,
+                                           int pr0, int slab_elems, unsigned m_slab, float* __restrict__ slab,
+                                           int tid) {
+    const int total = nch * slab_elems;
+    const long in_plane = (long)g.H * g.W;
+    for (int base = 0; base < total; base += NT * E) {
+        float v[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int idx = base + tid + e * NT;
+            v[e] = 0.0f;
+            if (idx < total) {
+                const int c = fdiv(idx, m_slab), rem = idx - c * slab_elems;
+                if (c_first + c < c_limit) {
+                    const int r = fdiv(rem, g.m_iwp), col = rem - r * g.IWp;
+                    const long pl = (long)b * g.Cin + c_first + c;
+                    float mean = 0.0f, rstd = 1.0f;
+                    if (stats) {
+                        mean = stats[2 * pl];
+                        rstd = stats[2 * pl + 1];
+                    }
+                    v[e] = virt_input(g, x + pl * in_plane, pr0 + r, col, mean, rstd, stats != nullptr);
+                }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int idx = base + tid + e * NT;
+            if (idx < total) {
+                const int c = fdiv(idx, m_slab), rem = idx - c * slab_elems;
+                slab[c * g.slab_stride + rem] = v[e];
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // forward / data-gradient kernel
 // ---------------------------------------------------------------------------------------
-template <int WAVES, int WM, int WN>
-__global__ __launch_bounds__(WAVES * 64) void conv_mfma_kernel(ConvGeom g, const float* __restrict__ x,
-                                                               const float* __restrict__ stats,
-                                                               const float* __restrict__ wp,
-                                                               const float* __restrict__ bias,
-                                                               float* __restrict__ out) {
+// The MFMA row dimension runs over (sample, grid pixel) pairs flattened over the whole batch,
+// q = sample*P + pixel, so a tile of PT rows may end one sample and begin the next: the slab of a
+// channel then has two segments (rows of the first sample's tail, rows of the next sample's
+// head) and no MFMA row is wasted on per-sample padding.
+//
+// Staging is LDS-DMA (global_load_lds), double buffered: while the MFMA loop of chunk k runs,
+// the raw input values of chunk k+1 are gathered straight into the other slab buffer (4 bytes
+// per lane, source address from a per-workgroup offset table), its packed weights are copied
+// 16 bytes per lane, and the {mean, rstd} pairs it needs are fetched too; no staging value
+// passes through a register and there is one barrier per chunk.  Padding positions are never
+// written by the DMA: they are filled once with 0, or with NaN when the producer's instance
+// norm + ReLU is applied on the fly -- max((NaN-mean)*rstd, 0) is 0, which is what a padded
+// activation must be.  The normalisation itself is applied to the A operand after its LDS
+// read (3 VALU ops per operand, hidden under the 64-cycle MFMAs).
+typedef float f32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+#define MV_GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+#define MV_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+template <int CK>
+__global__ __launch_bounds__(256, 3) void conv_mfma_kernel(ConvGeom g, const float* __restrict__ x,
+                                                            const float* __restrict__ stats,
+                                                            const float* __restrict__ wp,
+                                                            const float* __restrict__ bias,
+                                                            float* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int WM = 2, WN = 3, WAVES = 4;
     constexpr int NT = WAVES * 64;
     constexpr int PT = WAVES * WM * 32;
     constexpr int NTILE = WN * 32;
-    const int KK = g.KS * g.KS;
-    float* slab = smem;
-    float* wl = smem + g.CK * g.slab_stride;
+    constexpr int NQ = NTILE / 4;
+    constexpr int CP = CK / 2;
+    constexpr int WBUF = MAX_TAPS * CK * NTILE;          // floats per weight buffer
+    const int sbuf = CK * g.slab_stride;                  // floats per slab buffer
+    float* wl0 = smem;                                    // [2][ntaps][CK][NTILE]
+    float* slab0 = smem + 2 * WBUF;                       // [2][CK][slab_elems]
+    float* st0 = slab0 + 2 * sbuf;                        // [2][2 samples][CK][2]
+    int* tbl = reinterpret_cast<int*>(st0 + 2 * 4 * CK);  // [slab_stride] source offsets
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, l32 = lane & 31;
-    const int P = g.OH * g.OW;
-    const int p0 = blockIdx.x * PT, n0 = blockIdx.y * NTILE, b = blockIdx.z;
-    const int oy0 = p0 / g.OW;
-    const int plast = min(P - 1, p0 + PT - 1);
-    const int nrows = (plast / g.OW - oy0) * g.S + g.KS;
-    const int pr0 = oy0 * g.S;
-    const int slab_elems = nrows * g.IWp;
+    const int P = g.SH * g.SW;
+    const long Q = (long)g.B * P;
+    const long q0 = (long)blockIdx.x * PT;
+    const int n0 = blockIdx.y * NTILE;
+    const long qlast = min(Q - 1, q0 + PT - 1);
+    const int s0 = (int)(q0 / P);
+    const int pa0 = (int)(q0 - (long)s0 * P);
+    const bool two = qlast >= (long)(s0 + 1) * P;
+    // segment 0: sample s0, grid pixels pa0 .. pe0;  segment 1: sample s0+1, grid pixels 0 .. pe1
+    const int pe0 = two ? P - 1 : (int)(qlast - (long)s0 * P);
+    const int a00 = fdiv(pa0, g.m_sw);
+    const int seg0 = ((fdiv(pe0, g.m_sw) - a00) * g.S + g.KHe) * g.IWp;
+    const int pe1 = two ? (int)(qlast - (long)(s0 + 1) * P) : 0;
+    const int seg1 = two ? (fdiv(pe1, g.m_sw) * g.S + g.KHe) * g.IWp : 0;
+    const int slab_elems = seg0 + seg1;                   // <= slab_stride; also the channel stride
+    const unsigned m_slab = magic_of(slab_elems);
+    const int in_plane = g.H * g.W;
+    const bool norm = stats != nullptr;
 
-    int lane_base[WM];
+    // source offset (relative to channel 0 of sample s0; -1 = padding) of every slab position
+    for (int rem = tid; rem < slab_elems; rem += NT) {
+        const int sg = rem >= seg0;
+        const int rr = sg ? rem - seg0 : rem;
+        const int r = fdiv(rr, g.m_iwp), col = rr - r * g.IWp;
+        int vy = (sg ? 0 : a00 * g.S) + r - g.pad, vx = col - g.pad;
+        bool ok = true;
+        if (g.reflect) {
+            vy = vy < 0 ? -vy : (vy >= g.H ? 2 * (g.H - 1) - vy : vy);
+            vx = vx < 0 ? -vx : (vx >= g.W ? 2 * (g.W - 1) - vx : vx);
+        } else {
+            ok = vy >= 0 && vy < g.H && vx >= 0 && vx < g.W;
+        }
+        tbl[rem] = ok ? sg * g.Cin * in_plane + vy * g.W + vx : -1;
+    }
+    __syncthreads();
+    const int stotal = CK * slab_elems;
+    {   // padding positions of both buffers, once
+        const float fill = norm ? __builtin_nanf("") : 0.0f;
+        for (int idx = tid; idx < stotal; idx += NT) {
+            const int c = fdiv(idx, m_slab), rem = idx - c * slab_elems;
+            if (tbl[rem] < 0) {
+                slab0[idx] = fill;
+                slab0[sbuf + idx] = fill;
+            }
+        }
+    }
+
+    int lane_base[WM], lane_seg[WM];
 #pragma unroll
     for (int m = 0; m < WM; ++m) {
-        const int p = min(P - 1, p0 + (wave * WM + m) * 32 + l32);
-        const int oy = p / g.OW, ox = p - oy * g.OW;
-        lane_base[m] = (oy - oy0) * g.S * g.IWp + ox * g.S;
+        const long q = min(Q - 1, q0 + (wave * WM + m) * 32 + l32);
+        const int sg = q >= (long)(s0 + 1) * P;
+        const int pp = (int)(q - (long)(s0 + sg) * P);
+        const int a = fdiv(pp, g.m_sw), bb = pp - a * g.SW;
+        lane_base[m] = (sg ? seg0 + a * g.S * g.IWp : (a - a00) * g.S * g.IWp) + bb * g.S + h * slab_elems;
+        lane_seg[m] = sg;
     }
     f32x16 acc[WM][WN];
 #pragma unroll
@@ -105,61 +214,132 @@ __global__ __launch_bounds__(WAVES * 64) void conv_mfma_kernel(ConvGeom g, const
 #pragma unroll
             for (int j = 0; j < 16; ++j) acc[m][n][j] = 0.0f;
 
-    const long in_plane = (long)g.H * g.W;
-    for (int c0 = 0; c0 < g.Cin; c0 += g.CK) {
-        __syncthreads();
-        for (int idx = tid; idx < g.CK * slab_elems; idx += NT) {
-            const int c = idx / slab_elems, rem = idx - c * slab_elems;
-            const int r = rem / g.IWp, col = rem - r * g.IWp;
-            const long pl = (long)b * g.Cin + c0 + c;
-            float mean = 0.0f, rstd = 1.0f;
-            if (stats) {
-                mean = stats[2 * pl];
-                rstd = stats[2 * pl + 1];
+    const int wtotal = g.ntaps * CK * NQ;
+    const float* xs0 = x + (long)s0 * g.Cin * in_plane;
+    const int s1 = min(s0 + 1, g.B - 1);
+
+    auto issue = [&](int c0, int buf) {
+        float* sdst = slab0 + buf * sbuf;
+        for (int base = 0; base < stotal; base += NT) {
+            const int idx = base + tid;
+            if (idx < stotal) {
+                const int c = fdiv(idx, m_slab), rem = idx - c * slab_elems;
+                const int off = tbl[rem];
+                if (off >= 0)
+                    __builtin_amdgcn_global_load_lds(MV_GLOBAL_PTR(xs0 + (long)(c0 + c) * in_plane + off),
+                                                     MV_LDS_PTR(sdst + base + wave * 64), 4, 0, 0);
             }
-            slab[c * g.slab_stride + rem] = virt_input(g, x + pl * in_plane, pr0 + r, col, mean, rstd, stats != nullptr);
         }
-        const int nq = NTILE / 4;
-        for (int i4 = tid; i4 < KK * g.CK * nq; i4 += NT) {
-            const int row = i4 / nq, q = i4 - row * nq;
-            const int tap = row / g.CK, c = row - tap * g.CK;
-            const float4 v = *reinterpret_cast<const float4*>(wp + ((long)(tap * g.Cin + c0 + c)) * g.CoutP + n0 + q * 4);
-            *reinterpret_cast<float4*>(wl + row * NTILE + q * 4) = v;
+        float* wdst = wl0 + buf * WBUF;
+        for (int base = 0; base < wtotal; base += NT) {
+            const int i4 = base + tid;
+            if (i4 < wtotal) {
+                const int row = i4 / NQ, q = i4 - row * NQ;
+                const int t = row / CK, c = row - t * CK;
+                __builtin_amdgcn_global_load_lds(
+                    MV_GLOBAL_PTR(wp + ((long)(g.tap_w[t] * g.Cin + c0 + c)) * g.CoutP + n0 + q * 4),
+                    MV_LDS_PTR(wdst + (base + wave * 64) * 4), 16, 0, 0);
+            }
         }
-        __syncthreads();
-        for (int ky = 0; ky < g.KS; ++ky) {
-            for (int kx = 0; kx < g.KS; ++kx) {
-                const float* sl = slab + h * g.slab_stride + ky * g.IWp + kx;
-                const float* wr = wl + ((ky * g.KS + kx) * g.CK + h) * NTILE + l32;
-                for (int cp = 0; cp < g.CK / 2; ++cp) {
-                    float a[WM], bb[WN];
+        if (norm && tid < 4 * CK) {      // {mean, rstd} of the chunk's channels for both samples
+            const int sg = tid / (2 * CK), k = tid - sg * 2 * CK;
+            __builtin_amdgcn_global_load_lds(MV_GLOBAL_PTR(stats + 2 * ((long)(sg ? s1 : s0) * g.Cin + c0) + k),
+                                             MV_LDS_PTR(st0 + buf * 4 * CK), 4, 0, 0);
+        }
+    };
+
+    issue(0, 0);
+    int buf = 0;
+    for (int c0 = 0; c0 < g.Cin; c0 += CK, buf ^= 1) {
+        __syncthreads();     // chunk c0 has landed (the barrier drains the DMA) and the other buffer is free
+        if (c0 + CK < g.Cin) issue(c0 + CK, buf ^ 1);
+        const float* slab = slab0 + buf * sbuf;
+        const float* wl = wl0 + buf * WBUF;
+        float mean[WM][CP], rstd[WM][CP];
+        if (norm) {
+            const float* st = st0 + buf * 4 * CK;
 #pragma unroll
-                    for (int m = 0; m < WM; ++m) a[m] = sl[cp * 2 * g.slab_stride + lane_base[m]];
+            for (int m = 0; m < WM; ++m)
 #pragma unroll
-                    for (int n = 0; n < WN; ++n) bb[n] = wr[cp * 2 * NTILE + n * 32];
-#pragma unroll
-                    for (int m = 0; m < WM; ++m)
-#pragma unroll
-                        for (int n = 0; n < WN; ++n)
-                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], bb[n], acc[m][n], 0, 0, 0);
+                for (int cp = 0; cp < CP; ++cp) {
+                    mean[m][cp] = st[(lane_seg[m] * CK + 2 * cp + h) * 2];
+                    rstd[m][cp] = st[(lane_seg[m] * CK + 2 * cp + h) * 2 + 1];
                 }
+        }
+        for (int t = 0; t < g.ntaps; ++t) {
+            const float* sl = slab + g.tap_off[t];
+            const float* wr = wl + (t * CK + h) * NTILE + l32;
+            float A[CP][WM], Bv[CP][WN];
+#pragma unroll
+            for (int cp = 0; cp < CP; ++cp) {
+#pragma unroll
+                for (int m = 0; m < WM; ++m) A[cp][m] = sl[cp * 2 * slab_elems + lane_base[m]];
+#pragma unroll
+                for (int n = 0; n < WN; ++n) Bv[cp][n] = wr[cp * 2 * NTILE + n * 32];
             }
+            if (norm) {
+#pragma unroll
+                for (int cp = 0; cp < CP; ++cp)
+#pragma unroll
+                    for (int m = 0; m < WM; ++m) {
+                        float v = (A[cp][m] - mean[m][cp]) * rstd[m][cp];
+                        if (g.relu_in) v = fmaxf(v, 0.0f);
+                        else v = (v != v) ? 0.0f : v;
+                        A[cp][m] = v;
+                    }
+            } else if (g.relu_in) {
+#pragma unroll
+                for (int cp = 0; cp < CP; ++cp)
+#pragma unroll
+                    for (int m = 0; m < WM; ++m) A[cp][m] = fmaxf(A[cp][m], 0.0f);
+            }
+#pragma unroll
+            for (int cp = 0; cp < CP; ++cp)
+#pragma unroll
+                for (int m = 0; m < WM; ++m)
+#pragma unroll
+                    for (int n = 0; n < WN; ++n)
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[cp][m], Bv[cp][n], acc[m][n], 0, 0, 0);
         }
     }
-    // epilogue: accumulator register j of a 32x32 tile holds row (j&3)+8*(j>>2)+4*h, column l32
+    // epilogue: accumulator registers 4g..4g+3 of a 32x32 tile hold rows 8g+4h .. 8g+4h+3 (four
+    // consecutive q) of column l32
+    const long oplane_sz = (long)g.OHf * g.OWf;
+    const bool linear = g.osx == 1 && g.osy == 1 && g.SW == g.OWf;
 #pragma unroll
     for (int n = 0; n < WN; ++n) {
         const int ch = n0 + n * 32 + l32;
         if (ch < g.Cout) {
             const float bv = bias ? bias[ch] : 0.0f;
-            float* oplane = out + ((long)b * g.Cout + ch) * P;
 #pragma unroll
             for (int m = 0; m < WM; ++m) {
-                const int pbase = p0 + (wave * WM + m) * 32 + 4 * h;
 #pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    const int p = pbase + (j & 3) + 8 * (j >> 2);
-                    if (p < P) oplane[p] = acc[m][n][j] + bv;
+                for (int gq = 0; gq < 4; ++gq) {
+                    const long q = q0 + (wave * WM + m) * 32 + 8 * gq + 4 * h;
+                    if (q >= Q) continue;
+                    const int sg = q >= (long)(s0 + 1) * P;
+                    const int pp = (int)(q - (long)(s0 + sg) * P);
+                    float* oplane = out + ((long)(s0 + sg) * g.Cout + ch) * oplane_sz;
+                    if (linear && pp + 3 < P) {
+                        f32x4_a4 o;
+                        o.x = acc[m][n][4 * gq] + bv;
+                        o.y = acc[m][n][4 * gq + 1] + bv;
+                        o.z = acc[m][n][4 * gq + 2] + bv;
+                        o.w = acc[m][n][4 * gq + 3] + bv;
+                        *reinterpret_cast<f32x4_a4*>(oplane + pp) = o;
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const long qk = q + k;
+                            if (qk < Q) {
+                                const int sk = qk >= (long)(s0 + 1) * P;
+                                const int pk = (int)(qk - (long)(s0 + sk) * P);
+                                const int a = fdiv(pk, g.m_sw), bb = pk - a * g.SW;
+                                float* op = out + ((long)(s0 + sk) * g.Cout + ch) * oplane_sz;
+                                op[(a * g.osy + g.oy0) * g.OWf + bb * g.osx + g.ox0] = acc[m][n][4 * gq + k] + bv;
+                            }
+                        }
+                    }
                 }
             }
         }
@@ -169,7 +349,7 @@ __global__ __launch_bounds__(WAVES * 64) void conv_mfma_kernel(ConvGeom g, const
 // Stem: one input channel, so the MFMA K dimension runs over the taps (49 -> 50, the last with
 // zero weight).  wp is [50][CoutP].
 template <int WAVES, int WM, int WN>
-__global__ __launch_bounds__(WAVES * 64) void conv_stem_kernel(ConvGeom g, const float* __restrict__ x,
+__global__ __launch_bounds__(WAVES * 64) void conv_stem_kernel(ConvGeom g, int KS, const float* __restrict__ x,
                                                                const float* __restrict__ wp,
                                                                const float* __restrict__ bias,
                                                                float* __restrict__ out) {
@@ -177,24 +357,24 @@ __global__ __launch_bounds__(WAVES * 64) void conv_stem_kernel(ConvGeom g, const
     constexpr int NT = WAVES * 64;
     constexpr int PT = WAVES * WM * 32;
     constexpr int NTILE = WN * 32;
-    const int KK = g.KS * g.KS;
+    const int KK = KS * KS;
     const int KKP = (KK + 1) & ~1;
     float* slab = smem;
     float* wl = smem + g.slab_stride;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, l32 = lane & 31;
-    const int P = g.OH * g.OW;
+    const int P = g.SH * g.SW;
     const int p0 = blockIdx.x * PT, n0 = blockIdx.y * NTILE, b = blockIdx.z;
-    const int oy0 = p0 / g.OW;
+    const int a0 = fdiv(p0, g.m_sw);
     const int plast = min(P - 1, p0 + PT - 1);
-    const int nrows = (plast / g.OW - oy0) * g.S + g.KS;
-    const int pr0 = oy0 * g.S;
+    const int nrows = (fdiv(plast, g.m_sw) - a0) * g.S + g.KHe;
+    const int pr0 = a0 * g.S;
     const int slab_elems = nrows * g.IWp;
     int lane_base[WM];
 #pragma unroll
     for (int m = 0; m < WM; ++m) {
         const int p = min(P - 1, p0 + (wave * WM + m) * 32 + l32);
-        const int oy = p / g.OW, ox = p - oy * g.OW;
-        lane_base[m] = (oy - oy0) * g.S * g.IWp + ox * g.S;
+        const int a = fdiv(p, g.m_sw), bb = p - a * g.SW;
+        lane_base[m] = (a - a0) * g.S * g.IWp + bb * g.S;
     }
     f32x16 acc[WM][WN];
 #pragma unroll
@@ -204,20 +384,17 @@ __global__ __launch_bounds__(WAVES * 64) void conv_stem_kernel(ConvGeom g, const
 #pragma unroll
             for (int j = 0; j < 16; ++j) acc[m][n][j] = 0.0f;
 
-    const float* plane = x + (long)b * g.H * g.W;
-    for (int idx = tid; idx < slab_elems; idx += NT) {
-        const int r = idx / g.IWp, col = idx - r * g.IWp;
-        slab[idx] = virt_input(g, plane, pr0 + r, col, 0.0f, 1.0f, false);
-    }
+    stage_slab<NT, 8>(g, x, nullptr, b, 0, 1, 1, pr0, slab_elems, magic_of(slab_elems), slab, tid);
     for (int i = tid; i < KKP * NTILE; i += NT) {
         const int tap = i / NTILE, n = i - tap * NTILE;
         wl[i] = wp[(long)tap * g.CoutP + n0 + n];
     }
     __syncthreads();
+#pragma unroll 5
     for (int step = 0; step < KKP / 2; ++step) {
         const int tap = 2 * step + h;
         const int ta = min(tap, KK - 1);            // address of the padded tap stays inside the slab
-        const int ky = ta / g.KS, kx = ta - ky * g.KS;
+        const int ky = ta / KS, kx = ta - ky * KS;
         const int toff = ky * g.IWp + kx;
         float a[WM], bb[WN];
 #pragma unroll
@@ -283,84 +460,99 @@ __global__ void conv_pack_stem_kernel(const float* __restrict__ w, int Cout, int
 // ---------------------------------------------------------------------------------------
 // weight gradient
 // ---------------------------------------------------------------------------------------
-// Workgroup tile: 64 output channels x 64 input channels x all taps (KK <= 9); 4 waves as
-// 2 (n) x 2 (c).  K dimension = output pixels of the samples of this group.
-// partial [G][KK][Cout][Cin]
+// Workgroup tile: 64 output channels x 64 input channels x 9 taps; 4 waves as 2 (n) x 2 (c).
+// K dimension = output pixels of the samples of this group.  partial [G][9][Cout][Cin]
 constexpr int WG_NT = 256;
-template <int KKT>
-__global__ __launch_bounds__(WG_NT) void conv_wgrad_kernel(ConvGeom g, const float* __restrict__ x,
-                                                           const float* __restrict__ stats,
-                                                           const float* __restrict__ gout, int ptw,
-                                                           int samples_per_group, float* __restrict__ partial) {
+__global__ __launch_bounds__(WG_NT, 2) void conv_wgrad_kernel(ConvGeom g, const float* __restrict__ x,
+                                                              const float* __restrict__ stats,
+                                                              const float* __restrict__ gout, int ptw, int cslab,
+                                                              int samples_per_group, float* __restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int KKT = 9;
     const int gl_stride = ptw + 1;
     float* gl = smem;                               // [64][ptw+1]
-    float* slab = smem + 64 * gl_stride;            // [64][slab_stride]
+    float* slab = smem + 64 * gl_stride;            // [cslab][slab_stride]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, l32 = lane & 31;
     const int wn = wave >> 1, wc = wave & 1;
     const int n0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
-    const int P = g.OH * g.OW;
+    const int P = g.SH * g.SW;
     const int b_begin = blockIdx.z * samples_per_group;
     const int b_end = min(g.B, b_begin + samples_per_group);
-    const long in_plane = (long)g.H * g.W;
+    const unsigned m_ptw = magic_of(ptw);
 
     f32x16 acc[KKT];
 #pragma unroll
     for (int t = 0; t < KKT; ++t)
 #pragma unroll
         for (int j = 0; j < 16; ++j) acc[t][j] = 0.0f;
+    // lanes of a channel row that does not exist read row 0 (its products are discarded)
+    const int crow = (c0 + wc * 32 + l32 < g.Cin) ? wc * 32 + l32 : 0;
 
     for (int b = b_begin; b < b_end; ++b) {
         for (int p0 = 0; p0 < P; p0 += ptw) {
-            const int oy0 = p0 / g.OW;
+            const int a0 = fdiv(p0, g.m_sw);
             const int plast = min(P - 1, p0 + ptw - 1);
-            const int nrows = (plast / g.OW - oy0) * g.S + g.KS;
-            const int pr0 = oy0 * g.S;
+            const int nrows = (fdiv(plast, g.m_sw) - a0) * g.S + g.KHe;
+            const int pr0 = a0 * g.S;
             const int slab_elems = nrows * g.IWp;
             __syncthreads();
-            for (int idx = tid; idx < 64 * ptw; idx += WG_NT) {
-                const int n = idx / ptw, pp = idx - n * ptw;
-                float v = 0.0f;
-                if (n0 + n < g.Cout && p0 + pp < P) v = gout[((long)b * g.Cout + n0 + n) * P + p0 + pp];
-                gl[n * gl_stride + pp] = v;
-            }
-            for (int idx = tid; idx < 64 * slab_elems; idx += WG_NT) {
-                const int c = idx / slab_elems, rem = idx - c * slab_elems;
-                float v = 0.0f;
-                if (c0 + c < g.Cin) {
-                    const int r = rem / g.IWp, col = rem - r * g.IWp;
-                    const long pl = (long)b * g.Cin + c0 + c;
-                    float mean = 0.0f, rstd = 1.0f;
-                    if (stats) {
-                        mean = stats[2 * pl];
-                        rstd = stats[2 * pl + 1];
+            {   // grad_out tile, E loads in flight per thread
+                constexpr int E = 8;
+                const int total = 64 * ptw;
+                for (int base = 0; base < total; base += WG_NT * E) {
+                    float v[E];
+#pragma unroll
+                    for (int e = 0; e < E; ++e) {
+                        const int idx = base + tid + e * WG_NT;
+                        v[e] = 0.0f;
+                        if (idx < total) {
+                            const int n = fdiv(idx, m_ptw), pp = idx - n * ptw;
+                            if (n0 + n < g.Cout && p0 + pp < P) v[e] = gout[((long)b * g.Cout + n0 + n) * P + p0 + pp];
+                        }
                     }
-                    v = virt_input(g, x + pl * in_plane, pr0 + r, col, mean, rstd, stats != nullptr);
+#pragma unroll
+                    for (int e = 0; e < E; ++e) {
+                        const int idx = base + tid + e * WG_NT;
+                        if (idx < total) {
+                            const int n = fdiv(idx, m_ptw), pp = idx - n * ptw;
+                            gl[n * gl_stride + pp] = v[e];
+                        }
+                    }
                 }
-                slab[c * g.slab_stride + rem] = v;
             }
+            stage_slab<WG_NT, 8>(g, x, stats, b, c0, cslab, g.Cin, pr0, slab_elems, magic_of(slab_elems), slab, tid);
             __syncthreads();
             const float* ga = gl + (wn * 32 + l32) * gl_stride + h;
-            const float* sb = slab + (wc * 32 + l32) * g.slab_stride;
-            // pixel (p0 + k + h) -> slab offset, advanced by two pixels per step
+            const float* sb = slab + crow * g.slab_stride;
+            // pixel (p0 + 2k + h): slab offset advanced by two pixels per step
             int pix = p0 + h;
-            int oy = pix / g.OW, ox = pix - oy * g.OW;
+            int a = fdiv(pix, g.m_sw), bb = pix - a * g.SW;
             const int npairs = (min(ptw, P - p0) + 1) >> 1;
-            for (int k = 0; k < npairs; ++k) {
-                const float a = ga[2 * k];
+            float av0, bv0[KKT], av1, bv1[KKT];
+            auto load_k = [&](int k, float& av, float (&bv)[KKT]) {
+                av = ga[2 * k];
                 // a pixel past the end of the plane carries a zero gradient; clamp its address
-                const int oyc = min(oy, g.OH - 1);
-                const int off = (oyc - oy0) * g.S * g.IWp + ox * g.S;
+                const int ac = min(a, g.SH - 1);
+                const int off = (ac - a0) * g.S * g.IWp + bb * g.S;
 #pragma unroll
-                for (int t = 0; t < KKT; ++t) {
-                    const int ky = t / 3, kx = t - ky * 3;      // KKT == 9 -> 3x3 taps
-                    const float bv = sb[off + ky * g.IWp + kx];
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[t], 0, 0, 0);
+                for (int t = 0; t < KKT; ++t) bv[t] = sb[off + (t / 3) * g.IWp + (t % 3)];
+                bb += 2;
+                if (bb >= g.SW) {
+                    bb -= g.SW;
+                    ++a;
                 }
-                ox += 2;
-                if (ox >= g.OW) {
-                    ox -= g.OW;
-                    ++oy;
+            };
+            auto mma_k = [&](float av, float (&bv)[KKT]) {
+#pragma unroll
+                for (int t = 0; t < KKT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[t], acc[t], 0, 0, 0);
+            };
+            load_k(0, av0, bv0);
+            for (int k = 0; k < npairs; k += 2) {
+                if (k + 1 < npairs) load_k(k + 1, av1, bv1);
+                mma_k(av0, bv0);
+                if (k + 1 < npairs) {
+                    if (k + 2 < npairs) load_k(k + 2, av0, bv0);
+                    mma_k(av1, bv1);
                 }
             }
         }
@@ -385,35 +577,43 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __r
     const long total = (long)KK * Cout * Cin;
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= total) return;
-    float s = 0.0f;
-    for (int z = 0; z < G; ++z) s += partial[(long)z * total + idx];
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+    int z = 0;
+    for (; z + 3 < G; z += 4) {
+        s0 += partial[(long)z * total + idx];
+        s1 += partial[(long)(z + 1) * total + idx];
+        s2 += partial[(long)(z + 2) * total + idx];
+        s3 += partial[(long)(z + 3) * total + idx];
+    }
+    for (; z < G; ++z) s0 += partial[(long)z * total + idx];
     const int c = (int)(idx % Cin);
     const long t = idx / Cin;
     const int n = (int)(t % Cout), tap = (int)(t / Cout);
-    dw[((long)n * Cin + c) * KK + tap] = s;
+    dw[((long)n * Cin + c) * KK + tap] = (s0 + s1) + (s2 + s3);
 }
 
 // Stem weight gradient (one input channel): D[n][tap] accumulates over pixels.
 // 4 waves split the pixels of each chunk; their accumulators are added through LDS at the end.
 // partial [G][Cout][KK]
-__global__ __launch_bounds__(256) void conv_stem_wgrad_kernel(ConvGeom g, const float* __restrict__ x,
+__global__ __launch_bounds__(256) void conv_stem_wgrad_kernel(ConvGeom g, int KS, const float* __restrict__ x,
                                                               const float* __restrict__ gout, int ptw,
                                                               int samples_per_group, float* __restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int KK = g.KS * g.KS;
+    const int KK = KS * KS;
     const int gl_stride = ptw + 1;
     float* gl = smem;                          // [64][ptw+1]
     float* slab = smem + 64 * gl_stride;       // [slab_stride] (+ one zero word at the end)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, l32 = lane & 31;
-    const int P = g.OH * g.OW;
+    const int P = g.SH * g.SW;
     const int b_begin = blockIdx.z * samples_per_group;
     const int b_end = min(g.B, b_begin + samples_per_group);
+    const unsigned m_ptw = magic_of(ptw);
     // per-lane tap offsets for the two tap tiles (taps >= KK read the zero word)
     int toff[2];
 #pragma unroll
     for (int jt = 0; jt < 2; ++jt) {
         const int tap = jt * 32 + l32;
-        const int ky = tap / g.KS, kx = tap - ky * g.KS;
+        const int ky = tap / KS, kx = tap - ky * KS;
         toff[jt] = (tap < KK) ? ky * g.IWp + kx : -1;
     }
     const int zero_at = g.slab_stride - 1;
@@ -426,42 +626,57 @@ __global__ __launch_bounds__(256) void conv_stem_wgrad_kernel(ConvGeom g, const 
             for (int j = 0; j < 16; ++j) acc[i][jt][j] = 0.0f;
 
     for (int b = b_begin; b < b_end; ++b) {
-        const float* plane = x + (long)b * g.H * g.W;
         for (int p0 = 0; p0 < P; p0 += ptw) {
-            const int oy0 = p0 / g.OW;
+            const int a0 = fdiv(p0, g.m_sw);
             const int plast = min(P - 1, p0 + ptw - 1);
-            const int nrows = (plast / g.OW - oy0) * g.S + g.KS;
-            const int pr0 = oy0 * g.S;
+            const int nrows = (fdiv(plast, g.m_sw) - a0) * g.S + g.KHe;
+            const int pr0 = a0 * g.S;
             const int slab_elems = nrows * g.IWp;
             __syncthreads();
-            for (int idx = tid; idx < 64 * ptw; idx += 256) {
-                const int n = idx / ptw, pp = idx - n * ptw;
-                float v = 0.0f;
-                if (n < g.Cout && p0 + pp < P) v = gout[((long)b * g.Cout + n) * P + p0 + pp];
-                gl[n * gl_stride + pp] = v;
+            {
+                constexpr int E = 8;
+                const int total = 64 * ptw;
+                for (int base = 0; base < total; base += 256 * E) {
+                    float v[E];
+#pragma unroll
+                    for (int e = 0; e < E; ++e) {
+                        const int idx = base + tid + e * 256;
+                        v[e] = 0.0f;
+                        if (idx < total) {
+                            const int n = fdiv(idx, m_ptw), pp = idx - n * ptw;
+                            if (n < g.Cout && p0 + pp < P) v[e] = gout[((long)b * g.Cout + n) * P + p0 + pp];
+                        }
+                    }
+#pragma unroll
+                    for (int e = 0; e < E; ++e) {
+                        const int idx = base + tid + e * 256;
+                        if (idx < total) {
+                            const int n = fdiv(idx, m_ptw), pp = idx - n * ptw;
+                            gl[n * gl_stride + pp] = v[e];
+                        }
+                    }
+                }
             }
-            for (int idx = tid; idx < slab_elems; idx += 256) {
-                const int r = idx / g.IWp, col = idx - r * g.IWp;
-                slab[idx] = virt_input(g, plane, pr0 + r, col, 0.0f, 1.0f, false);
-            }
+            stage_slab<256, 8>(g, x, nullptr, b, 0, 1, 1, pr0, slab_elems, magic_of(slab_elems), slab, tid);
             if (tid == 0) slab[zero_at] = 0.0f;
             __syncthreads();
             // wave w takes pixel pairs w, w+4, w+8, ...
             const int npairs = (min(ptw, P - p0) + 1) >> 1;
+#pragma unroll 2
             for (int k = wave; k < npairs; k += 4) {
                 const int pix = min(P - 1, p0 + 2 * k + h);
-                const int oy = pix / g.OW, ox = pix - oy * g.OW;
-                const int off = (oy - oy0) * g.S * g.IWp + ox * g.S;
-                float a[2], bv[2];
+                const int a = fdiv(pix, g.m_sw), bb = pix - a * g.SW;
+                const int off = (a - a0) * g.S * g.IWp + bb * g.S;
+                float av[2], bv[2];
 #pragma unroll
-                for (int i = 0; i < 2; ++i) a[i] = gl[(i * 32 + l32) * gl_stride + 2 * k + h];
+                for (int i = 0; i < 2; ++i) av[i] = gl[(i * 32 + l32) * gl_stride + 2 * k + h];
 #pragma unroll
                 for (int jt = 0; jt < 2; ++jt) bv[jt] = slab[toff[jt] >= 0 ? off + toff[jt] : zero_at];
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int jt = 0; jt < 2; ++jt)
-                        acc[i][jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bv[jt], acc[i][jt], 0, 0, 0);
+                        acc[i][jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[jt], acc[i][jt], 0, 0, 0);
             }
         }
     }
@@ -500,39 +715,61 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restri
 // ---------------------------------------------------------------------------------------
 static int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
-struct ConvPlan {
-    ConvGeom g;
-    int waves, wm, wn;   // tile shape
-    int pt, ntile;
-    size_t lds;
-};
-
-static int out_rows_touched(int pt, int OW, int OH) {
-    int r = (pt + OW - 2) / OW + 1;
-    return r < OH ? r : OH;
+// grid rows touched by `pt` consecutive grid pixels that start at a multiple of pt
+static int rows_touched(int pt, int SW, int SH) {
+    int r = (pt % SW == 0) ? pt / SW : (pt + SW - 2) / SW + 1;
+    return r < SH ? r : SH;
 }
 
 static void set_attr_once(const void* fn) {
     (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
-template <int WAVES, int WM, int WN>
-static int launch_conv(const ConvGeom& g, size_t lds, const float* x, const float* stats, const float* wp,
-                       const float* bias, float* out, bool stem, hipStream_t st) {
-    constexpr int PT = WAVES * WM * 32, NTILE = WN * 32;
-    const int P = g.OH * g.OW;
-    dim3 grid((P + PT - 1) / PT, g.CoutP / NTILE, g.B);
-    if (stem) {
-        static bool once = false;
-        if (!once) { set_attr_once(reinterpret_cast<const void*>(conv_stem_kernel<WAVES, WM, WN>)); once = true; }
-        hipLaunchKernelGGL((conv_stem_kernel<WAVES, WM, WN>), grid, dim3(WAVES * 64), lds, st, g, x, wp, bias, out);
-    } else {
-        static bool once = false;
-        if (!once) { set_attr_once(reinterpret_cast<const void*>(conv_mfma_kernel<WAVES, WM, WN>)); once = true; }
-        hipLaunchKernelGGL((conv_mfma_kernel<WAVES, WM, WN>), grid, dim3(WAVES * 64), lds, st, g, x, stats, wp, bias,
-                           out);
-    }
+static void finish_geom(ConvGeom& g, int KWe) {
+    g.IWp = (g.SW - 1) * g.S + KWe;
+    g.m_iwp = magic_of(g.IWp);
+    g.m_sw = magic_of(g.SW);
+}
+
+template <int CK>
+static void launch_conv_t(const ConvGeom& g, size_t lds, const float* x, const float* stats, const float* wp,
+                          const float* bias, float* out, hipStream_t st) {
+    constexpr int PT = 256, NTILE = 96;
+    static bool once = false;
+    if (!once) { set_attr_once(reinterpret_cast<const void*>(conv_mfma_kernel<CK>)); once = true; }
+    const long Q = (long)g.B * g.SH * g.SW;
+    dim3 grid((unsigned)((Q + PT - 1) / PT), g.CoutP / NTILE, 1);
+    hipLaunchKernelGGL((conv_mfma_kernel<CK>), grid, dim3(256), lds, st, g, x, stats, wp, bias, out);
+}
+
+// One grid over all (sample, grid pixel) rows of the launch.
+static int launch_conv(ConvGeom g, const float* x, const float* stats, const float* wp, const float* bias, float* out,
+                       hipStream_t st) {
+    const int P = g.SH * g.SW;
+    constexpr int PT = 256;
+    MV_REQUIRE(P >= PT, E_SHAPE, "mdnvae_conv2d: plane of %d pixels is smaller than the %d-pixel tile", P, PT);
+    // slab rows of a 256-row tile: one segment starting anywhere in a plane, or the tail of one
+    // sample plus the head of the next (each segment carries its own KHe halo)
+    const int one = ((PT + g.SW - 2) / g.SW) * g.S + g.KHe;
+    const int two = (PT / g.SW) * g.S + 2 * g.KHe;
+    const int rows = one > two ? one : two;
+    g.slab_stride = rows * g.IWp;
+    auto lds_of = [&](int ck) {
+        return ((size_t)2 * MAX_TAPS * ck * 96 + (size_t)2 * ck * g.slab_stride + 2 * 4 * ck + g.slab_stride) * 4;
+    };
+    // 4 input channels per chunk keeps three workgroups resident per CU
+    const size_t lds = lds_of(4);
+    MV_REQUIRE(lds <= 160 * 1024, E_SHAPE, "mdnvae_conv2d: tile needs %zu bytes of LDS", lds);
+    launch_conv_t<4>(g, lds, x, stats, wp, bias, out, st);
+    MV_LAUNCH_CHECK("conv_mfma_kernel");
     return 0;
+}
+
+static int wgrad_groups(int B, int ntiles) {
+    int G = 512 / ntiles;
+    if (G < 1) G = 1;
+    if (G > B) G = B;
+    return G;
 }
 
 }  // namespace mdnvae
@@ -576,77 +813,93 @@ int mdnvae_conv2d(const float* x, const float* in_stats, int relu_in, const floa
     if (B == 0) return 0;
     MV_REQUIRE(x && packed_w && out, E_ARG, "mdnvae_conv2d: null pointer");
     MV_REQUIRE(B <= 65535, E_SHAPE, "mdnvae_conv2d: batch %d exceeds the grid limit 65535", B);
-    MV_REQUIRE(KS == 3 || KS == 7, E_SHAPE, "mdnvae_conv2d: kernel size %d (3 or 7 supported)", KS);
     MV_REQUIRE(stride == 1 || stride == 2, E_SHAPE, "mdnvae_conv2d: stride %d", stride);
     MV_REQUIRE(!(reflect && (transposed || stride != 1)), E_SHAPE, "mdnvae_conv2d: reflection padding needs stride 1");
     MV_REQUIRE(Cin == 1 || Cin % 8 == 0, E_SHAPE, "mdnvae_conv2d: Cin %d must be 1 or a multiple of 8", Cin);
     MV_REQUIRE(!(Cin == 1 && (transposed || in_stats)), E_SHAPE, "mdnvae_conv2d: single-channel input is forward only");
+    MV_REQUIRE((Cin == 1 && KS == 7) || (Cin > 1 && KS == 3), E_SHAPE,
+               "mdnvae_conv2d: supported kernels: 7x7 on one channel, 3x3 on many (got k%d, Cin %d)", KS, Cin);
+    hipStream_t st = (hipStream_t)stream;
     ConvGeom g{};
-    g.B = B; g.Cin = Cin; g.H = H; g.W = W; g.Cout = Cout; g.OH = OH; g.OW = OW; g.KS = KS;
+    g.B = B; g.Cin = Cin; g.H = H; g.W = W; g.Cout = Cout; g.OHf = OH; g.OWf = OW;
     g.relu_in = relu_in;
+    g.osy = g.osx = 1; g.oy0 = g.ox0 = 0;
     if (!transposed) {
-        g.S = stride; g.pad = pad; g.reflect = reflect; g.dil = 1; g.VH = H; g.VW = W;
         MV_REQUIRE(OH == (H + 2 * pad - KS) / stride + 1 && OW == (W + 2 * pad - KS) / stride + 1, E_SHAPE,
                    "mdnvae_conv2d: output %dx%d does not match input %dx%d k%d s%d p%d", OH, OW, H, W, KS, stride, pad);
         MV_REQUIRE(!reflect || (pad < H && pad < W), E_SHAPE, "mdnvae_conv2d: reflection pad %d too large", pad);
-    } else {
-        // correlation of the zero-inserted, zero-padded gradient with the flipped weights:
-        // here (H,W) is the gradient w.r.t. the forward output and (OH,OW) the forward input plane
-        g.S = 1; g.pad = KS - 1 - pad; g.reflect = 0; g.dil = stride;
-        g.VH = 1 << 28; g.VW = 1 << 28;   // the upper bound is the gradient's own extent (H, W)
-        MV_REQUIRE(g.pad >= 0, E_SHAPE, "mdnvae_conv2d: transposed padding %d", pad);
-        MV_REQUIRE(H == (OH + 2 * pad - KS) / stride + 1 && W == (OW + 2 * pad - KS) / stride + 1, E_SHAPE,
-                   "mdnvae_conv2d: gradient %dx%d is not the k%d s%d p%d image of a %dx%d plane", H, W, KS, stride, pad,
-                   OH, OW);
-    }
-    g.IWp = (OW - 1) * g.S + KS;
-    const int P = OH * OW;
-    const bool stem = (Cin == 1);
-    int waves, wm, wn;
-    if (stem) {
-        waves = 4; wm = 2; wn = 2;
-        g.CoutP = round_up(Cout, 64);
-    } else {
-        wn = 3;
+        g.SH = OH; g.SW = OW; g.S = stride; g.pad = pad; g.reflect = reflect; g.KHe = KS;
+        finish_geom(g, KS);
+        if (Cin == 1) {
+            constexpr int WAVES = 4, WM = 2, WN = 2, PT = WAVES * WM * 32;
+            g.CoutP = round_up(Cout, 64);
+            const int rows = (rows_touched(PT, g.SW, g.SH) - 1) * g.S + KS;
+            g.slab_stride = rows * g.IWp + 1;
+            const size_t lds = ((size_t)g.slab_stride + (size_t)((KS * KS + 1) & ~1) * WN * 32) * 4;
+            MV_REQUIRE(lds <= 160 * 1024, E_SHAPE, "mdnvae_conv2d: tile needs %zu bytes of LDS", lds);
+            static bool once = false;
+            if (!once) { set_attr_once(reinterpret_cast<const void*>(conv_stem_kernel<WAVES, WM, WN>)); once = true; }
+            dim3 grid((OH * OW + PT - 1) / PT, g.CoutP / (WN * 32), B);
+            hipLaunchKernelGGL((conv_stem_kernel<WAVES, WM, WN>), grid, dim3(WAVES * 64), lds, st, g, KS, x, packed_w,
+                               bias, out);
+            MV_LAUNCH_CHECK("conv_stem_kernel");
+            return 0;
+        }
         g.CoutP = round_up(Cout, 96);
-        // pixel tile of 256, 320 or 384: the one that wastes the smallest share of MFMA rows
-        wm = 2; waves = 4;
-        double best = 2.0;
-        for (int wv = 4; wv <= 6; ++wv) {
-            const int t = wv * 64;
-            const double waste = (double)(round_up(P, t) - P) / round_up(P, t);
-            if (waste < best - 1e-9) { best = waste; waves = wv; }
+        g.ntaps = 9;
+        for (int t = 0; t < 9; ++t) {
+            g.tap_off[t] = (t / 3) * g.IWp + (t % 3);
+            g.tap_w[t] = t;
         }
+        return launch_conv(g, x, in_stats, packed_w, bias, out, st);
     }
-    const int pt = waves * wm * 32;
-    const int rows = (out_rows_touched(pt, OW, OH) - 1) * g.S + KS;
-    g.slab_stride = rows * g.IWp + 1;
-    const int KK = KS * KS;
-    size_t lds;
-    if (stem) {
-        g.CK = 1;
-        lds = ((size_t)g.slab_stride + (size_t)((KK + 1) & ~1) * wn * 32) * 4;
-    } else {
-        g.CK = 8;
-        lds = ((size_t)g.CK * g.slab_stride + (size_t)KK * g.CK * wn * 32) * 4;
-        if (lds > 64 * 1024 && Cin % 4 == 0) {
-            g.CK = 4;
-            lds = ((size_t)g.CK * g.slab_stride + (size_t)KK * g.CK * wn * 32) * 4;
+    // ---- data gradient: x = gradient w.r.t. the conv output [B,Cin,H,W], out = gradient w.r.t. its input
+    MV_REQUIRE(pad >= 0 && pad <= KS - 1, E_SHAPE, "mdnvae_conv2d: transposed padding %d", pad);
+    MV_REQUIRE(H == (OH + 2 * pad - KS) / stride + 1 && W == (OW + 2 * pad - KS) / stride + 1, E_SHAPE,
+               "mdnvae_conv2d: gradient %dx%d is not the k%d s%d p%d image of a %dx%d plane", H, W, KS, stride, pad, OH,
+               OW);
+    g.CoutP = round_up(Cout, 96);
+    g.reflect = 0;
+    g.S = 1;
+    if (stride == 1) {
+        g.SH = OH; g.SW = OW; g.pad = KS - 1 - pad; g.KHe = KS;
+        finish_geom(g, KS);
+        g.ntaps = 9;
+        for (int t = 0; t < 9; ++t) {
+            g.tap_off[t] = (t / 3) * g.IWp + (t % 3);
+            g.tap_w[t] = t;                       // the packed copy is already flipped
         }
+        return launch_conv(g, x, in_stats, packed_w, nullptr, out, st);
     }
-    MV_REQUIRE(lds <= 160 * 1024, E_SHAPE, "mdnvae_conv2d: tile needs %zu bytes of LDS", lds);
-    hipStream_t st = (hipStream_t)stream;
-    if (stem) launch_conv<4, 2, 2>(g, lds, x, nullptr, packed_w, bias, out, true, st);
-    else if (waves == 6) launch_conv<6, 2, 3>(g, lds, x, in_stats, packed_w, bias, out, false, st);
-    else if (waves == 5) launch_conv<5, 2, 3>(g, lds, x, in_stats, packed_w, bias, out, false, st);
-    else launch_conv<4, 2, 3>(g, lds, x, in_stats, packed_w, bias, out, false, st);
-    MV_LAUNCH_CHECK("conv_mfma_kernel");
+    // stride 2, 3x3, pad 1: input pixel (2a+py, 2b+px) receives kernel rows ky with (py+1-ky) even
+    MV_REQUIRE(KS == 3 && pad == 1, E_SHAPE, "mdnvae_conv2d: stride-2 data gradient supports k3 p1");
+    for (int py = 0; py < 2; ++py)
+        for (int px = 0; px < 2; ++px) {
+            ConvGeom q = g;
+            q.SH = (OH - py + 1) / 2; q.SW = (OW - px + 1) / 2;
+            if (q.SH <= 0 || q.SW <= 0) continue;
+            q.osy = q.osx = 2; q.oy0 = py; q.ox0 = px; q.pad = 0;
+            q.KHe = py ? 2 : 1;
+            finish_geom(q, px ? 2 : 1);
+            // (ky, dy): py == 0 -> (1, 0);  py == 1 -> (0, 1), (2, 0)
+            const int kys[2][2] = {{1, -1}, {0, 2}}, dys[2][2] = {{0, 0}, {1, 0}};
+            q.ntaps = 0;
+            for (int iy = 0; iy < (py ? 2 : 1); ++iy)
+                for (int ix = 0; ix < (px ? 2 : 1); ++ix) {
+                    const int ky = kys[py][iy], kx = kys[px][ix];
+                    q.tap_off[q.ntaps] = dys[py][iy] * q.IWp + dys[px][ix];
+                    q.tap_w[q.ntaps] = (2 - ky) * 3 + (2 - kx);      // index in the flipped packed copy
+                    ++q.ntaps;
+                }
+            if (int rc = launch_conv(q, x, in_stats, packed_w, nullptr, out, st)) return rc;
+        }
     return 0;
 }
 
 size_t mdnvae_conv_wgrad_workspace_floats(int B, int Cout, int Cin, int KS) {
-    const int G = B < 64 ? B : 64;
-    return (size_t)G * KS * KS * Cout * Cin;
+    if (Cin == 1) return (size_t)wgrad_groups(B, 1) * Cout * KS * KS;
+    const int ntiles = ((Cout + 63) / 64) * ((Cin + 63) / 64);
+    return (size_t)wgrad_groups(B, ntiles) * KS * KS * Cout * Cin;
 }
 
 // dW [Cout,Cin,KS,KS] = sum over samples and pixels of grad_out x (padded, normalised) input.
@@ -661,17 +914,17 @@ int mdnvae_conv2d_wgrad(const float* x, const float* in_stats, int relu_in, cons
                "mdnvae_conv2d_wgrad: output size mismatch");
     MV_REQUIRE(Cin > 1 || Cout <= 64, E_SHAPE, "mdnvae_conv2d_wgrad: single-channel input supports Cout <= 64");
     ConvGeom g{};
-    g.B = B; g.Cin = Cin; g.H = H; g.W = W; g.Cout = Cout; g.OH = OH; g.OW = OW; g.KS = KS;
-    g.S = stride; g.pad = pad; g.reflect = reflect; g.dil = 1; g.VH = H; g.VW = W; g.relu_in = relu_in;
-    g.IWp = (OW - 1) * stride + KS;
+    g.B = B; g.Cin = Cin; g.H = H; g.W = W; g.Cout = Cout; g.OHf = OH; g.OWf = OW; g.SH = OH; g.SW = OW;
+    g.osy = g.osx = 1;
+    g.S = stride; g.pad = pad; g.reflect = reflect; g.relu_in = relu_in; g.KHe = KS;
+    finish_geom(g, KS);
     const int KK = KS * KS;
-    const int G = B < 64 ? B : 64;
-    const int spg = (B + G - 1) / G;
-    const int Gz = (B + spg - 1) / spg;
     hipStream_t st = (hipStream_t)stream;
     if (Cin == 1) {
+        const int Gz0 = wgrad_groups(B, 1);
+        const int spg = (B + Gz0 - 1) / Gz0, Gz = (B + spg - 1) / spg;
         const int ptw = 256;
-        const int rows = (out_rows_touched(ptw, OW, OH) - 1) * stride + KS;
+        const int rows = (rows_touched(ptw, OW, OH) - 1) * stride + KS;
         g.slab_stride = rows * g.IWp + 2;
         size_t lds = ((size_t)64 * (ptw + 1) + g.slab_stride) * 4;
         const size_t red = (size_t)4 * 64 * 65 * 4;
@@ -679,7 +932,7 @@ int mdnvae_conv2d_wgrad(const float* x, const float* in_stats, int relu_in, cons
         MV_REQUIRE(lds <= 160 * 1024, E_SHAPE, "mdnvae_conv2d_wgrad: needs %zu bytes of LDS", lds);
         static bool once = false;
         if (!once) { set_attr_once(reinterpret_cast<const void*>(conv_stem_wgrad_kernel)); once = true; }
-        hipLaunchKernelGGL(conv_stem_wgrad_kernel, dim3(1, 1, Gz), dim3(256), lds, st, g, x, grad_out, ptw, spg,
+        hipLaunchKernelGGL(conv_stem_wgrad_kernel, dim3(1, 1, Gz), dim3(256), lds, st, g, KS, x, grad_out, ptw, spg,
                            workspace);
         MV_LAUNCH_CHECK("conv_stem_wgrad_kernel");
         const long n = (long)Cout * KK;
@@ -688,20 +941,33 @@ int mdnvae_conv2d_wgrad(const float* x, const float* in_stats, int relu_in, cons
         MV_LAUNCH_CHECK("sum_partials_kernel");
         return 0;
     }
-    // pixel chunk: the largest of 128/64/32 whose tiles fit in LDS
-    int ptw = 128;
-    size_t lds = 0;
-    for (; ptw >= 32; ptw >>= 1) {
-        const int rows = (out_rows_touched(ptw, OW, OH) - 1) * stride + KS;
-        g.slab_stride = (rows * g.IWp) | 1;
-        lds = ((size_t)64 * (ptw + 1) + (size_t)64 * g.slab_stride) * 4;
-        if (lds <= 150 * 1024) break;
+    // pixel chunk: whole grid rows when they fit, so that two workgroups share a CU's LDS
+    const int cslab = Cin < 64 ? Cin : 64;
+    int best_ptw = 0;
+    size_t best_lds = 0;
+    auto try_ptw = [&](int ptw, size_t cap) {
+        if (ptw < 2 || ptw > 128 || (ptw & 1)) return;
+        const int rows = (rows_touched(ptw, OW, OH) - 1) * stride + KS;
+        const int ss = (rows * g.IWp) | 1;
+        const size_t lds = ((size_t)64 * (ptw + 1) + (size_t)cslab * ss) * 4;
+        if (lds <= cap && ptw > best_ptw) { best_ptw = ptw; best_lds = lds; }
+    };
+    for (size_t cap : {(size_t)80 * 1024, (size_t)160 * 1024}) {
+        for (int k = 1; k * OW <= 128; ++k) try_ptw(k * OW, cap);
+        for (int ptw : {128, 96, 64, 48, 32, 16}) try_ptw(ptw, cap);
+        if (best_ptw) break;
     }
-    MV_REQUIRE(ptw >= 32, E_SHAPE, "mdnvae_conv2d_wgrad: tile needs %zu bytes of LDS", lds);
+    MV_REQUIRE(best_ptw > 0, E_SHAPE, "mdnvae_conv2d_wgrad: no pixel chunk fits in LDS");
+    const int ptw = best_ptw;
+    g.slab_stride = (((rows_touched(ptw, OW, OH) - 1) * stride + KS) * g.IWp) | 1;
+    const int ntiles = ((Cout + 63) / 64) * ((Cin + 63) / 64);
+    const int Gz0 = wgrad_groups(B, ntiles);
+    const int spg = (B + Gz0 - 1) / Gz0, Gz = (B + spg - 1) / spg;
     static bool once = false;
-    if (!once) { set_attr_once(reinterpret_cast<const void*>(conv_wgrad_kernel<9>)); once = true; }
+    if (!once) { set_attr_once(reinterpret_cast<const void*>(conv_wgrad_kernel)); once = true; }
     dim3 grid((Cout + 63) / 64, (Cin + 63) / 64, Gz);
-    hipLaunchKernelGGL(conv_wgrad_kernel<9>, grid, dim3(WG_NT), lds, st, g, x, in_stats, grad_out, ptw, spg, workspace);
+    hipLaunchKernelGGL(conv_wgrad_kernel, grid, dim3(WG_NT), best_lds, st, g, x, in_stats, grad_out, ptw, cslab, spg,
+                       workspace);
     MV_LAUNCH_CHECK("conv_wgrad_kernel");
     const long total = (long)KK * Cout * Cin;
     hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, workspace, Gz,
