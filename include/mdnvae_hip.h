@@ -169,7 +169,11 @@ int mdnvae_conv2d_wgrad(const float* x, const float* in_stats, int relu_in, cons
 
 /* stats[plane] = {mean, 1/sqrt(biased var + 1e-5)} of each of nplanes planes of P <= 8192 floats. */
 int mdnvae_plane_stats(const float* x, long nplanes, int P, float* stats, void* stream);
-/* out = (skip ? skip : 0) + [relu]((raw - mean)*rstd): the materialised activation
+/* Instance norm in one pass over raw: stats[plane] = {mean, rstd} and
+ * out = (skip ? skip : 0) + [relu]((raw - mean)*rstd)  (InstanceNorm2d + ReLU, or x + block(x)). */
+int mdnvae_inorm_fwd(const float* raw, const float* skip, int relu, long nplanes, int P, float* out, float* stats,
+                     void* stream);
+/* out = (skip ? skip : 0) + [relu]((raw - mean)*rstd) from given stats: the materialised activation
  * (x + block(x) of the ResidualBlock when skip is given). */
 int mdnvae_norm_act_add(const float* raw, const float* stats, const float* skip, int relu, long nplanes, int P,
                         float* out, void* stream);

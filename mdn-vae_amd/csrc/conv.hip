@@ -128,8 +128,8 @@ typedef float f32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
 #define MV_GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 #define MV_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 
-template <int CK>
-__global__ __launch_bounds__(256, 3) void conv_mfma_kernel(ConvGeom g, const float* __restrict__ x,
+template <int CK, int SI>
+__global__ __launch_bounds__(256, (SI > 8 ? 2 : 3)) void conv_mfma_kernel(ConvGeom g, const float* __restrict__ x,
                                                             const float* __restrict__ stats,
                                                             const float* __restrict__ wp,
                                                             const float* __restrict__ bias,
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_kernel(ConvGeom g, const flo
     float* wl0 = smem;                                    // [2][ntaps][CK][NTILE]
     float* slab0 = smem + 2 * WBUF;                       // [2][CK][slab_elems]
     float* st0 = slab0 + 2 * sbuf;                        // [2][2 samples][CK][2]
-    int* tbl = reinterpret_cast<int*>(st0 + 2 * 4 * CK);  // [slab_stride] source offsets
+    static_assert(CK == WAVES, "wave w stages input channel c0 + w of every chunk");
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, l32 = lane & 31;
     const int P = g.SH * g.SW;
@@ -164,36 +164,40 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_kernel(ConvGeom g, const flo
     const int pe1 = two ? (int)(qlast - (long)(s0 + 1) * P) : 0;
     const int seg1 = two ? (fdiv(pe1, g.m_sw) * g.S + g.KHe) * g.IWp : 0;
     const int slab_elems = seg0 + seg1;                   // <= slab_stride; also the channel stride
-    const unsigned m_slab = magic_of(slab_elems);
     const int in_plane = g.H * g.W;
     const bool norm = stats != nullptr;
 
-    // source offset (relative to channel 0 of sample s0; -1 = padding) of every slab position
-    for (int rem = tid; rem < slab_elems; rem += NT) {
-        const int sg = rem >= seg0;
-        const int rr = sg ? rem - seg0 : rem;
-        const int r = fdiv(rr, g.m_iwp), col = rr - r * g.IWp;
-        int vy = (sg ? 0 : a00 * g.S) + r - g.pad, vx = col - g.pad;
-        bool ok = true;
-        if (g.reflect) {
-            vy = vy < 0 ? -vy : (vy >= g.H ? 2 * (g.H - 1) - vy : vy);
-            vx = vx < 0 ? -vx : (vx >= g.W ? 2 * (g.W - 1) - vx : vx);
-        } else {
-            ok = vy >= 0 && vy < g.H && vx >= 0 && vx < g.W;
-        }
-        tbl[rem] = ok ? sg * g.Cin * in_plane + vy * g.W + vx : -1;
-    }
-    __syncthreads();
-    const int stotal = CK * slab_elems;
-    {   // padding positions of both buffers, once
-        const float fill = norm ? __builtin_nanf("") : 0.0f;
-        for (int idx = tid; idx < stotal; idx += NT) {
-            const int c = fdiv(idx, m_slab), rem = idx - c * slab_elems;
-            if (tbl[rem] < 0) {
-                slab0[idx] = fill;
-                slab0[sbuf + idx] = fill;
+    // Wave w stages channel c0 + w of every chunk; lane l owns slab positions l, l+64, ...  Their
+    // source offsets (relative to channel 0 of sample s0; -1 = padding, -2 = past the slab) are the
+    // same for every chunk, so they are computed once and kept in registers.
+    int soff[SI];
+#pragma unroll
+    for (int i = 0; i < SI; ++i) {
+        const int rem = i * 64 + lane;
+        soff[i] = -2;
+        if (rem < slab_elems) {
+            const int sg = rem >= seg0;
+            const int rr = sg ? rem - seg0 : rem;
+            const int r = fdiv(rr, g.m_iwp), col = rr - r * g.IWp;
+            int vy = (sg ? 0 : a00 * g.S) + r - g.pad, vx = col - g.pad;
+            bool ok = true;
+            if (g.reflect) {
+                vy = vy < 0 ? -vy : (vy >= g.H ? 2 * (g.H - 1) - vy : vy);
+                vx = vx < 0 ? -vx : (vx >= g.W ? 2 * (g.W - 1) - vx : vx);
+            } else {
+                ok = vy >= 0 && vy < g.H && vx >= 0 && vx < g.W;
             }
+            soff[i] = ok ? sg * g.Cin * in_plane + vy * g.W + vx : -1;
         }
+    }
+    {   // padding positions of both buffers, once (the DMA never writes them)
+        const float fill = norm ? __builtin_nanf("") : 0.0f;
+#pragma unroll
+        for (int i = 0; i < SI; ++i)
+            if (soff[i] == -1) {
+                slab0[wave * slab_elems + i * 64 + lane] = fill;
+                slab0[sbuf + wave * slab_elems + i * 64 + lane] = fill;
+            }
     }
 
     int lane_base[WM], lane_seg[WM];
@@ -219,17 +223,12 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_kernel(ConvGeom g, const flo
     const int s1 = min(s0 + 1, g.B - 1);
 
     auto issue = [&](int c0, int buf) {
-        float* sdst = slab0 + buf * sbuf;
-        for (int base = 0; base < stotal; base += NT) {
-            const int idx = base + tid;
-            if (idx < stotal) {
-                const int c = fdiv(idx, m_slab), rem = idx - c * slab_elems;
-                const int off = tbl[rem];
-                if (off >= 0)
-                    __builtin_amdgcn_global_load_lds(MV_GLOBAL_PTR(xs0 + (long)(c0 + c) * in_plane + off),
-                                                     MV_LDS_PTR(sdst + base + wave * 64), 4, 0, 0);
-            }
-        }
+        float* sdst = slab0 + buf * sbuf + wave * slab_elems;
+        const float* src = xs0 + (long)(c0 + wave) * in_plane;
+#pragma unroll
+        for (int i = 0; i < SI; ++i)
+            if (soff[i] >= 0)
+                __builtin_amdgcn_global_load_lds(MV_GLOBAL_PTR(src + soff[i]), MV_LDS_PTR(sdst + i * 64), 4, 0, 0);
         float* wdst = wl0 + buf * WBUF;
         for (int base = 0; base < wtotal; base += NT) {
             const int i4 = base + tid;
@@ -461,101 +460,184 @@ __global__ void conv_pack_stem_kernel(const float* __restrict__ w, int Cout, int
 // weight gradient
 // ---------------------------------------------------------------------------------------
 // Workgroup tile: 64 output channels x 64 input channels x 9 taps; 4 waves as 2 (n) x 2 (c).
-// K dimension = output pixels of the samples of this group.  partial [G][9][Cout][Cin]
+// K dimension = output pixels of the samples of this group, in chunks of ptw pixels (whole grid
+// rows).  Both operand tiles are staged by LDS-DMA into double buffers while the previous
+// chunk's MFMAs run; the source-offset table of chunk k+2 is computed during chunk k.  The
+// producer's instance norm + ReLU is applied to the B operand after its LDS read.
+// partial [G][9][Cout][Cin]
 constexpr int WG_NT = 256;
+template <bool NORM>
 __global__ __launch_bounds__(WG_NT, 2) void conv_wgrad_kernel(ConvGeom g, const float* __restrict__ x,
                                                               const float* __restrict__ stats,
                                                               const float* __restrict__ gout, int ptw, int cslab,
                                                               int samples_per_group, float* __restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int KKT = 9;
-    const int gl_stride = ptw + 1;
-    float* gl = smem;                               // [64][ptw+1]
-    float* slab = smem + 64 * gl_stride;            // [cslab][slab_stride]
+    const int GS = ptw + 1;                          // odd row stride of the grad_out tile
+    const int gbuf = 64 * GS, sbuf = cslab * g.slab_stride;
+    float* gl0 = smem;                               // [2][64][GS]
+    float* slab0 = smem + 2 * gbuf;                  // [2][cslab][slab_stride]
+    int* tbl0 = reinterpret_cast<int*>(slab0 + 2 * sbuf);   // [2][slab_stride]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, l32 = lane & 31;
     const int wn = wave >> 1, wc = wave & 1;
     const int n0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
     const int P = g.SH * g.SW;
     const int b_begin = blockIdx.z * samples_per_group;
     const int b_end = min(g.B, b_begin + samples_per_group);
-    const unsigned m_ptw = magic_of(ptw);
+    const int npc = (P + ptw - 1) / ptw;             // chunks per plane
+    const int nchunks = (b_end - b_begin) * npc;
+    const unsigned m_gs = magic_of(GS), m_ss = magic_of(g.slab_stride);
+    const int in_plane = g.H * g.W;
+    constexpr bool norm = NORM;
+    const float fill = norm ? __builtin_nanf("") : 0.0f;
 
     f32x16 acc[KKT];
 #pragma unroll
     for (int t = 0; t < KKT; ++t)
 #pragma unroll
         for (int j = 0; j < 16; ++j) acc[t][j] = 0.0f;
-    // lanes of a channel row that does not exist read row 0 (its products are discarded)
+    // lanes of a channel row that does not exist read row 0 (their products are discarded)
     const int crow = (c0 + wc * 32 + l32 < g.Cin) ? wc * 32 + l32 : 0;
 
-    for (int b = b_begin; b < b_end; ++b) {
-        for (int p0 = 0; p0 < P; p0 += ptw) {
-            const int a0 = fdiv(p0, g.m_sw);
-            const int plast = min(P - 1, p0 + ptw - 1);
-            const int nrows = (fdiv(plast, g.m_sw) - a0) * g.S + g.KHe;
-            const int pr0 = a0 * g.S;
-            const int slab_elems = nrows * g.IWp;
-            __syncthreads();
-            {   // grad_out tile, E loads in flight per thread
-                constexpr int E = 8;
-                const int total = 64 * ptw;
-                for (int base = 0; base < total; base += WG_NT * E) {
-                    float v[E];
-#pragma unroll
-                    for (int e = 0; e < E; ++e) {
-                        const int idx = base + tid + e * WG_NT;
-                        v[e] = 0.0f;
-                        if (idx < total) {
-                            const int n = fdiv(idx, m_ptw), pp = idx - n * ptw;
-                            if (n0 + n < g.Cout && p0 + pp < P) v[e] = gout[((long)b * g.Cout + n0 + n) * P + p0 + pp];
-                        }
-                    }
-#pragma unroll
-                    for (int e = 0; e < E; ++e) {
-                        const int idx = base + tid + e * WG_NT;
-                        if (idx < total) {
-                            const int n = fdiv(idx, m_ptw), pp = idx - n * ptw;
-                            gl[n * gl_stride + pp] = v[e];
-                        }
-                    }
-                }
+    // geometry of chunk j of a plane (rows are whole grid rows, or the plane is one chunk)
+    auto chunk_rows = [&](int j, int& a0, int& nrows) {
+        const int p0 = j * ptw;
+        a0 = fdiv(p0, g.m_sw);
+        nrows = (fdiv(min(P - 1, p0 + ptw - 1), g.m_sw) - a0) * g.S + g.KHe;
+    };
+    auto make_tbl = [&](int ci) {                    // source offsets of chunk ci into tbl[ci & 1]
+        if (ci >= nchunks) return;
+        int a0, nrows;
+        chunk_rows(ci % npc, a0, nrows);
+        int* tbl = tbl0 + (ci & 1) * g.slab_stride;
+        for (int rem = tid; rem < nrows * g.IWp; rem += WG_NT) {
+            const int r = fdiv(rem, g.m_iwp), col = rem - r * g.IWp;
+            int vy = a0 * g.S + r - g.pad, vx = col - g.pad;
+            bool ok = true;
+            if (g.reflect) {
+                vy = vy < 0 ? -vy : (vy >= g.H ? 2 * (g.H - 1) - vy : vy);
+                vx = vx < 0 ? -vx : (vx >= g.W ? 2 * (g.W - 1) - vx : vx);
+            } else {
+                ok = vy >= 0 && vy < g.H && vx >= 0 && vx < g.W;
             }
-            stage_slab<WG_NT, 8>(g, x, stats, b, c0, cslab, g.Cin, pr0, slab_elems, magic_of(slab_elems), slab, tid);
-            __syncthreads();
-            const float* ga = gl + (wn * 32 + l32) * gl_stride + h;
-            const float* sb = slab + crow * g.slab_stride;
-            // pixel (p0 + 2k + h): slab offset advanced by two pixels per step
-            int pix = p0 + h;
-            int a = fdiv(pix, g.m_sw), bb = pix - a * g.SW;
-            const int npairs = (min(ptw, P - p0) + 1) >> 1;
-            float av0, bv0[KKT], av1, bv1[KKT];
-            auto load_k = [&](int k, float& av, float (&bv)[KKT]) {
-                av = ga[2 * k];
-                // a pixel past the end of the plane carries a zero gradient; clamp its address
-                const int ac = min(a, g.SH - 1);
-                const int off = (ac - a0) * g.S * g.IWp + bb * g.S;
-#pragma unroll
-                for (int t = 0; t < KKT; ++t) bv[t] = sb[off + (t / 3) * g.IWp + (t % 3)];
-                bb += 2;
-                if (bb >= g.SW) {
-                    bb -= g.SW;
-                    ++a;
-                }
-            };
-            auto mma_k = [&](float av, float (&bv)[KKT]) {
-#pragma unroll
-                for (int t = 0; t < KKT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[t], acc[t], 0, 0, 0);
-            };
-            load_k(0, av0, bv0);
-            for (int k = 0; k < npairs; k += 2) {
-                if (k + 1 < npairs) load_k(k + 1, av1, bv1);
-                mma_k(av0, bv0);
-                if (k + 1 < npairs) {
-                    if (k + 2 < npairs) load_k(k + 2, av0, bv0);
-                    mma_k(av1, bv1);
+            tbl[rem] = ok ? vy * g.W + vx : -1;
+        }
+    };
+    auto issue = [&](int ci) {                       // DMA of chunk ci into buffer ci & 1
+        if (ci >= nchunks) return;
+        const int b = b_begin + ci / npc, j = ci % npc, p0 = j * ptw;
+        int a0, nrows;
+        chunk_rows(j, a0, nrows);
+        const int slab_elems = nrows * g.IWp;
+        float* gdst = gl0 + (ci & 1) * gbuf;
+        for (int base = 0; base < gbuf; base += WG_NT) {
+            const int idx = base + tid;
+            if (idx < gbuf) {
+                const int n = fdiv(idx, m_gs), pp = idx - n * GS;
+                if (pp < ptw && n0 + n < g.Cout && p0 + pp < P)
+                    __builtin_amdgcn_global_load_lds(MV_GLOBAL_PTR(gout + ((long)b * g.Cout + n0 + n) * P + p0 + pp),
+                                                     MV_LDS_PTR(gdst + base + wave * 64), 4, 0, 0);
+            }
+        }
+        float* sdst = slab0 + (ci & 1) * sbuf;
+        const int* tbl = tbl0 + (ci & 1) * g.slab_stride;
+        const float* xb = x + ((long)b * g.Cin + c0) * in_plane;
+        for (int base = 0; base < sbuf; base += WG_NT) {
+            const int idx = base + tid;
+            if (idx < sbuf) {
+                const int c = fdiv(idx, m_ss), rem = idx - c * g.slab_stride;
+                if (rem < slab_elems && c0 + c < g.Cin) {
+                    const int off = tbl[rem];
+                    if (off >= 0)
+                        __builtin_amdgcn_global_load_lds(MV_GLOBAL_PTR(xb + (long)c * in_plane + off),
+                                                         MV_LDS_PTR(sdst + base + wave * 64), 4, 0, 0);
+                    else
+                        sdst[idx] = fill;
                 }
             }
         }
+    };
+
+    make_tbl(0);
+    make_tbl(1);
+    // {mean, rstd} of this lane's channel for the chunk about to be computed.  They are plain
+    // global loads, so they are issued after a chunk's MFMA loop and complete at the next
+    // barrier together with the DMA (a wait on them inside the loop would drain the DMA early).
+    float mean_n = 0.0f, rstd_n = 1.0f;
+    auto fetch_stats = [&](int ci) {
+        if (norm && ci < nchunks) {
+            const long pl = (long)(b_begin + ci / npc) * g.Cin + c0 + crow;
+            mean_n = stats[2 * pl];
+            rstd_n = stats[2 * pl + 1];
+        }
+    };
+    fetch_stats(0);
+    __syncthreads();
+    issue(0);
+    for (int ci = 0; ci < nchunks; ++ci) {
+        __syncthreads();            // chunk ci has landed; buffers and table of ci+1 are free / ready
+        issue(ci + 1);
+        const int j = ci % npc, p0 = j * ptw;
+        int a0, nrows;
+        chunk_rows(j, a0, nrows);
+        const float mean = mean_n, rstd = rstd_n;
+        const float* ga = gl0 + (ci & 1) * gbuf + (wn * 32 + l32) * GS + h;
+        const float* sb = slab0 + (ci & 1) * sbuf + crow * g.slab_stride;
+        const int count = min(ptw, P - p0);
+        const int npairs = (count + 1) >> 1;
+        // grid pixel (p0 + 2k + h) walks the chunk two pixels per step; its slab offset moves by
+        // 2*S inside a grid row and jumps by row_jump when the column wraps
+        const int pix = min(p0 + h, P - 1);
+        const int arow = fdiv(pix, g.m_sw);
+        int bb = pix - arow * g.SW;
+        int off = (arow - a0) * g.S * g.IWp + bb * g.S;
+        const int row_jump = g.S * g.IWp - g.SW * g.S;
+        const int off_max = (nrows - g.KHe) * g.IWp + (g.SW - 1) * g.S;   // last valid grid pixel of the chunk
+        const int t1 = g.IWp, t2 = 2 * g.IWp;
+        float av0, bv0[KKT], av1, bv1[KKT];
+        // load_k only issues LDS reads (nothing consumes them), so the wait for step k+1's operands
+        // lands after step k's MFMAs have been issued
+        auto load_k = [&](int k, float& av, float (&bv)[KKT]) {
+            av = ga[2 * k];
+            const float* s0p = sb + min(off, off_max);
+            bv[0] = s0p[0]; bv[1] = s0p[1]; bv[2] = s0p[2];
+            bv[3] = s0p[t1]; bv[4] = s0p[t1 + 1]; bv[5] = s0p[t1 + 2];
+            bv[6] = s0p[t2]; bv[7] = s0p[t2 + 1]; bv[8] = s0p[t2 + 2];
+            bb += 2;
+            off += 2 * g.S;
+            if (bb >= g.SW) {
+                bb -= g.SW;
+                off += row_jump;
+            }
+        };
+        auto mma_k = [&](int k, float av, float (&bv)[KKT]) {
+            av = (2 * k + h < count) ? av : 0.0f;          // past the end of the plane: zero gradient
+            if (norm) {
+#pragma unroll
+                for (int t = 0; t < KKT; ++t) {
+                    float v = (bv[t] - mean) * rstd;
+                    if (g.relu_in) v = fmaxf(v, 0.0f);
+                    else v = (v != v) ? 0.0f : v;
+                    bv[t] = v;
+                }
+            } else if (g.relu_in) {
+#pragma unroll
+                for (int t = 0; t < KKT; ++t) bv[t] = fmaxf(bv[t], 0.0f);
+            }
+#pragma unroll
+            for (int t = 0; t < KKT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[t], acc[t], 0, 0, 0);
+        };
+        load_k(0, av0, bv0);
+        for (int k = 0; k < npairs; k += 2) {
+            if (k + 1 < npairs) load_k(k + 1, av1, bv1);
+            mma_k(k, av0, bv0);
+            if (k + 1 < npairs) {
+                if (k + 2 < npairs) load_k(k + 2, av0, bv0);
+                mma_k(k + 1, av1, bv1);
+            }
+        }
+        make_tbl(ci + 2);           // its buffer (ci & 1) was last read by issue(ci), before this chunk's barrier
+        fetch_stats(ci + 1);
     }
     // partial[z][tap][n][c]
     float* dst = partial + (long)blockIdx.z * KKT * g.Cout * g.Cin;
@@ -731,15 +813,15 @@ static void finish_geom(ConvGeom& g, int KWe) {
     g.m_sw = magic_of(g.SW);
 }
 
-template <int CK>
+template <int CK, int SI>
 static void launch_conv_t(const ConvGeom& g, size_t lds, const float* x, const float* stats, const float* wp,
                           const float* bias, float* out, hipStream_t st) {
     constexpr int PT = 256, NTILE = 96;
     static bool once = false;
-    if (!once) { set_attr_once(reinterpret_cast<const void*>(conv_mfma_kernel<CK>)); once = true; }
+    if (!once) { set_attr_once(reinterpret_cast<const void*>(conv_mfma_kernel<CK, SI>)); once = true; }
     const long Q = (long)g.B * g.SH * g.SW;
     dim3 grid((unsigned)((Q + PT - 1) / PT), g.CoutP / NTILE, 1);
-    hipLaunchKernelGGL((conv_mfma_kernel<CK>), grid, dim3(256), lds, st, g, x, stats, wp, bias, out);
+    hipLaunchKernelGGL((conv_mfma_kernel<CK, SI>), grid, dim3(256), lds, st, g, x, stats, wp, bias, out);
 }
 
 // One grid over all (sample, grid pixel) rows of the launch.
@@ -754,13 +836,13 @@ static int launch_conv(ConvGeom g, const float* x, const float* stats, const flo
     const int two = (PT / g.SW) * g.S + 2 * g.KHe;
     const int rows = one > two ? one : two;
     g.slab_stride = rows * g.IWp;
-    auto lds_of = [&](int ck) {
-        return ((size_t)2 * MAX_TAPS * ck * 96 + (size_t)2 * ck * g.slab_stride + 2 * 4 * ck + g.slab_stride) * 4;
-    };
+    MV_REQUIRE(g.slab_stride <= 24 * 64, E_SHAPE, "mdnvae_conv2d: slab of %d floats per channel is too large",
+               g.slab_stride);
     // 4 input channels per chunk keeps three workgroups resident per CU
-    const size_t lds = lds_of(4);
+    const size_t lds = ((size_t)2 * MAX_TAPS * 4 * 96 + (size_t)2 * 4 * g.slab_stride + 2 * 4 * 4) * 4;
     MV_REQUIRE(lds <= 160 * 1024, E_SHAPE, "mdnvae_conv2d: tile needs %zu bytes of LDS", lds);
-    launch_conv_t<4>(g, lds, x, stats, wp, bias, out, st);
+    if (g.slab_stride <= 7 * 64) launch_conv_t<4, 7>(g, lds, x, stats, wp, bias, out, st);
+    else launch_conv_t<4, 24>(g, lds, x, stats, wp, bias, out, st);
     MV_LAUNCH_CHECK("conv_mfma_kernel");
     return 0;
 }
@@ -941,33 +1023,46 @@ int mdnvae_conv2d_wgrad(const float* x, const float* in_stats, int relu_in, cons
         MV_LAUNCH_CHECK("sum_partials_kernel");
         return 0;
     }
-    // pixel chunk: whole grid rows when they fit, so that two workgroups share a CU's LDS
+    // pixel chunk = whole grid rows (so every chunk of a plane has the same slab shape); the
+    // largest one whose double-buffered tiles leave room for two workgroups per CU, else for one
     const int cslab = Cin < 64 ? Cin : 64;
     int best_ptw = 0;
     size_t best_lds = 0;
-    auto try_ptw = [&](int ptw, size_t cap) {
-        if (ptw < 2 || ptw > 128 || (ptw & 1)) return;
+    auto lds_of = [&](int ptw) {
         const int rows = (rows_touched(ptw, OW, OH) - 1) * stride + KS;
-        const int ss = (rows * g.IWp) | 1;
-        const size_t lds = ((size_t)64 * (ptw + 1) + (size_t)cslab * ss) * 4;
-        if (lds <= cap && ptw > best_ptw) { best_ptw = ptw; best_lds = lds; }
+        const size_t ss = (size_t)((rows * g.IWp) | 1);
+        return ((size_t)2 * 64 * (ptw + 1) + 2 * cslab * ss + 2 * ss) * 4;
     };
     for (size_t cap : {(size_t)80 * 1024, (size_t)160 * 1024}) {
-        for (int k = 1; k * OW <= 128; ++k) try_ptw(k * OW, cap);
-        for (int ptw : {128, 96, 64, 48, 32, 16}) try_ptw(ptw, cap);
+        for (int k = 1; k * OW <= 128; ++k) {
+            int ptw = k * OW;
+            if (ptw & 1) continue;
+            const int ss = (((rows_touched(ptw, OW, OH) - 1) * stride + KS) * g.IWp) | 1;
+            if (ss <= 8 * 64 && lds_of(ptw) <= cap && ptw > best_ptw) { best_ptw = ptw; best_lds = lds_of(ptw); }
+        }
         if (best_ptw) break;
     }
-    MV_REQUIRE(best_ptw > 0, E_SHAPE, "mdnvae_conv2d_wgrad: no pixel chunk fits in LDS");
+    MV_REQUIRE(best_ptw > 0, E_SHAPE, "mdnvae_conv2d_wgrad: no pixel chunk of whole rows fits in LDS (OW=%d)", OW);
     const int ptw = best_ptw;
-    g.slab_stride = (((rows_touched(ptw, OW, OH) - 1) * stride + KS) * g.IWp) | 1;
+    g.slab_stride = (((rows_touched(ptw, OW, OH) - 1) * stride + KS) * g.IWp) | 1;   // odd: conflict-free B reads
+    MV_REQUIRE(g.slab_stride <= 8 * 64, E_SHAPE, "mdnvae_conv2d_wgrad: slab of %d floats per channel is too large",
+               g.slab_stride);
     const int ntiles = ((Cout + 63) / 64) * ((Cin + 63) / 64);
     const int Gz0 = wgrad_groups(B, ntiles);
     const int spg = (B + Gz0 - 1) / Gz0, Gz = (B + spg - 1) / spg;
     static bool once = false;
-    if (!once) { set_attr_once(reinterpret_cast<const void*>(conv_wgrad_kernel)); once = true; }
+    if (!once) {
+        set_attr_once(reinterpret_cast<const void*>(conv_wgrad_kernel<false>));
+        set_attr_once(reinterpret_cast<const void*>(conv_wgrad_kernel<true>));
+        once = true;
+    }
     dim3 grid((Cout + 63) / 64, (Cin + 63) / 64, Gz);
-    hipLaunchKernelGGL(conv_wgrad_kernel, grid, dim3(WG_NT), best_lds, st, g, x, in_stats, grad_out, ptw, cslab, spg,
-                       workspace);
+    if (in_stats)
+        hipLaunchKernelGGL(conv_wgrad_kernel<true>, grid, dim3(WG_NT), best_lds, st, g, x, in_stats, grad_out, ptw,
+                           cslab, spg, workspace);
+    else
+        hipLaunchKernelGGL(conv_wgrad_kernel<false>, grid, dim3(WG_NT), best_lds, st, g, x, in_stats, grad_out, ptw,
+                           cslab, spg, workspace);
     MV_LAUNCH_CHECK("conv_wgrad_kernel");
     const long total = (long)KK * Cout * Cin;
     hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, workspace, Gz,

@@ -62,6 +62,54 @@ __global__ __launch_bounds__(256) void plane_stats_kernel(const float* __restric
     }
 }
 
+// Fused statistics + normalise: out = (skip ? skip : 0) + [relu]((raw - mean) * rstd), and
+// stats[plane] = {mean, rstd}.  The plane stays in registers between the two reductions and the
+// write, so raw is read once.
+template <int TPP, int EPT>
+__global__ __launch_bounds__(256) void inorm_fwd_kernel(const float* __restrict__ raw, const float* __restrict__ skip,
+                                                        int relu, long nplanes, int P, float* __restrict__ out,
+                                                        float* __restrict__ stats) {
+    __shared__ float scratch[4];
+    constexpr int PPB = 256 / TPP;
+    const int sub = threadIdx.x / TPP, t = threadIdx.x % TPP;
+    const long plane = (long)blockIdx.x * PPB + sub;
+    const bool live = plane < nplanes;
+    const long pl = live ? plane : 0;
+    const float* px = raw + pl * (long)P;
+    float v[EPT];
+    float s = 0.0f;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const int i = t + e * TPP;
+        v[e] = (live && i < P) ? px[i] : 0.0f;
+        s += v[e];
+    }
+    const float mean = plane_sum<TPP>(s, scratch, sub) / (float)P;
+    float q = 0.0f;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const int i = t + e * TPP;
+        const float d = (i < P) ? v[e] - mean : 0.0f;
+        q += d * d;
+    }
+    const float var = plane_sum<TPP>(q, scratch, sub) / (float)P;
+    const float rstd = 1.0f / sqrtf(var + IN_EPS);
+    if (live && t == 0) {
+        stats[2 * plane] = mean;
+        stats[2 * plane + 1] = rstd;
+    }
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const int i = t + e * TPP;
+        if (live && i < P) {
+            float o = (v[e] - mean) * rstd;
+            if (relu) o = fmaxf(o, 0.0f);
+            if (skip) o += skip[pl * (long)P + i];
+            out[pl * (long)P + i] = o;
+        }
+    }
+}
+
 // out = (skip ? skip : 0) + act((raw - mean) * rstd)
 __global__ __launch_bounds__(256) void norm_act_add_kernel(const float* __restrict__ raw, const float* __restrict__ stats,
                                                            const float* __restrict__ skip, int relu, long n, int P,
@@ -247,6 +295,22 @@ int mdnvae_plane_stats(const float* x, long nplanes, int P, float* stats, void* 
     MV_PLANE_DISPATCH(P, CALL);
 #undef CALL
     MV_LAUNCH_CHECK("plane_stats_kernel");
+    return 0;
+}
+
+int mdnvae_inorm_fwd(const float* raw, const float* skip, int relu, long nplanes, int P, float* out, float* stats,
+                     void* stream) {
+    MV_REQUIRE(nplanes >= 0 && P >= 1, E_ARG, "mdnvae_inorm_fwd: bad size");
+    MV_REQUIRE(P <= PLANE_MAX, E_SHAPE, "mdnvae_inorm_fwd: plane of %d elements exceeds %d", P, PLANE_MAX);
+    if (nplanes == 0) return 0;
+    MV_REQUIRE(raw && out && stats, E_ARG, "mdnvae_inorm_fwd: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+#define CALL(TPP, EPT)                                                                                        \
+    hipLaunchKernelGGL((inorm_fwd_kernel<TPP, EPT>), dim3((unsigned)((nplanes + (256 / TPP) - 1) / (256 / TPP))), \
+                       dim3(256), 0, st, raw, skip, relu, nplanes, P, out, stats)
+    MV_PLANE_DISPATCH(P, CALL);
+#undef CALL
+    MV_LAUNCH_CHECK("inorm_fwd_kernel");
     return 0;
 }
 

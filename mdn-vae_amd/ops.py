@@ -409,6 +409,15 @@ def _norm_act_add(raw, stats, skip, relu):
     return out
 
 
+def _inorm_fwd(raw, skip, relu):
+    """(activation, stats): instance norm (+ReLU) (+skip) of raw in one pass."""
+    B, C, H, W = raw.shape
+    out = torch.empty_like(raw)
+    st = torch.empty(B * C, 2, dtype=torch.float32, device=raw.device)
+    call("mdnvae_inorm_fwd", ptr(raw), ptr(skip), int(relu), B * C, H * W, ptr(out), ptr(st), stream())
+    return out, st
+
+
 def _inorm_bwd(raw, stats, gact, relu, folded):
     B, C, H, W = raw.shape
     graw = torch.empty_like(raw)
@@ -440,23 +449,23 @@ class _ConvEncoder(torch.autograd.Function):
         ws = [w for w in wb[0::2]]
         bs = [b for b in wb[1::2]]
         packed = [ly.pack(w, dev, need_bwd) for ly, w in zip(layers, ws)]
+        # every normalised activation is materialised once (one extra write per layer, small next to
+        # the convolutions), so the convolution kernels stage plain tensors
         raw1 = layers[0].fwd(x, None, 0, packed[0][0], bs[0], B)
-        st1 = _plane_stats(raw1)
-        raw2 = layers[1].fwd(raw1, st1, 1, packed[1][0], bs[1], B)
-        st2 = _plane_stats(raw2)
-        raw3 = layers[2].fwd(raw2, st2, 1, packed[2][0], bs[2], B)
-        st3 = _plane_stats(raw3)
-        xk = _norm_act_add(raw3, st3, None, 1)
-        saved = [x, raw1, st1, raw2, st2, raw3, st3, xk]
+        act1, st1 = _inorm_fwd(raw1, None, 1)
+        raw2 = layers[1].fwd(act1, None, 0, packed[1][0], bs[1], B)
+        act2, st2 = _inorm_fwd(raw2, None, 1)
+        raw3 = layers[2].fwd(act2, None, 0, packed[2][0], bs[2], B)
+        xk, st3 = _inorm_fwd(raw3, None, 1)
+        saved = [x, raw1, st1, act1, raw2, st2, act2, raw3, st3, xk]
         nres = (len(layers) - 3) // 2
         for k in range(nres):
             la, lb = layers[3 + 2 * k], layers[4 + 2 * k]
             ra = la.fwd(xk, None, 0, packed[3 + 2 * k][0], bs[3 + 2 * k], B)
-            sa = _plane_stats(ra)
-            rb = lb.fwd(ra, sa, 1, packed[4 + 2 * k][0], bs[4 + 2 * k], B)
-            sb = _plane_stats(rb)
-            xk = _norm_act_add(rb, sb, xk, 0)
-            saved += [ra, sa, rb, sb, xk]
+            aa, sa = _inorm_fwd(ra, None, 1)
+            rb = lb.fwd(aa, None, 0, packed[4 + 2 * k][0], bs[4 + 2 * k], B)
+            xk, sb = _inorm_fwd(rb, xk, 0)
+            saved += [ra, sa, aa, rb, sb, xk]
         H = layers[-1].oh
         K = 8
         PH = H // K
@@ -473,10 +482,10 @@ class _ConvEncoder(torch.autograd.Function):
         sv = ctx.saved_tensors
         nres = ctx.nres
         layers = encoder_layers(ctx.n_nodes, nres)
-        x, raw1, st1, raw2, st2, raw3, st3, x0 = sv[:8]
-        blocks = [sv[8 + 5 * k: 13 + 5 * k] for k in range(nres)]
-        argmax = sv[8 + 5 * nres]
-        wbwd = sv[9 + 5 * nres:]          # packed data-gradient weights of layers 1..
+        x, raw1, st1, act1, raw2, st2, act2, raw3, st3, x0 = sv[:10]
+        blocks = [sv[10 + 6 * k: 16 + 6 * k] for k in range(nres)]
+        argmax = sv[10 + 6 * nres]
+        wbwd = sv[11 + 6 * nres:]         # packed data-gradient weights of layers 1..
         B = x.shape[0]
         H = layers[-1].oh
         gfeat = _c(gfeat)
@@ -485,11 +494,11 @@ class _ConvEncoder(torch.autograd.Function):
         gw = [None] * len(layers)
         gb = [None] * len(layers)
         for k in range(nres - 1, -1, -1):
-            ra, sa, rb, sb, _ = blocks[k]
-            xin = x0 if k == 0 else blocks[k - 1][4]
+            ra, sa, aa, rb, sb, _ = blocks[k]
+            xin = x0 if k == 0 else blocks[k - 1][5]
             ia, ib = 3 + 2 * k, 4 + 2 * k
             g_rb, gb[ib] = _inorm_bwd(rb, sb, G, 0, 0)
-            gw[ib] = layers[ib].wgrad(ra, sa, 1, g_rb, B)
+            gw[ib] = layers[ib].wgrad(aa, None, 0, g_rb, B)
             gp_a = layers[ib].dgrad(g_rb, wbwd[ib - 1], B)
             g_ra, gb[ia] = _inorm_bwd(ra, sa, gp_a, 1, 1)
             gw[ia] = layers[ia].wgrad(xin, None, 0, g_ra, B)
@@ -498,10 +507,10 @@ class _ConvEncoder(torch.autograd.Function):
             call("mdnvae_fold_add", ptr(G), ptr(gp_x), B * 192, H, H, ptr(Gn), stream())
             G = Gn
         g_r3, gb[2] = _inorm_bwd(raw3, st3, G, 1, 0)
-        gw[2] = layers[2].wgrad(raw2, st2, 1, g_r3, B)
+        gw[2] = layers[2].wgrad(act2, None, 0, g_r3, B)
         g_a2 = layers[2].dgrad(g_r3, wbwd[1], B)
         g_r2, gb[1] = _inorm_bwd(raw2, st2, g_a2, 1, 0)
-        gw[1] = layers[1].wgrad(raw1, st1, 1, g_r2, B)
+        gw[1] = layers[1].wgrad(act1, None, 0, g_r2, B)
         g_a1 = layers[1].dgrad(g_r2, wbwd[0], B)
         g_r1, gb[0] = _inorm_bwd(raw1, st1, g_a1, 1, 0)
         gw[0] = layers[0].wgrad(x.view(B, 1, ctx.n_nodes, ctx.n_nodes), None, 0, g_r1, B)

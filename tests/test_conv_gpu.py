@@ -95,6 +95,8 @@ def test_instance_norm_kernels(C, H, relu, folded):
     skip = torch.randn(B, C, H, H, generator=g)
     act2 = ops._norm_act_add(rg, st, skip.to(DEV), relu)
     assert _rel(act2, a + skip.double()) <= 1e-6
+    act3, st3 = ops._inorm_fwd(rg, skip.to(DEV), relu)          # statistics + normalise in one pass
+    assert torch.equal(st3, st) and torch.equal(act3, act2)
     graw, gsum = ops._inorm_bwd(rg, st, cot.to(DEV).contiguous(), relu, folded)
     assert _rel(graw, rd.grad) <= 2e-5
     assert float(gsum.abs().max()) <= 1e-3 * float(rd.grad.abs().sum())   # sums to zero up to rounding
