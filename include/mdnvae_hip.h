@@ -98,10 +98,12 @@ int mdnvae_decoder_unpack_gcn_grad(const float* dwt, const int* adj, int N, int 
  * outer products; icpt_w/icpt_b [N*N] (both or neither): out = out*icpt_w + icpt_b (the GraphCNN
  * intercept with identity mask, function/VAE-CNN-GCN.py:150,184,219-220); do_exp: out = exp(out);
  * drop [R,B,N]: optional multiplier on the final node vectors (dropout masks already scaled);
- * xlat [B,N] = sum of the first xlat_channels node vectors (the reference returns h1+h2+h3+h4). */
+ * xlat [B,N] = sum of the first xlat_channels node vectors (the reference returns h1+h2+h3+h4).
+ * components = 1: out is [B,R,N*N] with out[b,r] = g_r g_r^T, the per-channel matrices that the
+ * trait-gated mixture head uses as component means (no epilogue; build-defined, no reference code). */
 int mdnvae_decoder_fwd(const float* z, const float* wt, int B, int N, int L, int R, int NL, int acts,
                        int epi_act, const float* icpt_w, const float* icpt_b, int do_exp, const float* drop,
-                       int xlat_channels, float* out, float* xlat, void* stream);
+                       int xlat_channels, int components, float* out, float* xlat, void* stream);
 
 /* floats in each of layer_in / layer_dpre for a batch of B */
 size_t mdnvae_decoder_bwd_rows_floats(int B, int R, int NL);
@@ -112,7 +114,7 @@ size_t mdnvae_decoder_bwd_rows_floats(int B, int R, int NL);
  * sums are the intercept-weight gradient. */
 int mdnvae_decoder_bwd(const float* z, const float* wt, const float* wn, int B, int N, int L, int R, int NL,
                        int acts, int epi_act, const float* icpt_w, const float* icpt_b, int do_exp,
-                       const float* drop, int xlat_channels, const float* grad_out, const float* grad_xlat,
+                       const float* drop, int xlat_channels, int components, const float* grad_out, const float* grad_xlat,
                        float* grad_z, float* layer_in, float* layer_dpre, float* grad_times_act, void* stream);
 
 /* out_a[e] = sum_b a[b,e], out_c[e] = sum_b c[b,e] in a fixed order (bias / diagonal-weight gradients). */
@@ -198,6 +200,23 @@ int mdnvae_maxpool_bwd(const float* grad_feat, const int* argmax, long nplanes, 
  * the gradient first (1 for a SUM-reduced data-parallel gradient). */
 int mdnvae_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n, int step, float lr,
                      float beta1, float beta2, float eps, float grad_scale, void* stream);
+
+/* ---- trait-gated Gaussian-mixture likelihood (BUILD-DEFINED: the reference has no such code) ----
+ * comp_mean [B,K,D] component means, x [B,D], gate_logits [B,K] (from the traits), log_sigma [K];
+ *   nll = -sum_b logsumexp_k( log softmax(gate_logits)_bk
+ *                             + sum_d(-0.5((x_bd-m_bkd)/s_k)^2 - log s_k - 0.5 log 2pi) )
+ * loss_out[3] = {nll + KL, nll, KL} with KL as in function/MM_Gate.py:181; z [B,L] is written when
+ * eps and z are given; resp [B,K] (responsibilities) and sumsq [B,K] are saved for the backward. */
+size_t mdnvae_mdn_workspace_bytes(int B);
+int mdnvae_mdn_loss_fwd(const float* comp_mean, const float* x, const float* gate_logits, const float* log_sigma,
+                        int B, int K, int D, const float* mu, const float* logvar, int L, const float* eps, float* z,
+                        float* resp, float* sumsq, void* workspace, float* loss_out, void* stream);
+/* grad_comp [B,K,D], grad_logits [B,K], grad_log_sigma_rows [B,K] (sum over b = gradient of log_sigma),
+ * grad_mu/grad_logvar [B,L] (KL part; both or neither); grad_loss = device {g_nll, g_kl} or NULL. */
+int mdnvae_mdn_loss_bwd(const float* comp_mean, const float* x, const float* gate_logits, const float* log_sigma,
+                        const float* resp, const float* sumsq, int B, int K, int D, const float* mu,
+                        const float* logvar, int L, const float* grad_loss, float* grad_comp, float* grad_logits,
+                        float* grad_log_sigma_rows, float* grad_mu, float* grad_logvar, void* stream);
 
 #ifdef __cplusplus
 }

@@ -123,6 +123,7 @@ struct DecArgs {
     int has_icpt;    // out = a*wd + bi
     int do_exp;      // out = exp(out)
     int xlat_r;      // x_latent = sum of the first xlat_r channels (0 = none)
+    int comp_mode;   // 1: out[b][r][e] = g_r[i]*g_r[j] per channel (mixture components), no epilogue
 };
 
 constexpr int FWD_TS = 16;    // samples per tile
@@ -189,12 +190,17 @@ __global__ __launch_bounds__(FWD_NT) void chain_decoder_fwd_kernel(
             float* orow = out + (long)(b0 + s) * D;
             int i = t / N, j = t - i * N;
             for (int e = t; e < D; e += FWD_NT) {
-                float sum = 0.0f;
-                for (int r = 0; r < a.R; ++r) sum += gfin[s][r][i] * gfin[s][r][j];
-                float v = act_apply(a.epi_act, sum);
-                if (a.has_icpt) v = v * wd[e] + bi[e];
-                if (a.do_exp) v = expf(v);
-                orow[e] = v;
+                if (a.comp_mode) {
+                    float* crow = out + (long)(b0 + s) * a.R * D;
+                    for (int r = 0; r < a.R; ++r) crow[(long)r * D + e] = gfin[s][r][i] * gfin[s][r][j];
+                } else {
+                    float sum = 0.0f;
+                    for (int r = 0; r < a.R; ++r) sum += gfin[s][r][i] * gfin[s][r][j];
+                    float v = act_apply(a.epi_act, sum);
+                    if (a.has_icpt) v = v * wd[e] + bi[e];
+                    if (a.do_exp) v = expf(v);
+                    orow[e] = v;
+                }
                 i += di;
                 j += dj;
                 if (j >= N) { j -= N; ++i; }
@@ -288,74 +294,83 @@ __global__ __launch_bounds__(BWD_NT) void chain_decoder_bwd_kernel(
         const int di = BWD_NT / N, dj = BWD_NT - di * N;
         for (int s = 0; s < BWD_TS; ++s) {
             const bool live = b0 + s < a.B;       // uniform over the workgroup
-            if (live) {
-                const float* grow = gout + (long)(b0 + s) * D;
-                float* garow = ga ? ga + (long)(b0 + s) * D : nullptr;
-                int i = t / N, j = t - i * N;
-                for (int e = t; e < D; e += BWD_NT) {
-                    float sum = 0.0f;
-                    for (int r = 0; r < R; ++r) {
-                        float gi = ACTS(r, NL - 1, s, i), gj = ACTS(r, NL - 1, s, j);
-                        if (drop) {
-                            gi *= drop[((long)r * a.B + b0 + s) * N + i];
-                            gj *= drop[((long)r * a.B + b0 + s) * N + j];
-                        }
-                        sum += gi * gj;
-                    }
-                    const float av = act_apply(a.epi_act, sum);
-                    float g = grow[e];
-                    if (a.do_exp) {
-                        float o = av;
-                        if (a.has_icpt) o = o * wd[e] + bi[e];
-                        g *= expf(o);
-                    }
-                    if (a.has_icpt) {
-                        if (garow) garow[e] = g * av;
-                        g *= wd[e];
-                    }
-                    dA[i * lda + j] = g * act_slope(a.epi_act, av);
-                    i += di;
-                    j += dj;
-                    if (j >= N) { j -= N; ++i; }
-                }
-            }
-            __syncthreads();
-            if (live) {
-                // dgr[i] = sum_j (dA[i][j] + dA[j][i]) * g_r[j]; two threads per row, j split in halves
-                const int i = t & 127, half = t >> 7;
-                float acc[MAXR];
-#pragma unroll
-                for (int r = 0; r < MAXR; ++r) acc[r] = 0.0f;
-                if (i < N) {
-                    const int jh = (N + 1) / 2;
-                    const int j0 = half * jh, j1 = (half == 0) ? jh : N;
-                    for (int j = j0; j < j1; ++j) {
-                        const float v = dA[i * lda + j] + dA[j * lda + i];
-#pragma unroll
-                        for (int r = 0; r < MAXR; ++r)
-                            if (r < R) {
-                                float gj = ACTS(r, NL - 1, s, j);
-                                if (drop) gj *= drop[((long)r * a.B + b0 + s) * N + j];
-                                acc[r] += v * gj;
+            // sum mode: one pass with the gradient of the summed matrix feeding every channel;
+            // component mode: one pass per channel with that channel's own gradient matrix
+            const int npass = a.comp_mode ? R : 1;
+            for (int pass = 0; pass < npass; ++pass) {
+                if (live) {
+                    const float* grow = a.comp_mode ? gout + ((long)(b0 + s) * R + pass) * D : gout + (long)(b0 + s) * D;
+                    float* garow = ga ? ga + (long)(b0 + s) * D : nullptr;
+                    int i = t / N, j = t - i * N;
+                    for (int e = t; e < D; e += BWD_NT) {
+                        float g = grow[e];
+                        if (!a.comp_mode) {
+                            float sum = 0.0f;
+                            for (int r = 0; r < R; ++r) {
+                                float gi = ACTS(r, NL - 1, s, i), gj = ACTS(r, NL - 1, s, j);
+                                if (drop) {
+                                    gi *= drop[((long)r * a.B + b0 + s) * N + i];
+                                    gj *= drop[((long)r * a.B + b0 + s) * N + j];
+                                }
+                                sum += gi * gj;
                             }
+                            const float av = act_apply(a.epi_act, sum);
+                            if (a.do_exp) {
+                                float o = av;
+                                if (a.has_icpt) o = o * wd[e] + bi[e];
+                                g *= expf(o);
+                            }
+                            if (a.has_icpt) {
+                                if (garow) garow[e] = g * av;
+                                g *= wd[e];
+                            }
+                            g *= act_slope(a.epi_act, av);
+                        }
+                        dA[i * lda + j] = g;
+                        i += di;
+                        j += dj;
+                        if (j >= N) { j -= N; ++i; }
                     }
                 }
-                // combine the two halves through dpb (free at this point)
-                if (half == 1 && i < N)
-                    for (int r = 0; r < R; ++r) dpb[r * 128 + i] = acc[r];
                 __syncthreads();
-                if (half == 0 && i < N) {
-                    for (int r = 0; r < R; ++r) {
-                        float v = acc[r] + dpb[r * 128 + i];
-                        if (gxlat && r < a.xlat_r) v += gxlat[(long)(b0 + s) * N + i];
-                        if (drop) v *= drop[((long)r * a.B + b0 + s) * N + i];
-                        dg[(r * BWD_TS + s) * NP + i] = v;
+                if (live) {
+                    // dgr[i] = sum_j (dA[i][j] + dA[j][i]) * g_r[j]; two threads per row, j split in halves
+                    const int i = t & 127, half = t >> 7;
+                    float acc[MAXR];
+#pragma unroll
+                    for (int r = 0; r < MAXR; ++r) acc[r] = 0.0f;
+                    const int r_lo = a.comp_mode ? pass : 0, r_hi = a.comp_mode ? pass + 1 : R;
+                    if (i < N) {
+                        const int jh = (N + 1) / 2;
+                        const int j0 = half * jh, j1 = (half == 0) ? jh : N;
+                        for (int j = j0; j < j1; ++j) {
+                            const float v = dA[i * lda + j] + dA[j * lda + i];
+#pragma unroll
+                            for (int r = 0; r < MAXR; ++r)
+                                if (r >= r_lo && r < r_hi) {
+                                    float gj = ACTS(r, NL - 1, s, j);
+                                    if (drop) gj *= drop[((long)r * a.B + b0 + s) * N + j];
+                                    acc[r] += v * gj;
+                                }
+                        }
                     }
+                    // combine the two halves through dpb (free at this point)
+                    if (half == 1 && i < N)
+                        for (int r = r_lo; r < r_hi; ++r) dpb[r * 128 + i] = acc[r];
+                    __syncthreads();
+                    if (half == 0 && i < N) {
+                        for (int r = r_lo; r < r_hi; ++r) {
+                            float v = acc[r] + dpb[r * 128 + i];
+                            if (gxlat && r < a.xlat_r) v += gxlat[(long)(b0 + s) * N + i];
+                            if (drop) v *= drop[((long)r * a.B + b0 + s) * N + i];
+                            dg[(r * BWD_TS + s) * NP + i] = v;
+                        }
+                    }
+                } else if (pass == 0) {
+                    for (int i = t; i < R * NP; i += BWD_NT) dg[((i / NP) * BWD_TS + s) * NP + (i % NP)] = 0.0f;
                 }
-            } else {
-                for (int i = t; i < R * NP; i += BWD_NT) dg[((i / NP) * BWD_TS + s) * NP + (i % NP)] = 0.0f;
+                __syncthreads();
             }
-            __syncthreads();
         }
         // ---- phase 3: walk each chain backwards
         float dzacc[4] = {0.f, 0.f, 0.f, 0.f};
@@ -533,13 +548,15 @@ int mdnvae_decoder_unpack_gcn_grad(const float* dwt, const int* adj, int N, int 
 
 int mdnvae_decoder_fwd(const float* z, const float* wt, int B, int N, int L, int R, int NL, int acts, int epi_act,
                        const float* icpt_w, const float* icpt_b, int do_exp, const float* drop, int xlat_channels,
-                       float* out, float* xlat, void* stream) {
+                       int components, float* out, float* xlat, void* stream) {
     if (int rc = check_dec("mdnvae_decoder_fwd", B, N, L, R, NL)) return rc;
     if (B == 0) return 0;
     MV_REQUIRE(z && wt && out, E_ARG, "mdnvae_decoder_fwd: null pointer");
     MV_REQUIRE((icpt_w == nullptr) == (icpt_b == nullptr), E_ARG, "mdnvae_decoder_fwd: intercept needs weight and bias");
     MV_REQUIRE(xlat_channels >= 0 && xlat_channels <= R, E_ARG, "mdnvae_decoder_fwd: xlat_channels %d", xlat_channels);
-    DecArgs a{B, N, L, R, NL, acts, epi_act, icpt_w != nullptr, do_exp, xlat_channels};
+    MV_REQUIRE(!components || (!icpt_w && !do_exp && epi_act == 0), E_ARG,
+               "mdnvae_decoder_fwd: component output takes no epilogue");
+    DecArgs a{B, N, L, R, NL, acts, epi_act, icpt_w != nullptr, do_exp, xlat_channels, components};
     const int ntiles = (B + FWD_TS - 1) / FWD_TS;
     const int grid = ntiles < 2048 ? ntiles : 2048;
     hipLaunchKernelGGL(chain_decoder_fwd_kernel, dim3(grid), dim3(FWD_NT), 0, (hipStream_t)stream, a, z, wt, icpt_w,
@@ -552,14 +569,16 @@ size_t mdnvae_decoder_bwd_rows_floats(int B, int R, int NL) { return (size_t)R *
 
 int mdnvae_decoder_bwd(const float* z, const float* wt, const float* wn, int B, int N, int L, int R, int NL, int acts,
                        int epi_act, const float* icpt_w, const float* icpt_b, int do_exp, const float* drop,
-                       int xlat_channels, const float* grad_out, const float* grad_xlat, float* grad_z,
+                       int xlat_channels, int components, const float* grad_out, const float* grad_xlat, float* grad_z,
                        float* layer_in, float* layer_dpre, float* grad_times_act, void* stream) {
     if (int rc = check_dec("mdnvae_decoder_bwd", B, N, L, R, NL)) return rc;
     if (B == 0) return 0;
     MV_REQUIRE(z && wt && wn && grad_out && grad_z && layer_in && layer_dpre, E_ARG, "mdnvae_decoder_bwd: null pointer");
     MV_REQUIRE((icpt_w == nullptr) == (icpt_b == nullptr), E_ARG, "mdnvae_decoder_bwd: intercept needs weight and bias");
     MV_REQUIRE(!icpt_w || grad_times_act, E_ARG, "mdnvae_decoder_bwd: intercept gradient needs grad_times_act");
-    DecArgs a{B, N, L, R, NL, acts, epi_act, icpt_w != nullptr, do_exp, xlat_channels};
+    MV_REQUIRE(!components || (!icpt_w && !do_exp && epi_act == 0), E_ARG,
+               "mdnvae_decoder_bwd: component output takes no epilogue");
+    DecArgs a{B, N, L, R, NL, acts, epi_act, icpt_w != nullptr, do_exp, xlat_channels, components};
     const size_t lds = bwd_lds_bytes(N, R, NL);
     MV_REQUIRE(lds <= 160 * 1024, E_SHAPE, "mdnvae_decoder_bwd: needs %zu bytes of LDS", lds);
     static bool attr_set = false;

@@ -276,6 +276,16 @@ class MultiChannelGCNDecoder(nn.Module):
             self._spec = ops.ChainSpec(self.n_nodes, self.latent_dim, self.R, layers, epi_act=None, xlat_channels=0)
         return self._adj
 
+    def components(self, z, adjacency):
+        """Per-channel matrices g_r g_r^T [B,R,N*N]: the component means of the mixture head."""
+        self._adjacency(adjacency, z.device)
+        if getattr(self, "_comp_spec", None) is None or self._comp_spec_src is not self._spec:
+            sp = self._spec
+            self._comp_spec = ops.ChainSpec(sp.N, sp.L, sp.R, sp.layers, epi_act=None, xlat_channels=0, components=True)
+            self._comp_spec_src = sp
+        out, _ = ops.chain_decoder(z, self._comp_spec, self.chain_params())
+        return out
+
     def chain_params(self):
         params = []
         for r in range(self.R):
@@ -321,6 +331,33 @@ class GCNVAE(nn.Module):
         mu, logvar = self.encode(x)
         z = self.reparameterize(mu, logvar, eps)
         return self.decode(z, adjacency), mu, logvar
+
+
+class MDNGateVAE(GCNVAE):
+    """GCN-decoder VAE with a trait-gated Gaussian-mixture head.  BUILD-DEFINED: the reference
+    has no mixture code; this is the model its name and data/trait.pt point at.  The R channel
+    matrices of the GCN decoder are the component means, a linear gate on the subject's traits
+    gives the mixture weights, and each component has one learned log-scale."""
+
+    def __init__(self, R=5, n_nodes=68, k=32, n_layers=3, latent_dim=68, n_traits=4):
+        super().__init__(R=R, n_nodes=n_nodes, k=k, n_layers=n_layers, latent_dim=latent_dim)
+        self.gate = Linear(n_traits, R)
+        self.log_sigma = nn.Parameter(torch.zeros(R))
+
+    def forward(self, x, adjacency, traits, eps=None):
+        x = x.reshape(-1, self.n_nodes * self.n_nodes)
+        mu, logvar = self.encode(x)
+        z = self.reparameterize(mu, logvar, eps)
+        comp = self.decoder.components(z, adjacency)
+        return comp, self.gate(traits), mu, logvar
+
+    def loss(self, comp, gate_logits, x, mu, logvar):
+        return ops.mdn_loss(comp, x, gate_logits, self.log_sigma, mu, logvar)
+
+    def expected(self, comp, gate_logits):
+        """Mixture mean sum_k pi_k m_k [B, N*N] (a library batched GEMM over the K components)."""
+        pi = ops.softmax_rows(gate_logits)
+        return torch.bmm(pi.unsqueeze(1), comp).squeeze(1)
 
 
 # ---------------------------------------------------------------------------------------

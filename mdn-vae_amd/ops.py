@@ -229,13 +229,15 @@ class ChainSpec:
     """Static description of a chain decoder: R channels x NL layers.
     layers[l] = dict(kind='linear'|'gcn', act=..., mask=Tensor|None, adj=IntTensor|None)."""
 
-    def __init__(self, n_nodes, latent_dim, channels, layers, epi_act=None, xlat_channels=0, do_exp=False):
+    def __init__(self, n_nodes, latent_dim, channels, layers, epi_act=None, xlat_channels=0, do_exp=False,
+                 components=False):
         self.N, self.L, self.R = int(n_nodes), int(latent_dim), int(channels)
         self.layers = layers
         self.NL = len(layers)
         self.epi_act = ACTS[epi_act]
         self.xlat_channels = int(xlat_channels)
         self.do_exp = bool(do_exp)
+        self.components = bool(components)
         self.acts = 0
         for l, ly in enumerate(layers):
             a = ACTS[ly.get("act")]
@@ -276,11 +278,11 @@ class _ChainDecoder(torch.autograd.Function):
         dev = z.device
         wt, wn = _pack_panels(spec, params, dev)
         D = spec.N * spec.N
-        out = torch.empty(B, D, dtype=torch.float32, device=dev)
+        out = torch.empty((B, spec.R, D) if spec.components else (B, D), dtype=torch.float32, device=dev)
         xlat = torch.empty(B, spec.N, dtype=torch.float32, device=dev) if spec.xlat_channels else None
         call("mdnvae_decoder_fwd", ptr(z, "z"), ptr(wt), B, spec.N, spec.L, spec.R, spec.NL, spec.acts, spec.epi_act,
              ptr(icpt_w, "icpt_w"), ptr(icpt_b, "icpt_b"), int(spec.do_exp), ptr(drop, "drop"), spec.xlat_channels,
-             ptr(out), ptr(xlat), stream())
+             int(spec.components), ptr(out), ptr(xlat), stream())
         ctx.spec = spec
         ctx.save_for_backward(z, wt, wn, icpt_w, icpt_b, drop)
         ctx.param_shapes = [tuple(p.shape) if p is not None else None for p in params]
@@ -306,7 +308,8 @@ class _ChainDecoder(torch.autograd.Function):
         gz = torch.empty_like(z)
         ga = torch.empty_like(gout) if icpt_w is not None else None
         call("mdnvae_decoder_bwd", ptr(z), ptr(wt), ptr(wn), B, spec.N, spec.L, spec.R, spec.NL, spec.acts,
-             spec.epi_act, ptr(icpt_w), ptr(icpt_b), int(spec.do_exp), ptr(drop), spec.xlat_channels, ptr(gout),
+             spec.epi_act, ptr(icpt_w), ptr(icpt_b), int(spec.do_exp), ptr(drop), spec.xlat_channels,
+             int(spec.components), ptr(gout),
              ptr(gxlat), ptr(gz), ptr(hin), ptr(dp), ptr(ga), stream())
         # weight (+bias, last row) gradient of every layer: [KP x B] . [B x NP] library GEMMs
         dwt = torch.bmm(hin.transpose(1, 2), dp)
@@ -527,3 +530,62 @@ def conv_encoder(x, n_nodes, weights_and_biases):
     for w, b in weights_and_biases:
         flat += [w, b]
     return _ConvEncoder.apply(x, n_nodes, *flat)
+
+
+# ---------------------------------------------------------------------------------------
+# trait-gated mixture likelihood (build-defined; the reference has no counterpart)
+# ---------------------------------------------------------------------------------------
+class _MdnLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, comp, x, logits, log_sigma, mu, logvar):
+        comp, x, logits, log_sigma, mu, logvar = (_c(t) for t in (comp, x, logits, log_sigma, mu, logvar))
+        if comp.dim() != 3 or x.dim() != 2 or comp.shape[0] != x.shape[0] or comp.shape[2] != x.shape[1]:
+            raise RuntimeError(f"mdn loss: comp {tuple(comp.shape)} must be [B,K,D] for x {tuple(x.shape)}")
+        B, K, D = comp.shape
+        if logits.shape != (B, K) or log_sigma.shape != (K,):
+            raise RuntimeError("mdn loss: gate_logits must be [B,K] and log_sigma [K]")
+        L = mu.shape[1]
+        dev = comp.device
+        out = torch.empty(3, dtype=torch.float32, device=dev)
+        resp = torch.empty(B, K, dtype=torch.float32, device=dev)
+        ss = torch.empty(B, K, dtype=torch.float32, device=dev)
+        ws = torch.empty(_lib.load().mdnvae_mdn_workspace_bytes(B), dtype=torch.uint8, device=dev)
+        call("mdnvae_mdn_loss_fwd", ptr(comp, "comp_mean"), ptr(x, "x"), ptr(logits, "gate_logits"),
+             ptr(log_sigma, "log_sigma"), B, K, D, ptr(mu, "mu"), ptr(logvar, "logvar"), L, None, None, ptr(resp),
+             ptr(ss), ws.data_ptr(), ptr(out), stream())
+        ctx.save_for_backward(comp, x, logits, log_sigma, mu, logvar, resp, ss)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        comp, x, logits, log_sigma, mu, logvar, resp, ss = ctx.saved_tensors
+        B, K, D = comp.shape
+        L = mu.shape[1]
+        g2 = torch.stack((gout[0] + gout[1], gout[0] + gout[2])).contiguous()
+        gcomp = torch.empty_like(comp)
+        glogits = torch.empty_like(logits)
+        gls_rows = torch.empty_like(logits)
+        gmu = torch.empty_like(mu)
+        glv = torch.empty_like(mu)
+        call("mdnvae_mdn_loss_bwd", ptr(comp), ptr(x), ptr(logits), ptr(log_sigma), ptr(resp), ptr(ss), B, K, D,
+             ptr(mu), ptr(logvar), L, ptr(g2), ptr(gcomp), ptr(glogits), ptr(gls_rows), ptr(gmu), ptr(glv), stream())
+        gls = _colsum(gls_rows) if B > 0 else torch.zeros_like(log_sigma)
+        return gcomp, None, glogits, gls, gmu, glv
+
+
+def mdn_loss_terms(comp_mean, x, gate_logits, log_sigma, mu, logvar):
+    """(nll + KL, nll, KL) of the trait-gated Gaussian mixture."""
+    out = _MdnLoss.apply(comp_mean, x, gate_logits, log_sigma, mu, logvar)
+    return out[0], out[1], out[2]
+
+
+def mdn_loss(comp_mean, x, gate_logits, log_sigma, mu, logvar):
+    return mdn_loss_terms(comp_mean, x, gate_logits, log_sigma, mu, logvar)[0]
+
+
+def softmax_rows(logits):
+    """softmax over the last dimension of a small [B,K] tensor (evaluation helper; not differentiable)."""
+    with torch.no_grad():
+        m = logits.max(dim=1, keepdim=True).values
+        e = exp(logits - m)
+        return e / e.sum(dim=1, keepdim=True)

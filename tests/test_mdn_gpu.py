@@ -1,0 +1,94 @@
+"""Trait-gated Gaussian-mixture head.  BUILD-DEFINED model: the reference contains no
+mixture-density code, so parity against the reference is UNPINNED here; the oracle is this
+build's own float64 statement of the specification (oracle/ref_eager.py: mdn_nll)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_fixture, fixture_params
+from oracle import ref_eager as R
+import mdnvae_amd as M
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _rel(a, b):
+    a = torch.as_tensor(a).detach().double().cpu()
+    b = torch.as_tensor(b).detach().double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+@pytest.mark.parametrize("B,K,D,L", [(7, 5, 4624, 68), (3, 5, 7569, 68), (1, 1, 10, 2), (4, 8, 36, 5), (0, 5, 16, 4)])
+def test_mdn_loss_against_oracle(B, K, D, L):
+    g = torch.Generator().manual_seed(B * 31 + K)
+    comp = torch.rand(B, K, D, generator=g)
+    x = torch.rand(B, D, generator=g)
+    logits = torch.randn(B, K, generator=g)
+    log_sigma = torch.randn(K, generator=g) * 0.3
+    mu = torch.randn(B, L, generator=g)
+    lv = torch.randn(B, L, generator=g) * 0.5
+    cc, lc, sc, mc, vc = (t.clone().double().requires_grad_(True) for t in (comp, logits, log_sigma, mu, lv))
+    want = R.mdn_nll(cc, sc, lc, x.double()) + R.kl_term(mc, vc)
+    if B:
+        want.backward()
+    cd, ld, sd, md, vd = (t.to(DEV).requires_grad_(True) for t in (comp, logits, log_sigma, mu, lv))
+    total, nll, kl = M.mdn_loss_terms(cd, x.to(DEV), ld, sd, md, vd)
+    assert abs(total.item() - want.item()) <= 1e-5 * max(abs(want.item()), 1e-6)
+    if B:
+        (total * 1.25 + nll * 0.5).backward()
+        assert _rel(cd.grad, cc.grad * 1.75) <= 1e-4
+        assert _rel(ld.grad, lc.grad * 1.75) <= 1e-4
+        assert _rel(sd.grad, sc.grad * 1.75) <= 1e-4
+        assert _rel(md.grad, mc.grad * 1.25) <= 1e-5 and _rel(vd.grad, vc.grad * 1.25) <= 1e-5
+
+
+def test_mdn_responsibilities_are_a_distribution_and_loss_is_reproducible():
+    g = torch.Generator().manual_seed(4)
+    B, K, D, L = 2048, 5, 7569, 68
+    comp = torch.rand(B, K, D, generator=g).to(DEV)
+    x = torch.rand(B, D, generator=g).to(DEV)
+    logits = torch.randn(B, K, generator=g).to(DEV)
+    ls = torch.zeros(K, device=DEV)
+    mu = torch.randn(B, L, generator=g).to(DEV)
+    lv = torch.zeros(B, L, device=DEV)
+    a = M.mdn_loss(comp, x, logits, ls, mu, lv).item()
+    b = M.mdn_loss(comp, x, logits, ls, mu, lv).item()
+    assert a == b
+    h = B // 2
+    parts = M.mdn_loss(comp[:h], x[:h], logits[:h], ls, mu[:h], lv[:h]).item() + \
+        M.mdn_loss(comp[h:], x[h:], logits[h:], ls, mu[h:], lv[h:]).item()
+    assert abs(a - parts) <= 2e-6 * abs(a)
+
+
+def test_mdn_gate_vae_end_to_end_against_oracle():
+    fix = load_fixture("mm_gate")
+    params = fixture_params(fix)
+    torch.manual_seed(5)
+    model = M.MDNGateVAE(R=5, n_nodes=68, k=32, n_layers=3, latent_dim=68, n_traits=4)
+    model.load_state_dict(params, strict=False)
+    with torch.no_grad():
+        model.log_sigma.copy_(torch.tensor([0.1, -0.2, 0.0, 0.3, -0.1]))
+    p = {k: v.detach().clone().double().requires_grad_(True) for k, v in model.state_dict().items()}
+    model = model.to(DEV)
+    x = torch.from_numpy(fix["x"])
+    eps = torch.from_numpy(fix["eps"])
+    traits = torch.randn(x.shape[0], 4)
+    adjacency = [list(map(int, r)) for r in fix["adjacency"]]
+    comp, logits, mu, lv = model(x.to(DEV), adjacency, traits.to(DEV), eps=eps.to(DEV))
+    loss = model.loss(comp, logits, x.to(DEV), mu, lv)
+    loss.backward()
+    # oracle
+    mu_c, lv_c = R.fnn_encode(p, x.double())
+    z_c = R.reparameterize(mu_c, lv_c, eps.double())
+    comp_c = R.gcn_components(p, z_c, fix["adjacency"])
+    logit_c = R.mdn_gate_logits(traits.double(), p["gate.weight"], p["gate.bias"])
+    want = R.mdn_nll(comp_c, p["log_sigma"], logit_c, x.double()) + R.kl_term(mu_c, lv_c)
+    want.backward()
+    assert _rel(comp, comp_c) <= 1e-5
+    assert abs(loss.item() - want.item()) <= 1e-5 * abs(want.item())
+    for name, prm in model.named_parameters():
+        assert _rel(prm.grad, p[name].grad) <= 1e-4, name
+    mean = model.expected(comp, logits)
+    want_mean = (torch.softmax(logit_c, dim=1).unsqueeze(2) * comp_c).sum(dim=1)
+    assert _rel(mean, want_mean) <= 1e-5
