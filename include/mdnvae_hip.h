@@ -218,6 +218,25 @@ int mdnvae_mdn_loss_bwd(const float* comp_mean, const float* x, const float* gat
                         const float* logvar, int L, const float* grad_loss, float* grad_comp, float* grad_logits,
                         float* grad_log_sigma_rows, float* grad_mu, float* grad_logvar, void* stream);
 
+/* ---- FID validation statistics ------------------------------------------------------------
+ * np.mean / np.cov(rowvar=False) / sqrtm / trace of calculate_fid (function/VAE_CNN_NN.py:310-316,
+ * 331-337; validation/FID.py:61-81).  Feature rows x [n,d] fp32; `shift` [d] is any fixed vector
+ * near the mean (the same on every rank); sum [d] and gram [d,d] are float64 accumulators
+ * (zeroed by the caller) that add up across calls and, for data-parallel runs, across ranks. */
+size_t mdnvae_fid_gram_workspace_floats(long n, int d);
+/* sum += sum_rows (x - shift);  gram += sum_rows (x - shift)(x - shift)^T  (MFMA GEMM). */
+int mdnvae_fid_accumulate(const float* x, const float* shift, long n, int d, float* workspace, double* sum,
+                          double* gram, void* stream);
+/* mean [d] = shift + sum/n;  cov [d,d] = (gram - sum sum^T/n)/(n-1), float64. */
+int mdnvae_fid_finalize(const double* gram, const double* sum, const float* shift, double n, int d, double* mean,
+                        double* cov, void* stream);
+/* Elementwise steps of the coupled Newton-Schulz square root (float64; the products are library
+ * GEMMs issued by the host): t = 1.5 I - 0.5 zy;  out = scale * (a + a^T)/2;
+ * out2 = {trace(a), ||a||_F^2}. */
+int mdnvae_ns_residual(const double* zy, int d, double* t, void* stream);
+int mdnvae_symmetrize(const double* a, int d, double scale, double* out, void* stream);
+int mdnvae_trace_norm(const double* a, int d, double* out2, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

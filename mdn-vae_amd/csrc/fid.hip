@@ -1,0 +1,207 @@
+// FID validation statistics on the GPU.
+//   reference: np.mean / np.cov(rowvar=False) / scipy.linalg.sqrtm / np.trace in calculate_fid,
+//   function/VAE_CNN_NN.py:310-316, 331-337 and validation/FID.py:61-81.
+// Moments: the shifted Gram matrix sum_rows (x-c)(x-c)^T is an MFMA GEMM (fp32 32x32x2 tiles,
+// K = rows) over chunks of 256 rows whose partial tiles are added in float64 in a fixed order;
+// only tiles on or above the diagonal are computed.  Covariance and mean follow in float64.
+// The matrix square root is a coupled Newton-Schulz iteration on symmetric PSD matrices, run by
+// the host as float64 library GEMMs; this file supplies its elementwise steps
+// (T = 1.5 I - 0.5 Z Y, symmetrise, trace).
+#include "common.h"
+#include "../../include/mdnvae_hip.h"
+
+namespace mdnvae {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+constexpr int GR_ROWS = 256;      // rows (K) per chunk
+constexpr int GR_KT = 64;         // rows staged per LDS tile
+constexpr int GR_LD = 65;         // LDS row stride of a [GR_KT][64] tile
+
+// partial[chunk][d][d] (fp32): tile (ti,tj), ti <= tj, of sum over the chunk's rows
+__global__ __launch_bounds__(256) void gram_chunk_kernel(const float* __restrict__ x, const float* __restrict__ shift,
+                                                         long n, int d, float* __restrict__ partial) {
+    __shared__ float ta[GR_KT * GR_LD], tb[GR_KT * GR_LD];
+    const int ti = blockIdx.x, tj = blockIdx.y;
+    if (ti > tj) return;
+    const long r0 = (long)blockIdx.z * GR_ROWS;
+    const long r1 = min(n, r0 + GR_ROWS);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, l32 = lane & 31;
+    const int wi = wave >> 1, wj = wave & 1;
+    f32x16 acc;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = 0.0f;
+    for (long rr = r0; rr < r1; rr += GR_KT) {
+        __syncthreads();
+        for (int idx = tid; idx < GR_KT * 64; idx += 256) {
+            const int k = idx >> 6, c = idx & 63;
+            const long row = rr + k;
+            float va = 0.0f, vb = 0.0f;
+            if (row < r1) {
+                const int ca = ti * 64 + c, cb = tj * 64 + c;
+                if (ca < d) va = x[row * d + ca] - shift[ca];
+                if (cb < d) vb = x[row * d + cb] - shift[cb];
+            }
+            ta[k * GR_LD + c] = va;
+            tb[k * GR_LD + c] = vb;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int k = 0; k < GR_KT; k += 2) {
+            const float a = ta[(k + h) * GR_LD + wi * 32 + l32];
+            const float b = tb[(k + h) * GR_LD + wj * 32 + l32];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        }
+    }
+    float* dst = partial + (long)blockIdx.z * d * d;
+    const int col = tj * 64 + wj * 32 + l32;
+    if (col < d) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int row = ti * 64 + wi * 32 + (j & 3) + 8 * (j >> 2) + 4 * h;
+            if (row < d) dst[(long)row * d + col] = acc[j];
+        }
+    }
+}
+
+// gram[i][j] += sum_chunks partial (float64), mirrored below the diagonal
+__global__ __launch_bounds__(256) void gram_reduce_kernel(const float* __restrict__ partial, int nchunks, int d,
+                                                          double* __restrict__ gram) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)d * d) return;
+    const int i = (int)(idx / d), j = (int)(idx % d);
+    const int ti = i >> 6, tj = j >> 6;
+    // element (i,j) was computed if its tile is on/above the diagonal; otherwise read (j,i)
+    const long src = (ti <= tj) ? idx : (long)j * d + i;
+    double s = 0.0;
+    for (int c = 0; c < nchunks; ++c) s += (double)partial[(long)c * d * d + src];
+    gram[idx] += s;
+}
+
+// sum[c] += sum_rows (x[row][c] - shift[c]) in float64, one thread per column, fixed order
+__global__ __launch_bounds__(256) void shifted_colsum_kernel(const float* __restrict__ x,
+                                                             const float* __restrict__ shift, long n, int d,
+                                                             double* __restrict__ sum) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= d) return;
+    double s = 0.0;
+    const float sh = shift[c];
+    for (long r = 0; r < n; ++r) s += (double)(x[r * d + c] - sh);
+    sum[c] += s;
+}
+
+// mean = shift + sum/n ; cov = (gram - sum sum^T / n) / (n - 1)   (np.cov: unbiased)
+__global__ __launch_bounds__(256) void cov_finalize_kernel(const double* __restrict__ gram,
+                                                           const double* __restrict__ sum,
+                                                           const float* __restrict__ shift, double n, int d,
+                                                           double* __restrict__ mean, double* __restrict__ cov) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx < d) mean[idx] = (double)shift[idx] + sum[idx] / n;
+    if (idx < (long)d * d) {
+        const int i = (int)(idx / d), j = (int)(idx % d);
+        cov[idx] = (gram[idx] - sum[i] * sum[j] / n) / (n - 1.0);
+    }
+}
+
+// t = 1.5 I - 0.5 zy
+__global__ __launch_bounds__(256) void ns_residual_kernel(const double* __restrict__ zy, int d, double* __restrict__ t) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)d * d) return;
+    const int i = (int)(idx / d), j = (int)(idx % d);
+    t[idx] = (i == j ? 1.5 : 0.0) - 0.5 * zy[idx];
+}
+
+// out = 0.5 (a + a^T) * scale
+__global__ __launch_bounds__(256) void symmetrize_kernel(const double* __restrict__ a, int d, double scale,
+                                                         double* __restrict__ out) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)d * d) return;
+    const int i = (int)(idx / d), j = (int)(idx % d);
+    out[idx] = 0.5 * (a[idx] + a[(long)j * d + i]) * scale;
+}
+
+// out[0] = trace(a), out[1] = sum of squares (Frobenius norm^2); one workgroup, fixed order
+__global__ __launch_bounds__(256) void trace_norm_kernel(const double* __restrict__ a, int d, double* __restrict__ out) {
+    __shared__ double red[4];
+    double tr = 0.0, sq = 0.0;
+    for (long idx = threadIdx.x; idx < (long)d * d; idx += 256) {
+        const double v = a[idx];
+        sq += v * v;
+        if (idx / d == idx % d) tr += v;
+    }
+    tr = block_sum<256, double>(tr, red);
+    sq = block_sum<256, double>(sq, red);
+    if (threadIdx.x == 0) {
+        out[0] = tr;
+        out[1] = sq;
+    }
+}
+
+}  // namespace mdnvae
+using namespace mdnvae;
+
+static unsigned grid_for(long n) { return (unsigned)((n + 255) / 256); }
+
+extern "C" {
+
+size_t mdnvae_fid_gram_workspace_floats(long n, int d) {
+    const long nch = (n + GR_ROWS - 1) / GR_ROWS;
+    const long cap = nch < 64 ? nch : 64;            // chunks processed per launch
+    return (size_t)cap * d * d;
+}
+
+int mdnvae_fid_accumulate(const float* x, const float* shift, long n, int d, float* workspace, double* sum,
+                          double* gram, void* stream) {
+    MV_REQUIRE(n >= 0 && d >= 1, E_ARG, "mdnvae_fid_accumulate: bad size");
+    MV_REQUIRE(d <= 8192, E_SHAPE, "mdnvae_fid_accumulate: feature dimension %d exceeds 8192", d);
+    if (n == 0) return 0;
+    MV_REQUIRE(x && shift && workspace && sum && gram, E_ARG, "mdnvae_fid_accumulate: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const int tiles = (d + 63) / 64;
+    const long rows_per_launch = 64L * GR_ROWS;
+    for (long r0 = 0; r0 < n; r0 += rows_per_launch) {
+        const long rows = (n - r0 < rows_per_launch) ? n - r0 : rows_per_launch;
+        const int nch = (int)((rows + GR_ROWS - 1) / GR_ROWS);
+        hipLaunchKernelGGL(gram_chunk_kernel, dim3(tiles, tiles, nch), dim3(256), 0, st, x + r0 * d, shift, rows, d,
+                           workspace);
+        MV_LAUNCH_CHECK("gram_chunk_kernel");
+        hipLaunchKernelGGL(gram_reduce_kernel, dim3(grid_for((long)d * d)), dim3(256), 0, st, workspace, nch, d, gram);
+        MV_LAUNCH_CHECK("gram_reduce_kernel");
+    }
+    hipLaunchKernelGGL(shifted_colsum_kernel, dim3(grid_for(d)), dim3(256), 0, st, x, shift, n, d, sum);
+    MV_LAUNCH_CHECK("shifted_colsum_kernel");
+    return 0;
+}
+
+int mdnvae_fid_finalize(const double* gram, const double* sum, const float* shift, double n, int d, double* mean,
+                        double* cov, void* stream) {
+    MV_REQUIRE(d >= 1 && n >= 2.0, E_ARG, "mdnvae_fid_finalize: need at least two samples");
+    MV_REQUIRE(gram && sum && shift && mean && cov, E_ARG, "mdnvae_fid_finalize: null pointer");
+    hipLaunchKernelGGL(cov_finalize_kernel, dim3(grid_for((long)d * d)), dim3(256), 0, (hipStream_t)stream, gram, sum,
+                       shift, n, d, mean, cov);
+    MV_LAUNCH_CHECK("cov_finalize_kernel");
+    return 0;
+}
+
+int mdnvae_ns_residual(const double* zy, int d, double* t, void* stream) {
+    MV_REQUIRE(d >= 1 && zy && t, E_ARG, "mdnvae_ns_residual: bad argument");
+    hipLaunchKernelGGL(ns_residual_kernel, dim3(grid_for((long)d * d)), dim3(256), 0, (hipStream_t)stream, zy, d, t);
+    MV_LAUNCH_CHECK("ns_residual_kernel");
+    return 0;
+}
+
+int mdnvae_symmetrize(const double* a, int d, double scale, double* out, void* stream) {
+    MV_REQUIRE(d >= 1 && a && out && a != out, E_ARG, "mdnvae_symmetrize: bad argument (in-place is not supported)");
+    hipLaunchKernelGGL(symmetrize_kernel, dim3(grid_for((long)d * d)), dim3(256), 0, (hipStream_t)stream, a, d, scale,
+                       out);
+    MV_LAUNCH_CHECK("symmetrize_kernel");
+    return 0;
+}
+
+int mdnvae_trace_norm(const double* a, int d, double* out2, void* stream) {
+    MV_REQUIRE(d >= 1 && a && out2, E_ARG, "mdnvae_trace_norm: bad argument");
+    hipLaunchKernelGGL(trace_norm_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, a, d, out2);
+    MV_LAUNCH_CHECK("trace_norm_kernel");
+    return 0;
+}
+
+}  // extern "C"

@@ -85,3 +85,31 @@ def test_trainer_refuses_cpu_modules():
     tr = M.Trainer(net, "poisson_log")
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         tr.step((torch.rand(2, 100), [[0, 1, 2]] * 10), torch.rand(2, 100), eps=torch.randn(2, 4))
+
+
+def _stats_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    st = M.FeatureStats(3, torch.tensor([1.0, 2.0, 3.0]), device="cpu")
+    # accumulators as the moment kernel would have left them for this rank's rows
+    x = torch.arange(30, dtype=torch.float64).reshape(10, 3) ** 1.5
+    lo, hi = M.data.shard_range(10, rank, world)
+    xc = x[lo:hi] - st.shift.double()
+    st.n, st.sum, st.gram = hi - lo, xc.sum(0), xc.T @ xc
+    st.allreduce()
+    out[rank] = (st.n, st.sum.clone(), st.gram.clone())
+    dist.destroy_process_group()
+
+
+def test_two_rank_feature_stats_allreduce():
+    world = 2
+    out = mp.Manager().dict()
+    mp.spawn(_stats_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    x = torch.arange(30, dtype=torch.float64).reshape(10, 3) ** 1.5
+    xc = x - torch.tensor([1.0, 2.0, 3.0], dtype=torch.float64)
+    for r in range(world):
+        n, s, g = out[r]
+        assert n == 10
+        assert torch.allclose(s, xc.sum(0), rtol=1e-14)
+        assert torch.allclose(g, xc.T @ xc, rtol=1e-14)
