@@ -327,3 +327,35 @@ def fid_symmetric(mu1, sigma1, mu2, sigma2):
     ev = np.linalg.eigvalsh(root @ sigma2 @ root)
     diff = mu1 - mu2
     return float(diff.dot(diff) + np.trace(sigma1) + np.trace(sigma2) - 2 * np.sqrt(np.clip(ev, 0, None)).sum())
+
+
+# ---- evaluation loop (function/VAE_CNN_NN.py:239-289) --------------------------------------------
+def reconstruct(variant, params, x, eps, batch_size=64, **kw):
+    """function/VAE_CNN_NN.py:242-260: forward passes in batches of 64 without gradients; the
+    reconstruction is the first output.  `eps` [n,L] stands in for the draws of reparameterize."""
+    out = []
+    with torch.no_grad():
+        for lo in range(0, x.shape[0], batch_size):
+            res = vae_forward(variant, params, x[lo:lo + batch_size], eps[lo:lo + batch_size], **kw)
+            out.append(res[0])
+    return torch.cat(out)
+
+
+def normalise_for_metrics(real, generated):
+    """function/VAE_CNN_NN.py:268-271."""
+    real, generated = np.asarray(real), np.asarray(generated)
+    max_value = real.max()
+    return real / max_value, np.maximum(generated / max_value, 0)
+
+
+def compute_mse(real, generated):
+    """function/VAE_CNN_NN.py:273-276 on [n,N,N] stacks."""
+    return ((real - generated) ** 2).mean(axis=(1, 2)).mean()
+
+
+def compute_psnr(real, generated, max_value=1.0):
+    """function/VAE_CNN_NN.py:281-286."""
+    mse_values = ((real - generated) ** 2).mean(axis=(1, 2))
+    with np.errstate(divide="ignore"):
+        psnr = np.where(mse_values == 0, np.inf, 20 * np.log10(max_value) - 10 * np.log10(mse_values))
+    return psnr[np.isfinite(psnr)].mean()
