@@ -33,6 +33,7 @@ MODELS = {
     "cnn_nn": (dict(decoder="nn", intercept="dense", final="exp"), "poisson_rate", "sc"),    # function/VAE_CNN_NN.py
     "cnn_gcn_fc": (dict(decoder="gcn", intercept="diag", final="none"), "mse", "fc"),        # function_FC/VAE_CNN_GCN.py
     "mm_gate": (None, "poisson_log", "sc"),                                                  # function/MM_Gate.py
+    "mdn_gate": (None, "mdn", "sc"),          # MM_Gate with the trait-gated mixture head (build-defined)
 }
 
 
@@ -41,6 +42,8 @@ def build(model_name, n_nodes, device):
     torch.manual_seed(11111)
     if model_name == "mm_gate":
         model = M.GCNVAE(R=5, n_nodes=n_nodes, k=32, n_layers=3, latent_dim=68)
+    elif model_name == "mdn_gate":
+        model = M.MDNGateVAE(R=5, n_nodes=n_nodes, k=32, n_layers=3, latent_dim=68, n_traits=4)
     else:
         model = M.ConvVAE(n_nodes=n_nodes, latent_dim=68, **kw)
     return model.to(device), mode, kind
@@ -77,6 +80,10 @@ def cpu_baseline(model_name, n_nodes, seconds_budget=20.0):
     if model_name == "mm_gate":
         ref = M.GCNVAE(R=5, n_nodes=n_nodes, k=32, n_layers=3, latent_dim=68)
         adjacency = knn_adjacency_from(x, n_nodes)
+    elif model_name == "mdn_gate":
+        ref = M.MDNGateVAE(R=5, n_nodes=n_nodes, k=32, n_layers=3, latent_dim=68, n_traits=4)
+        adjacency = knn_adjacency_from(x, n_nodes)
+        traits = torch.randn(B, 4)
     else:
         ref = M.ConvVAE(n_nodes=n_nodes, latent_dim=68, **kw)
         mask = rank_mask_from(x, n_nodes) if kw["decoder"] == "gcn" else None
@@ -87,6 +94,12 @@ def cpu_baseline(model_name, n_nodes, seconds_budget=20.0):
     def loss_of(eps):
         if model_name == "mm_gate":
             recon, mu, lv, _, _ = R.vae_forward("mm_gate", p, x, eps, adjacency=adjacency)
+        elif model_name == "mdn_gate":
+            mu, lv = R.fnn_encode(p, x)
+            z = R.reparameterize(mu, lv, eps)
+            comp = R.gcn_components(p, z, adjacency)
+            logits = R.mdn_gate_logits(traits, p["gate.weight"], p["gate.bias"])
+            return R.mdn_nll(comp, p["log_sigma"], logits, x) + R.kl_term(mu, lv)
         else:
             mu, lv = R.conv_encode(p, x, n_nodes)
             z = R.reparameterize(mu, lv, eps)
@@ -162,10 +175,26 @@ def install_clock(clock):
         return clock.bracket("loss_stream_kernel", nbytes, lambda: orig_loss(recon, x, mu, logvar, mode))
 
     ops.vae_loss_and_grads = loss
+    # trait-gated mixture loss: forward and backward launches are bracketed separately
+    F = ops._MdnLoss
+    orig_mf, orig_mb = F.forward, F.backward
+
+    def mdn_fwd(ctx, comp, x, logits, log_sigma, mu, logvar):
+        B, K, D = comp.shape
+        nbytes = 4.0 * B * ((K + 1) * D + 2 * mu.shape[1] + 3 * K)
+        return clock.bracket("mdn_fwd_kernel", nbytes, lambda: orig_mf(ctx, comp, x, logits, log_sigma, mu, logvar))
+
+    def mdn_bwd(ctx, gout):
+        B, K, D = ctx.saved_tensors[0].shape
+        nbytes = 4.0 * B * ((2 * K + 1) * D + 4 * ctx.saved_tensors[4].shape[1] + 5 * K)
+        return clock.bracket("mdn_bwd_stream_kernel", nbytes, lambda: orig_mb(ctx, gout))
+
+    F.forward, F.backward = staticmethod(mdn_fwd), staticmethod(mdn_bwd)
 
     def restore():
         L.fwd, L.dgrad, L.wgrad = orig_fwd, orig_dgrad, orig_wgrad
         ops.vae_loss_and_grads = orig_loss
+        F.forward, F.backward = staticmethod(orig_mf), staticmethod(orig_mb)
     return restore
 
 
@@ -201,8 +230,10 @@ def main():
     if args.model in ("cnn_gcn", "cnn_gcn_fc"):
         mask = rank_mask_from(gen(256, args.nodes, seed=1234, device=device), args.nodes)
         model.set_mask([mask] * 5)
-    if args.model == "mm_gate":
+    if args.model in ("mm_gate", "mdn_gate"):
         extra_inputs = (knn_adjacency_from(gen(256, args.nodes, seed=1234, device=device), args.nodes),)
+    if args.model == "mdn_gate":
+        extra_inputs += (torch.randn(args.batch, 4, device=device, generator=torch.Generator(device=device).manual_seed(7)),)
     trainer = M.Trainer(model, mode)
     eps_gen = torch.Generator(device=device).manual_seed(99 + rank)
 
@@ -250,7 +281,7 @@ def main():
         kernels = {}
         for tag, r in ks.items():
             per_launch = r["seconds"] / max(r["launches"], 1)
-            if tag == "loss_stream_kernel":
+            if tag in ("loss_stream_kernel", "mdn_fwd_kernel", "mdn_bwd_stream_kernel"):
                 kernels[tag] = dict(bound="hbm", achieved=r["work"] / r["seconds"] / 1e9, peak=PEAK_HBM_GBPS, unit="GB/s",
                                     frac=r["work"] / r["seconds"] / 1e9 / PEAK_HBM_GBPS, launches=r["launches"],
                                     avg_ms=per_launch * 1e3, share_of_step=r["seconds"] / elapsed, traffic=None)

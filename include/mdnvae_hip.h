@@ -212,11 +212,13 @@ int mdnvae_mdn_loss_fwd(const float* comp_mean, const float* x, const float* gat
                         int B, int K, int D, const float* mu, const float* logvar, int L, const float* eps, float* z,
                         float* resp, float* sumsq, void* workspace, float* loss_out, void* stream);
 /* grad_comp [B,K,D], grad_logits [B,K], grad_log_sigma_rows [B,K] (sum over b = gradient of log_sigma),
- * grad_mu/grad_logvar [B,L] (KL part; both or neither); grad_loss = device {g_nll, g_kl} or NULL. */
+ * grad_mu/grad_logvar [B,L] (KL part; both or neither); grad_loss = device {g_nll, g_kl} or NULL;
+ * workspace of mdnvae_mdn_workspace_bytes(B) bytes; B*K*D < 2^32. */
 int mdnvae_mdn_loss_bwd(const float* comp_mean, const float* x, const float* gate_logits, const float* log_sigma,
                         const float* resp, const float* sumsq, int B, int K, int D, const float* mu,
                         const float* logvar, int L, const float* grad_loss, float* grad_comp, float* grad_logits,
-                        float* grad_log_sigma_rows, float* grad_mu, float* grad_logvar, void* stream);
+                        float* grad_log_sigma_rows, float* grad_mu, float* grad_logvar, void* workspace,
+                        void* stream);
 
 /* ---- FID validation statistics ------------------------------------------------------------
  * np.mean / np.cov(rowvar=False) / sqrtm / trace of calculate_fid (function/VAE_CNN_NN.py:310-316,

@@ -60,6 +60,21 @@ __device__ __forceinline__ float wave_max_all(float v) {
     return v;
 }
 
+// Wave sum on the DPP path (no LDS crossbar): inclusive scan within each row of 16 lanes, then
+// the row totals are carried forward by the two row broadcasts; the total is valid in lane 63.
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+#define MV_DPP_ADD(ctrl, row_mask)                                                                       \
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, row_mask, 0xf, false))
+    MV_DPP_ADD(0x111, 0xf);   // row_shr:1
+    MV_DPP_ADD(0x112, 0xf);   // row_shr:2
+    MV_DPP_ADD(0x114, 0xf);   // row_shr:4
+    MV_DPP_ADD(0x118, 0xf);   // row_shr:8
+    MV_DPP_ADD(0x142, 0xa);   // row_bcast:15 into rows 1 and 3
+    MV_DPP_ADD(0x143, 0xc);   // row_bcast:31 into rows 2 and 3
+#undef MV_DPP_ADD
+    return v;
+}
+
 // Sum over a workgroup of NT threads (multiple of 64); result valid in thread 0.
 // `scratch` must hold NT/64 elements; fixed summation order (deterministic).
 template <int NT, typename T>

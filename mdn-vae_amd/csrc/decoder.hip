@@ -291,8 +291,72 @@ __global__ __launch_bounds__(BWD_NT) void chain_decoder_bwd_kernel(
             }
         }
         // ---- phase 2: per sample, gradient w.r.t. the final node vectors
+        if (a.comp_mode) {
+            // Component mode: channel r has its own gradient matrix G = gout[b][r].  One wave per
+            // (sample, channel) streams G row by row straight from global memory, 4 rows (8 loads)
+            // in flight; lane c owns columns c and c+64:
+            //   dg[i] = sum_j G[i][j] g[j]  (row sums: DPP wave reduction, total in lane 63)
+            //         + sum_j G[j][i] g[j]  (column sums: accumulated per lane)
+            float* urow = dpb;                                  // [BWD_NT/64][128] row sums per wave
+            const int lane = t & 63, wv = t >> 6;
+            for (int pair = wv; pair < BWD_TS * R; pair += BWD_NT / 64) {
+                const int s = pair / R, r = pair - s * R;
+                const bool c0 = lane < N, c1 = lane + 64 < N;
+                float out0 = 0.0f, out1 = 0.0f;
+                if (b0 + s < a.B) {                             // uniform over the wave
+                    const float* G = gout + ((long)(b0 + s) * R + r) * D;
+                    const float* gv = &ACTS(r, NL - 1, s, 0);
+                    const float* dr = drop ? drop + ((long)r * a.B + b0 + s) * N : nullptr;
+                    float g0 = c0 ? gv[lane] : 0.0f, g1 = c1 ? gv[lane + 64] : 0.0f;
+                    if (dr) {
+                        if (c0) g0 *= dr[lane];
+                        if (c1) g1 *= dr[lane + 64];
+                    }
+                    float v0 = 0.0f, v1 = 0.0f;
+                    for (int j = 0; j < N; j += 4) {
+                        float a0[4], a1[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const bool live_row = j + q < N;
+                            a0[q] = (live_row && c0) ? G[(j + q) * N + lane] : 0.0f;
+                            a1[q] = (live_row && c1) ? G[(j + q) * N + lane + 64] : 0.0f;
+                        }
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            if (j + q < N) {
+                                float gj = gv[j + q];
+                                if (dr) gj *= dr[j + q];
+                                v0 += a0[q] * gj;
+                                v1 += a1[q] * gj;
+                                const float p = wave_sum_dpp(a0[q] * g0 + a1[q] * g1);
+                                if (lane == 63) urow[wv * 128 + j + q] = p;
+                            }
+                        }
+                    }
+                    // urow was written and is read by this wave only; the LDS write of lane 63
+                    // is ordered before the reads below by the wave-level fence
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    if (c0) out0 = v0 + urow[wv * 128 + lane];
+                    if (c1) out1 = v1 + urow[wv * 128 + lane + 64];
+                    if (gxlat && r < a.xlat_r) {
+                        if (c0) out0 += gxlat[(long)(b0 + s) * N + lane];
+                        if (c1) out1 += gxlat[(long)(b0 + s) * N + lane + 64];
+                    }
+                    if (dr) {
+                        if (c0) out0 *= dr[lane];
+                        if (c1) out1 *= dr[lane + 64];
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+                if (lane < NP) dg[(r * BWD_TS + s) * NP + lane] = c0 ? out0 : 0.0f;
+                if (lane + 64 < NP) dg[(r * BWD_TS + s) * NP + lane + 64] = c1 ? out1 : 0.0f;
+            }
+            __syncthreads();
+        }
         const int di = BWD_NT / N, dj = BWD_NT - di * N;
-        for (int s = 0; s < BWD_TS; ++s) {
+        for (int s = 0; s < (a.comp_mode ? 0 : BWD_TS); ++s) {
             const bool live = b0 + s < a.B;       // uniform over the workgroup
             // sum mode: one pass with the gradient of the summed matrix feeding every channel;
             // component mode: one pass per channel with that channel's own gradient matrix

@@ -1,6 +1,6 @@
 // Fused reparameterisation + KL + reconstruction-loss kernels (forward, backward and the
 // one-pass forward+gradient form).  HBM-streaming: recon and x are read as one flat array
-// of B*D floats with 16-byte loads, 8 loads in flight per lane; sums are reduced
+// of B*D floats with 16-byte non-temporal loads, 4 loads in flight per lane; sums are reduced
 // lane -> wave (shuffle) -> workgroup (LDS) -> one double per workgroup, and a second
 // one-workgroup launch adds the per-workgroup partials in a fixed order, so the loss is
 // bit-reproducible run to run.
@@ -16,8 +16,39 @@
 namespace mdnvae {
 
 constexpr int LOSS_NT = 256;          // threads per workgroup
-constexpr int LOSS_UNROLL = 4;        // float4 chunks per lane per array per tile
-constexpr int LOSS_MAX_BLOCKS = 2048; // 256 CUs x 8
+#ifndef LOSS_UNROLL_N
+#define LOSS_UNROLL_N 2
+#endif
+#ifndef LOSS_MAX_BLOCKS_N
+#define LOSS_MAX_BLOCKS_N 1024
+#endif
+#ifndef LOSS_NT_LOADS
+#define LOSS_NT_LOADS 1
+#endif
+// Measured on MI355X at B=8192, N=87 (tools/loss_tune.sh): 1024 workgroups x 2 float4 per lane per
+// array with non-temporal accesses streams at 6.4-6.5 TB/s; more bytes in flight per lane, more
+// workgroups, or default-policy loads are all slower (5.3 TB/s at 2048 x 4, default policy).
+constexpr int LOSS_UNROLL = LOSS_UNROLL_N;         // float4 chunks per lane per array per tile
+constexpr int LOSS_MAX_BLOCKS = LOSS_MAX_BLOCKS_N; // 4 workgroups per CU
+
+__device__ __forceinline__ float4 stream_load(const float4* p) {
+#if LOSS_NT_LOADS
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+#else
+    return *p;
+#endif
+}
+__device__ __forceinline__ void stream_store(float4* p, float4 v) {
+#if LOSS_NT_LOADS
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    v4f t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<v4f*>(p));
+#else
+    *p = v;
+#endif
+}
 
 template <int MODE>
 __device__ __forceinline__ float recon_value(float r, float x) {
@@ -60,8 +91,8 @@ __global__ __launch_bounds__(LOSS_NT) void loss_stream_kernel(
         for (int u = 0; u < LOSS_UNROLL; ++u) {
             const long i = base + u * LOSS_NT + threadIdx.x;
             if (i < n4) {
-                rv[u] = r4[i];
-                xv[u] = x4[i];
+                rv[u] = stream_load(r4 + i);
+                xv[u] = stream_load(x4 + i);
             }
         }
 #pragma unroll
@@ -78,7 +109,7 @@ __global__ __launch_bounds__(LOSS_NT) void loss_stream_kernel(
                     o.y = g * recon_slope<MODE>(rv[u].y, xv[u].y);
                     o.z = g * recon_slope<MODE>(rv[u].z, xv[u].z);
                     o.w = g * recon_slope<MODE>(rv[u].w, xv[u].w);
-                    g4[i] = o;
+                    stream_store(g4 + i, o);
                 }
             }
         }

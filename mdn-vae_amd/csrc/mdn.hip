@@ -10,10 +10,11 @@
 //       nll   = - sum_b logsumexp_k ( log pi_bk + ll_bk )
 //   loss = nll + KL(q(z|x) || N(0,I))   (KL as in function/MM_Gate.py:181).
 //
-// One workgroup streams one sample: x once and its K component rows, coalesced, keeping K
-// running sums of squares per lane; the K sums are reduced lane -> wave (shuffle) -> workgroup
-// (LDS) and the log-sum-exp over the K components is taken by wave shuffles.  The same
-// workgroup does the sample's latent part (z, KL).  Backward is a second streaming kernel:
+// One wave streams one sample at a time: x and its K component rows are read once with 16-byte
+// non-temporal loads, K running sums of squares per lane; the K sums are reduced by wave
+// shuffles, lane k keeps component k, and the log-sum-exp over the K components is again taken
+// by shuffles - no LDS and no workgroup barrier.  The same wave does the sample's latent part
+// (z, KL).  Backward is a second streaming kernel:
 // grad_m_bkd = g * r_bk (m_bkd - x_bd) / sigma_k^2 with the responsibilities r_bk saved by the
 // forward.
 #include "common.h"
@@ -21,76 +22,94 @@
 
 namespace mdnvae {
 
-constexpr int MDN_NT = 256;
+constexpr int MDN_NT = 256;              // four waves per workgroup, one sample per wave
 constexpr int MDN_MAXK = 8;
 constexpr float LOG_2PI = 1.8378770664093453f;
 
-template <int K, bool VEC4>
+// Rows of D floats start at arbitrary 4-byte phases when D is not a multiple of 4 (87*87 = 7569);
+// the hardware takes 16-byte vector accesses at any 4-byte aligned address, so rows are walked as
+// quads of their own elements through this 4-byte aligned vector type.
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef v4f v4fu __attribute__((aligned(4)));
+
+#ifndef MDN_NT_LD
+#define MDN_NT_LD 1
+#endif
+#ifndef MDN_NT_ST
+#define MDN_NT_ST 1
+#endif
+__device__ __forceinline__ v4f quad_load(const float* row, int i) {
+#if MDN_NT_LD
+    return __builtin_nontemporal_load(reinterpret_cast<const v4fu*>(row) + i);
+#else
+    return *(reinterpret_cast<const v4fu*>(row) + i);
+#endif
+}
+__device__ __forceinline__ void quad_store(float* row, int i, v4f v) {
+#if MDN_NT_ST
+    __builtin_nontemporal_store(v, reinterpret_cast<v4fu*>(row) + i);
+#else
+    *(reinterpret_cast<v4fu*>(row) + i) = v;
+#endif
+}
+
+template <int K>
 __global__ __launch_bounds__(MDN_NT) void mdn_fwd_kernel(const float* __restrict__ comp, const float* __restrict__ x,
                                                          const float* __restrict__ logits,
-                                                         const float* __restrict__ log_sigma, int D,
+                                                         const float* __restrict__ log_sigma, int B, int D,
                                                          const float* __restrict__ mu, const float* __restrict__ logvar,
                                                          const float* __restrict__ eps, float* __restrict__ z, int L,
                                                          float* __restrict__ resp, float* __restrict__ ss_out,
                                                          double* __restrict__ per_sample) {
-    __shared__ float red[MDN_NT / 64][MDN_MAXK];
-    __shared__ float klred[MDN_NT / 64];
-    const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wid = t >> 6;
-    const float* xr = x + (long)b * D;
-    const float* cr = comp + (long)b * K * D;
-    float ss[K];
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * (MDN_NT / 64) + (threadIdx.x >> 6);
+    const int nwaves = gridDim.x * (MDN_NT / 64);
+    const int D4 = D >> 2;
+    for (int b = wave; b < B; b += nwaves) {
+        const float* xr = x + (long)b * D;
+        const float* cr = comp + (long)b * K * D;
+        float ss[K];
 #pragma unroll
-    for (int k = 0; k < K; ++k) ss[k] = 0.0f;
-    if (VEC4) {
-        const int D4 = D >> 2;
-        const float4* x4 = reinterpret_cast<const float4*>(xr);
-        for (int i = t; i < D4; i += MDN_NT) {
-            const float4 xv = x4[i];
-            float4 mv[K];
+        for (int k = 0; k < K; ++k) ss[k] = 0.0f;
+        for (int i = lane; i < D4; i += 64) {
+            const v4f xv = quad_load(xr, i);
+            v4f mv[K];
 #pragma unroll
-            for (int k = 0; k < K; ++k) mv[k] = reinterpret_cast<const float4*>(cr + (long)k * D)[i];
+            for (int k = 0; k < K; ++k)
+                mv[k] = quad_load(cr + (long)k * D, i);
 #pragma unroll
             for (int k = 0; k < K; ++k) {
-                const float d0 = xv.x - mv[k].x, d1 = xv.y - mv[k].y, d2 = xv.z - mv[k].z, d3 = xv.w - mv[k].w;
-                ss[k] += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+                const v4f d = xv - mv[k];
+                ss[k] += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
             }
         }
-    } else {
-        for (int i = t; i < D; i += MDN_NT) {
+        for (int i = (D4 << 2) + lane; i < D; i += 64) {          // at most 3 elements
             const float xv = xr[i];
-            float mv[K];
-#pragma unroll
-            for (int k = 0; k < K; ++k) mv[k] = cr[(long)k * D + i];
 #pragma unroll
             for (int k = 0; k < K; ++k) {
-                const float d = xv - mv[k];
+                const float d = xv - cr[(long)k * D + i];
                 ss[k] += d * d;
             }
         }
-    }
+        // lane k < K ends up owning component k
+        float ssk = 0.0f;
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-        const float v = wave_sum(ss[k]);
-        if (lane == 0) red[wid][k] = v;
-    }
-    // latent part of this sample
-    float kl = 0.0f;
-    for (int i = t; i < L; i += MDN_NT) {
-        const long j = (long)b * L + i;
-        const float m = mu[j], lv = logvar[j];
-        kl += -0.5f * (1.0f + lv - m * m - expf(lv));
-        if (eps && z) z[j] = m + eps[j] * expf(0.5f * lv);
-    }
-    kl = wave_sum(kl);
-    if (lane == 0) klred[wid] = kl;
-    __syncthreads();
-    if (wid == 0) {
-        // lane k < K owns component k; log-sum-exp across lanes by shuffles
-        float a = -INFINITY, gl = -INFINITY, ssk = 0.0f;
-        if (lane < K) {
-            ssk = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
-            gl = logits[(long)b * K + lane];
+        for (int k = 0; k < K; ++k) {
+            const float v = wave_sum_all(ss[k]);
+            if (lane == k) ssk = v;
         }
+        // latent part of this sample
+        float kl = 0.0f;
+        for (int i = lane; i < L; i += 64) {
+            const long j = (long)b * L + i;
+            const float m = mu[j], lv = logvar[j];
+            kl += -0.5f * (1.0f + lv - m * m - expf(lv));
+            if (eps && z) z[j] = m + eps[j] * expf(0.5f * lv);
+        }
+        kl = wave_sum_all(kl);
+        // log-sum-exp across the K owning lanes by shuffles
+        float a = -INFINITY, gl = -INFINITY;
+        if (lane < K) gl = logits[(long)b * K + lane];
         const float gmax = wave_max_all(gl);
         const float gsum = wave_sum_all(lane < K ? expf(gl - gmax) : 0.0f);
         if (lane < K) {
@@ -107,7 +126,7 @@ __global__ __launch_bounds__(MDN_NT) void mdn_fwd_kernel(const float* __restrict
         }
         if (lane == 0) {
             per_sample[2 * b] = -(double)lse;
-            per_sample[2 * b + 1] = (double)((klred[0] + klred[1]) + (klred[2] + klred[3]));
+            per_sample[2 * b + 1] = (double)kl;
         }
     }
 }
@@ -130,90 +149,145 @@ __global__ __launch_bounds__(256) void mdn_finalize_kernel(const double* __restr
     }
 }
 
-// gscale[0] scales the mixture term, gscale[1] the KL term (NULL = 1,1)
-template <int K, bool VEC4>
-__global__ __launch_bounds__(MDN_NT) void mdn_bwd_kernel(const float* __restrict__ comp, const float* __restrict__ x,
-                                                         const float* __restrict__ logits,
-                                                         const float* __restrict__ log_sigma,
-                                                         const float* __restrict__ resp, const float* __restrict__ ss,
-                                                         int D, const float* __restrict__ mu,
-                                                         const float* __restrict__ logvar, int L,
-                                                         const float* __restrict__ gscale, float* __restrict__ gcomp,
-                                                         float* __restrict__ glogits, float* __restrict__ glsig_rows,
-                                                         float* __restrict__ gmu, float* __restrict__ glogvar) {
-    const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wid = t >> 6;
+#ifndef MDN_UNROLL_N
+#define MDN_UNROLL_N 2
+#endif
+constexpr int MDN_UNROLL = MDN_UNROLL_N;            // quads per lane per tile
+#ifndef MDN_BWD_BLOCKS_N
+#define MDN_BWD_BLOCKS_N 8192
+#endif
+
+// Backward, pass 1 (one thread per (sample, component)): coef = g r / sigma^2, the gate and scale
+// gradients; plus the latent gradients.  gscale[0] scales the mixture term, gscale[1] the KL term
+// (NULL = 1,1).
+__global__ __launch_bounds__(256) void mdn_bwd_small_kernel(const float* __restrict__ logits,
+                                                            const float* __restrict__ log_sigma,
+                                                            const float* __restrict__ resp, const float* __restrict__ ss,
+                                                            int B, int K, int D, const float* __restrict__ mu,
+                                                            const float* __restrict__ logvar, int L,
+                                                            const float* __restrict__ gscale, float* __restrict__ coef,
+                                                            float* __restrict__ glogits, float* __restrict__ glsig_rows,
+                                                            float* __restrict__ gmu, float* __restrict__ glogvar) {
     const float g = gscale ? gscale[0] : 1.0f, gk = gscale ? gscale[1] : 1.0f;
-    float coef[K];
-#pragma unroll
-    for (int k = 0; k < K; ++k) coef[k] = g * resp[(long)b * K + k] * expf(-2.0f * log_sigma[k]);
-    const float* xr = x + (long)b * D;
-    const float* cr = comp + (long)b * K * D;
-    float* gr = gcomp + (long)b * K * D;
-    if (VEC4) {
-        const int D4 = D >> 2;
-        for (int i = t; i < D4; i += MDN_NT) {
-            const float4 xv = reinterpret_cast<const float4*>(xr)[i];
-            float4 mv[K];
-#pragma unroll
-            for (int k = 0; k < K; ++k) mv[k] = reinterpret_cast<const float4*>(cr + (long)k * D)[i];
-#pragma unroll
-            for (int k = 0; k < K; ++k) {
-                float4 o;
-                o.x = coef[k] * (mv[k].x - xv.x);
-                o.y = coef[k] * (mv[k].y - xv.y);
-                o.z = coef[k] * (mv[k].z - xv.z);
-                o.w = coef[k] * (mv[k].w - xv.w);
-                reinterpret_cast<float4*>(gr + (long)k * D)[i] = o;
-            }
-        }
-    } else {
-        for (int i = t; i < D; i += MDN_NT) {
-            const float xv = xr[i];
-            float mv[K];
-#pragma unroll
-            for (int k = 0; k < K; ++k) mv[k] = cr[(long)k * D + i];
-#pragma unroll
-            for (int k = 0; k < K; ++k) gr[(long)k * D + i] = coef[k] * (mv[k] - xv);
-        }
-    }
-    if (wid == 0) {
-        float gl = (lane < K) ? logits[(long)b * K + lane] : -INFINITY;
-        const float gmax = wave_max_all(gl);
-        const float gsum = wave_sum_all(lane < K ? expf(gl - gmax) : 0.0f);
-        if (lane < K) {
-            const float pi = expf(gl - gmax) / gsum;
-            const float r = resp[(long)b * K + lane];
-            glogits[(long)b * K + lane] = g * (pi - r);
-            glsig_rows[(long)b * K + lane] = g * r * ((float)D - ss[(long)b * K + lane] * expf(-2.0f * log_sigma[lane]));
-        }
+    const long tid = (long)blockIdx.x * 256 + threadIdx.x, nth = (long)gridDim.x * 256;
+    for (long i = tid; i < (long)B * K; i += nth) {
+        const int b = (int)(i / K), k = (int)(i - (long)b * K);
+        float gmax = -INFINITY;
+        for (int j = 0; j < K; ++j) gmax = fmaxf(gmax, logits[(long)b * K + j]);
+        float gsum = 0.0f;
+        for (int j = 0; j < K; ++j) gsum += expf(logits[(long)b * K + j] - gmax);
+        const float pi = expf(logits[i] - gmax) / gsum;
+        const float r = resp[i], is2 = expf(-2.0f * log_sigma[k]);
+        coef[i] = g * r * is2;
+        glogits[i] = g * (pi - r);
+        glsig_rows[i] = g * r * ((float)D - ss[i] * is2);
     }
     if (gmu) {
-        for (int i = t; i < L; i += MDN_NT) {
-            const long j = (long)b * L + i;
+        for (long j = tid; j < (long)B * L; j += nth) {
             gmu[j] = gk * mu[j];
             glogvar[j] = gk * 0.5f * (expf(logvar[j]) - 1.0f);
         }
     }
 }
 
+// Backward, pass 2: grad_comp = coef[row] (comp - x) streamed as ONE flat array of B*K*D floats
+// (the same sweep as the reconstruction-loss kernels: consecutive workgroups take consecutive
+// 8 KB tiles, so the chip works on a compact window of addresses).  A quad usually lies inside one
+// component row; the few that straddle two rows take the per-element path.  x rows are re-read
+// once per component from cache (default policy), comp / grad_comp are non-temporal.
+__global__ __launch_bounds__(MDN_NT) void mdn_bwd_stream_kernel(const float* __restrict__ comp,
+                                                                const float* __restrict__ x,
+                                                                const float* __restrict__ coef, unsigned total,
+                                                                unsigned D, unsigned K, unsigned magicD,
+                                                                unsigned magicK, float* __restrict__ gcomp) {
+    // floor(n / d) for n < 2^32 given magic = ceil(2^32 / d) is exact only for small n, so the
+    // quotient is corrected by one step either way (d >= 1, n < 2^32).
+    auto divide = [](unsigned n, unsigned d, unsigned magic) {
+        unsigned q = d == 1 ? n : __umulhi(n, magic);
+        const long rem = (long)n - (long)q * d;
+        if (rem < 0) --q;
+        else if (rem >= (long)d) ++q;
+        return q;
+    };
+    const unsigned nquads = total >> 2;
+    constexpr unsigned TILE = MDN_NT * MDN_UNROLL;
+    for (unsigned base = blockIdx.x * TILE; base < nquads; base += gridDim.x * TILE) {
+        v4f mv[MDN_UNROLL], xv[MDN_UNROLL];
+        float cf[MDN_UNROLL];
+        bool whole[MDN_UNROLL];
+#pragma unroll
+        for (int u = 0; u < MDN_UNROLL; ++u) {
+            const unsigned q = base + u * MDN_NT + threadIdx.x;
+            whole[u] = false;
+            if (q < nquads) {
+                const unsigned f = q << 2;
+                const unsigned row = divide(f, D, magicD);
+                const unsigned d = f - row * D;
+                whole[u] = d + 3 < D;
+                if (whole[u]) {
+                    const unsigned b = divide(row, K, magicK);
+                    mv[u] = __builtin_nontemporal_load(reinterpret_cast<const v4fu*>(comp) + q);
+                    xv[u] = *reinterpret_cast<const v4fu*>(x + (size_t)b * D + d);
+                    cf[u] = coef[row];
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < MDN_UNROLL; ++u) {
+            const unsigned q = base + u * MDN_NT + threadIdx.x;
+            if (q < nquads) {
+                if (whole[u]) {
+                    const v4f o = cf[u] * (mv[u] - xv[u]);
+                    __builtin_nontemporal_store(o, reinterpret_cast<v4fu*>(gcomp) + q);
+                } else {
+                    for (unsigned c = 0; c < 4; ++c) {
+                        const unsigned f = (q << 2) + c;
+                        const unsigned row = divide(f, D, magicD);
+                        const unsigned d = f - row * D;
+                        const unsigned b = divide(row, K, magicK);
+                        gcomp[f] = coef[row] * (comp[f] - x[(size_t)b * D + d]);
+                    }
+                }
+            }
+        }
+    }
+    // the (at most 3) elements past the last whole quad
+    const unsigned f = (nquads << 2) + blockIdx.x * MDN_NT + threadIdx.x;
+    if (f < total) {
+        const unsigned row = divide(f, D, magicD);
+        const unsigned d = f - row * D;
+        const unsigned b = divide(row, K, magicK);
+        gcomp[f] = coef[row] * (comp[f] - x[(size_t)b * D + d]);
+    }
+}
+
 }  // namespace mdnvae
 using namespace mdnvae;
 
-#define MV_MDN_DISPATCH(K, VEC, CALL) \
-    switch (K) {                      \
-        case 1: if (VEC) { CALL(1, true); } else { CALL(1, false); } break; \
-        case 2: if (VEC) { CALL(2, true); } else { CALL(2, false); } break; \
-        case 3: if (VEC) { CALL(3, true); } else { CALL(3, false); } break; \
-        case 4: if (VEC) { CALL(4, true); } else { CALL(4, false); } break; \
-        case 5: if (VEC) { CALL(5, true); } else { CALL(5, false); } break; \
-        case 6: if (VEC) { CALL(6, true); } else { CALL(6, false); } break; \
-        case 7: if (VEC) { CALL(7, true); } else { CALL(7, false); } break; \
-        default: if (VEC) { CALL(8, true); } else { CALL(8, false); } break; \
+#define MV_MDN_DISPATCH(K, CALL) \
+    switch (K) {                 \
+        case 1: CALL(1); break;  \
+        case 2: CALL(2); break;  \
+        case 3: CALL(3); break;  \
+        case 4: CALL(4); break;  \
+        case 5: CALL(5); break;  \
+        case 6: CALL(6); break;  \
+        case 7: CALL(7); break;  \
+        default: CALL(8); break; \
     }
+
+#ifndef MDN_MAX_BLOCKS_N
+#define MDN_MAX_BLOCKS_N 1024
+#endif
+static unsigned mdn_grid(int B) {
+    const int blocks = (B + MDN_NT / 64 - 1) / (MDN_NT / 64);
+    return (unsigned)(blocks < MDN_MAX_BLOCKS_N ? blocks : MDN_MAX_BLOCKS_N);
+}
 
 extern "C" {
 
-size_t mdnvae_mdn_workspace_bytes(int B) { return sizeof(double) * 2 * (size_t)(B > 0 ? B : 1); }
+// forward: 2 doubles per sample; backward: one float per (sample, component)
+size_t mdnvae_mdn_workspace_bytes(int B) { return sizeof(float) * MDN_MAXK * (size_t)(B > 0 ? B : 1); }
 
 int mdnvae_mdn_loss_fwd(const float* comp_mean, const float* x, const float* gate_logits, const float* log_sigma,
                         int B, int K, int D, const float* mu, const float* logvar, int L, const float* eps, float* z,
@@ -227,11 +301,10 @@ int mdnvae_mdn_loss_fwd(const float* comp_mean, const float* x, const float* gat
                    "mdnvae_mdn_loss_fwd: null pointer");
         MV_REQUIRE(L == 0 || (mu && logvar), E_ARG, "mdnvae_mdn_loss_fwd: mu/logvar is null");
         MV_REQUIRE(!z || eps, E_ARG, "mdnvae_mdn_loss_fwd: z requested without eps");
-        const bool vec = (D % 4 == 0) && aligned16(comp_mean) && aligned16(x);
-#define CALL(KK, VV)                                                                                              \
-    hipLaunchKernelGGL((mdn_fwd_kernel<KK, VV>), dim3(B), dim3(MDN_NT), 0, st, comp_mean, x, gate_logits, log_sigma, \
-                       D, mu, logvar, eps, z, L, resp, sumsq, (double*)workspace)
-        MV_MDN_DISPATCH(K, vec, CALL)
+#define CALL(KK)                                                                                            \
+    hipLaunchKernelGGL((mdn_fwd_kernel<KK>), dim3(mdn_grid(B)), dim3(MDN_NT), 0, st, comp_mean, x, \
+                       gate_logits, log_sigma, B, D, mu, logvar, eps, z, L, resp, sumsq, (double*)workspace)
+        MV_MDN_DISPATCH(K, CALL)
 #undef CALL
         MV_LAUNCH_CHECK("mdn_fwd_kernel");
     }
@@ -243,23 +316,31 @@ int mdnvae_mdn_loss_fwd(const float* comp_mean, const float* x, const float* gat
 int mdnvae_mdn_loss_bwd(const float* comp_mean, const float* x, const float* gate_logits, const float* log_sigma,
                         const float* resp, const float* sumsq, int B, int K, int D, const float* mu,
                         const float* logvar, int L, const float* grad_loss, float* grad_comp, float* grad_logits,
-                        float* grad_log_sigma_rows, float* grad_mu, float* grad_logvar, void* stream) {
+                        float* grad_log_sigma_rows, float* grad_mu, float* grad_logvar, void* workspace,
+                        void* stream) {
     MV_REQUIRE(B >= 0 && D >= 1 && L >= 0, E_ARG, "mdnvae_mdn_loss_bwd: bad size");
     MV_REQUIRE(K >= 1 && K <= MDN_MAXK, E_SHAPE, "mdnvae_mdn_loss_bwd: %d components (1..%d supported)", K, MDN_MAXK);
     if (B == 0) return 0;
+    MV_REQUIRE((double)B * K * D < 4294967296.0, E_SHAPE,
+               "mdnvae_mdn_loss_bwd: B*K*D must stay below 2^32 elements per call");
     MV_REQUIRE(comp_mean && x && gate_logits && log_sigma && resp && sumsq && grad_comp && grad_logits &&
-                   grad_log_sigma_rows, E_ARG, "mdnvae_mdn_loss_bwd: null pointer");
+                   grad_log_sigma_rows && workspace, E_ARG, "mdnvae_mdn_loss_bwd: null pointer");
     MV_REQUIRE((grad_mu == nullptr) == (grad_logvar == nullptr), E_ARG, "mdnvae_mdn_loss_bwd: grad_mu/grad_logvar");
     MV_REQUIRE(!grad_mu || (mu && logvar), E_ARG, "mdnvae_mdn_loss_bwd: mu/logvar is null");
     hipStream_t st = (hipStream_t)stream;
-    const bool vec = (D % 4 == 0) && aligned16(comp_mean) && aligned16(x) && aligned16(grad_comp);
-#define CALL(KK, VV)                                                                                               \
-    hipLaunchKernelGGL((mdn_bwd_kernel<KK, VV>), dim3(B), dim3(MDN_NT), 0, st, comp_mean, x, gate_logits, log_sigma,  \
-                       resp, sumsq, D, mu, logvar, L, grad_loss, grad_comp, grad_logits, grad_log_sigma_rows, grad_mu, \
-                       grad_logvar)
-    MV_MDN_DISPATCH(K, vec, CALL)
-#undef CALL
-    MV_LAUNCH_CHECK("mdn_bwd_kernel");
+    float* coef = (float*)workspace;                       // B*K floats
+    const long small = (long)B * (K > L ? K : L);
+    hipLaunchKernelGGL(mdn_bwd_small_kernel, dim3((unsigned)((small + 255) / 256 > 1024 ? 1024 : (small + 255) / 256)),
+                       dim3(256), 0, st, gate_logits, log_sigma, resp, sumsq, B, K, D, mu, logvar, L, grad_loss, coef,
+                       grad_logits, grad_log_sigma_rows, grad_mu, grad_logvar);
+    MV_LAUNCH_CHECK("mdn_bwd_small_kernel");
+    const unsigned total = (unsigned)((long)B * K * D);
+    const unsigned tiles = ((total >> 2) + MDN_NT * MDN_UNROLL - 1) / (MDN_NT * MDN_UNROLL);
+    const unsigned grid = tiles < 1 ? 1 : (tiles > MDN_BWD_BLOCKS_N ? MDN_BWD_BLOCKS_N : tiles);
+    const unsigned magicD = (unsigned)((4294967296ull + D - 1) / D), magicK = (unsigned)((4294967296ull + K - 1) / K);
+    hipLaunchKernelGGL(mdn_bwd_stream_kernel, dim3(grid), dim3(MDN_NT), 0, st, comp_mean, x, coef, total, (unsigned)D,
+                       (unsigned)K, magicD, magicK, grad_comp);
+    MV_LAUNCH_CHECK("mdn_bwd_stream_kernel");
     return 0;
 }
 

@@ -567,8 +567,10 @@ class _MdnLoss(torch.autograd.Function):
         gls_rows = torch.empty_like(logits)
         gmu = torch.empty_like(mu)
         glv = torch.empty_like(mu)
+        ws = torch.empty(_lib.load().mdnvae_mdn_workspace_bytes(B), dtype=torch.uint8, device=comp.device)
         call("mdnvae_mdn_loss_bwd", ptr(comp), ptr(x), ptr(logits), ptr(log_sigma), ptr(resp), ptr(ss), B, K, D,
-             ptr(mu), ptr(logvar), L, ptr(g2), ptr(gcomp), ptr(glogits), ptr(gls_rows), ptr(gmu), ptr(glv), stream())
+             ptr(mu), ptr(logvar), L, ptr(g2), ptr(gcomp), ptr(glogits), ptr(gls_rows), ptr(gmu), ptr(glv),
+             ws.data_ptr(), stream())
         gls = _colsum(gls_rows) if B > 0 else torch.zeros_like(log_sigma)
         return gcomp, None, glogits, gls, gmu, glv
 

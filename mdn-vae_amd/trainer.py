@@ -70,9 +70,16 @@ class Trainer:
         self.fused_loss = fused_loss
 
     def forward_backward(self, inputs, target, eps=None):
-        """inputs: positional arguments of model.forward; returns the detached loss (0-dim)."""
+        """inputs: positional arguments of model.forward; returns the detached loss (0-dim).
+        loss_mode "mdn" trains a model whose forward returns (component means, gate logits, mu,
+        logvar) and whose .loss() is the trait-gated mixture likelihood + KL."""
         self.buf.zero_grad()
         out = self.model(*inputs, eps=eps)
+        if self.loss_mode == "mdn":
+            comp, gate_logits, mu, logvar = out
+            loss = self.model.loss(comp, gate_logits, target, mu, logvar)
+            loss.backward()
+            return loss.detach()
         recon, mu, logvar = out[0], out[1], out[2]
         if self.fused_loss:
             terms, g_recon, g_mu, g_lv = ops.vae_loss_and_grads(recon.detach(), target, mu.detach(), logvar.detach(),
@@ -94,3 +101,50 @@ class Trainer:
         loss = self.forward_backward(inputs, target, eps)
         self.optimizer_step()
         return loss
+
+    def hinge_step(self, fc, sc, eps_with=None, eps_without=None, generator=None, margin=0.01):
+        """Conditional-VAE step of function_FC_SC/SC-FC.py:134-167: one forward with the FC input,
+        one with the FC rows of a random half of the batch zeroed, and
+        loss = loss_with + relu(loss_with - loss_without + margin).  Returns the detached loss."""
+        self.buf.zero_grad()
+        B = fc.shape[0]
+        idx = torch.randperm(B, device=fc.device, generator=generator)[: B // 2]
+        fc_without = fc.clone()
+        fc_without[idx] = 0.0
+        recon, mu, logvar = self.model(fc, sc, eps=eps_with)
+        loss_with = ops.vae_loss_terms(recon, sc, mu, logvar, "mse")[0]
+        recon_no, mu_no, logvar_no = self.model(fc_without, sc, eps=eps_without)
+        loss_without = ops.vae_loss_terms(recon_no, sc, mu_no, logvar_no, "mse")[0]
+        loss = loss_with + torch.relu(loss_with - loss_without + margin)
+        loss.backward()
+        self.optimizer_step()
+        return loss.detach()
+
+    def train_epoch(self, data, batch_size=256, extra=(), target=None, shuffle=True, generator=None,
+                    eps_generator=None):
+        """One pass over `data` [n, D] (device resident) in batches of `batch_size`, last batch
+        ragged, order reshuffled when `shuffle` (function/VAE_CNN_NN.py:53-55, 209-222).  The
+        per-step losses are accumulated on the device and read back once; returns the epoch
+        metric of the scripts, sum of losses / number of subjects (with data-parallel ranks: of
+        this rank's shard).  `extra(idx)` may be a callable giving per-batch extra inputs (e.g.
+        traits) or a tuple of fixed extra inputs (the adjacency list)."""
+        n = data.shape[0]
+        order = torch.randperm(n, device=data.device, generator=generator) if shuffle else \
+            torch.arange(n, device=data.device)
+        latent = self.exp_avg.new_zeros(())                     # running loss on the device
+        self.model.train()
+        for lo in range(0, n, batch_size):
+            idx = order[lo:lo + batch_size]
+            x = data.index_select(0, idx)
+            y = x if target is None else target.index_select(0, idx)
+            more = extra(idx) if callable(extra) else tuple(extra)
+            eps = None
+            if eps_generator is not None:
+                eps = torch.randn(x.shape[0], self._latent_dim(), device=x.device, generator=eps_generator)
+            latent += self.step((x,) + tuple(more), y, eps=eps)
+        return float(latent.item()) / n
+
+    def _latent_dim(self):
+        m = self.model
+        head = getattr(m, "fc_mean", None) or getattr(m, "fc21", None) or getattr(m, "fc_mu")
+        return head.out_features

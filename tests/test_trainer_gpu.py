@@ -70,3 +70,78 @@ def test_conv_vae_trainer_reduces_the_loss():
     losses = [trainer.step((x,), x, eps=torch.randn(16, 68, device=DEV, generator=gen)).item() for _ in range(12)]
     assert all(l == l for l in losses)
     assert losses[-1] < losses[0]
+
+
+def test_train_epoch_matches_the_oracle_loop():
+    """train_epoch of function/MM_Gate.py:195-208 with the ragged last batch: 10 subjects in
+    batches of 4 (4, 4, 2), unshuffled, epsilon from a seeded generator; the epoch metric is
+    sum of losses / number of subjects."""
+    fix = load_fixture("mm_gate")
+    params = fixture_params(fix)
+    model = M.GCNVAE(R=5, n_nodes=68, k=32, n_layers=3, latent_dim=68)
+    model.load_state_dict(params)
+    model = model.to(DEV)
+    adjacency = [list(map(int, r)) for r in fix["adjacency"]]
+    x = torch.from_numpy(fix["x"])
+    data = torch.cat([x, x.flip(0), x])[:10]
+    trainer = M.Trainer(model, "poisson_log")
+    got = trainer.train_epoch(data.to(DEV), batch_size=4, extra=(adjacency,), shuffle=False,
+                              eps_generator=torch.Generator(device=DEV).manual_seed(5))
+
+    gen = torch.Generator(device=DEV).manual_seed(5)
+    p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    state = {k: (torch.zeros_like(v), torch.zeros_like(v)) for k, v in p.items()}
+    total = 0.0
+    for t, lo in enumerate(range(0, 10, 4)):
+        xb = data[lo:lo + 4]
+        e = torch.randn(xb.shape[0], 68, device=DEV, generator=gen).cpu()
+        for v in p.values():
+            v.grad = None
+        recon, mu, lv, _, _ = R.vae_forward("mm_gate", p, xb, e, adjacency=fix["adjacency"])
+        loss = R.vae_loss(recon, xb, mu, lv, "poisson_log")
+        loss.backward()
+        total += loss.item()
+        with torch.no_grad():
+            R.adam_step(p, {k: v.grad for k, v in p.items()}, state, t + 1)
+    assert abs(got - total / 10) <= 1e-4 * abs(total / 10)
+    # shuffled epochs visit every subject once: the multiset of batch sizes is the same
+    g = torch.Generator(device=DEV).manual_seed(1)
+    m2 = trainer.train_epoch(data.to(DEV), batch_size=4, extra=(adjacency,), shuffle=True, generator=g,
+                             eps_generator=torch.Generator(device=DEV).manual_seed(6))
+    assert m2 == m2 and trainer.steps == 6
+
+
+def test_hinge_step_runs_and_matches_manual_composition():
+    """function_FC_SC/SC-FC.py:134-167 through Trainer.hinge_step: the loss equals the manual
+    composition with the same permutation and epsilon (the composition itself is checked against
+    the reference fixture in test_decoder_gpu)."""
+    torch.manual_seed(3)
+    model = M.cVAE(in_dim=100, latent_dim=8, hidden_dim=32).to(DEV)
+    twin = M.cVAE(in_dim=100, latent_dim=8, hidden_dim=32).to(DEV)
+    twin.load_state_dict(model.state_dict())
+    fc, sc = torch.rand(6, 100, device=DEV), torch.rand(6, 100, device=DEV)
+    ea, eb = torch.randn(6, 8, device=DEV), torch.randn(6, 8, device=DEV)
+    trainer = M.Trainer(model, "mse")
+    got = trainer.hinge_step(fc, sc, ea, eb, generator=torch.Generator(device=DEV).manual_seed(9))
+    idx = torch.randperm(6, device=DEV, generator=torch.Generator(device=DEV).manual_seed(9))[:3]
+    fc_no = fc.clone()
+    fc_no[idx] = 0.0
+    r, mu, lv = twin(fc, sc, eps=ea)
+    a = M.loss_function_mse_terms(r, sc, mu, lv)[0]
+    r2, mu2, lv2 = twin(fc_no, sc, eps=eb)
+    b = M.loss_function_mse_terms(r2, sc, mu2, lv2)[0]
+    want = a + torch.relu(a - b + 0.01)
+    assert abs(got.item() - want.item()) <= 1e-6 * abs(want.item())
+
+
+def test_mdn_trainer_step_reduces_the_loss():
+    torch.manual_seed(11111)
+    model = M.MDNGateVAE(R=5, n_nodes=68, k=32, n_layers=3, latent_dim=68, n_traits=4).to(DEV)
+    x = M.data.synthetic_sc(16, 68, seed=1, device=DEV)
+    traits = torch.randn(16, 4, device=DEV)
+    adjacency = [[(u + j) % 68 for j in range(32)] for u in range(68)]
+    trainer = M.Trainer(model, "mdn")
+    gen = torch.Generator(device=DEV).manual_seed(0)
+    losses = [trainer.step((x, adjacency, traits), x, eps=torch.randn(16, 68, device=DEV, generator=gen)).item()
+              for _ in range(10)]
+    assert all(l == l for l in losses) and losses[-1] < losses[0]
