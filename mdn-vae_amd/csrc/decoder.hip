@@ -132,9 +132,10 @@ constexpr int FWD_NT = 256;
 __global__ __launch_bounds__(FWD_NT) void chain_decoder_fwd_kernel(
     DecArgs a, const float* __restrict__ z, const float* __restrict__ wt, const float* __restrict__ wd,
     const float* __restrict__ bi, const float* __restrict__ drop, float* __restrict__ out,
-    float* __restrict__ xlat) {
+    float* __restrict__ xlat, float* __restrict__ nodes) {
     __shared__ float abuf[2][KP][FWD_TS];          // layer input, [k][sample]
     __shared__ float gfin[FWD_TS][MAXR][NP];       // final node vectors per channel
+    __shared__ __attribute__((aligned(16))) float wl[KP * NP];   // the current layer's weight panel
     const int t = threadIdx.x;
     const int n = t % NP, sg = t / NP;             // chain phase: 2 sample groups of 8 (threads < 192)
     const int N = a.N, L = a.L, D = N * N;
@@ -152,7 +153,12 @@ __global__ __launch_bounds__(FWD_NT) void chain_decoder_fwd_kernel(
             int cur = 0;
             for (int l = 0; l < a.NL; ++l) {
                 const int K = (l == 0) ? L : N;
-                const float* w = wt + ((long)(r * a.NL + l) * KP) * NP;
+                {   // staged by all threads, coalesced: per-thread reads from global were latency bound
+                    const float4* src = reinterpret_cast<const float4*>(wt + ((long)(r * a.NL + l) * KP) * NP);
+                    for (int i = t; i < KP * NP / 4; i += FWD_NT) reinterpret_cast<float4*>(wl)[i] = src[i];
+                }
+                __syncthreads();
+                const float* w = wl;
                 if (t < 2 * NP) {
                     float acc[8];
                     const float bias = w[(KP - 1) * NP + n];
@@ -182,6 +188,12 @@ __global__ __launch_bounds__(FWD_NT) void chain_decoder_fwd_kernel(
                 }
                 __syncthreads();
                 cur ^= 1;
+            }
+        }
+        if (nodes) {                                   // final node vectors [B][R][NP]
+            for (int i = t; i < FWD_TS * a.R * NP; i += FWD_NT) {
+                const int s = i / (a.R * NP), rem = i - s * (a.R * NP);
+                if (b0 + s < a.B) nodes[(long)(b0 + s) * a.R * NP + rem] = gfin[s][rem / NP][rem % NP];
             }
         }
         // epilogue: out[b][i*N+j] = f(sum_r g_r[i] g_r[j])
@@ -221,17 +233,74 @@ constexpr int BWD_TS = 8;
 constexpr int BWD_NT = 256;
 
 
+// Component mode, gradient w.r.t. the final node vectors: channel r of sample b has its own
+// gradient matrix G = gout[b][r] (N x N), and
+//   dnode[i] = sum_j G[i][j] g[j]  (row sums: DPP wave reduction, total in lane 63)
+//            + sum_j G[j][i] g[j]  (column sums: accumulated per lane).
+// One wave per (sample, channel) streams G row by row, 16 rows (32 loads) in flight; lane c owns
+// columns c and c+64 (N <= 95).  No LDS; the grid fills the chip, so the pass is HBM bound.
+constexpr int OG_ROWS = 16;
+__global__ __launch_bounds__(256) void comp_outer_grad_kernel(const float* __restrict__ gout,
+                                                              const float* __restrict__ nodes,
+                                                              const float* __restrict__ drop, int B, int R, int N,
+                                                              float* __restrict__ dnode) {
+    const int lane = threadIdx.x & 63;
+    const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long)gridDim.x * 4;
+    const bool c0 = lane < N, c1 = lane + 64 < N;
+    const int D = N * N;
+    for (long pair = wave; pair < (long)B * R; pair += nwaves) {
+        const float* G = gout + pair * D;
+        const float* gv = nodes + pair * NP;
+        const float g0 = c0 ? gv[lane] : 0.0f, g1 = c1 ? gv[lane + 64] : 0.0f;
+        float v0 = 0.0f, v1 = 0.0f, u0 = 0.0f, u1 = 0.0f;
+        for (int j = 0; j < N; j += OG_ROWS) {
+            float a0[OG_ROWS], a1[OG_ROWS];
+#pragma unroll
+            for (int q = 0; q < OG_ROWS; ++q) {
+                const bool live_row = j + q < N;
+                a0[q] = (live_row && c0) ? __builtin_nontemporal_load(G + (j + q) * N + lane) : 0.0f;
+                a1[q] = (live_row && c1) ? __builtin_nontemporal_load(G + (j + q) * N + lane + 64) : 0.0f;
+            }
+#pragma unroll
+            for (int q = 0; q < OG_ROWS; ++q) {
+                const int row = j + q;                                  // uniform over the wave
+                if (row < N) {
+                    const float gj = __int_as_float(
+                        __builtin_amdgcn_readlane(__float_as_int(row < 64 ? g0 : g1), row & 63));
+                    v0 += a0[q] * gj;
+                    v1 += a1[q] * gj;
+                    const float p = wave_sum_dpp(a0[q] * g0 + a1[q] * g1);
+                    const float tot = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p), 63));
+                    if (row < 64) u0 = (lane == row) ? tot : u0;
+                    else u1 = (lane == row - 64) ? tot : u1;
+                }
+            }
+        }
+        float o0 = u0 + v0, o1 = u1 + v1;
+        if (drop) {
+            const int b = (int)(pair / R), r = (int)(pair - (long)b * R);
+            const float* dr = drop + ((long)r * B + b) * N;
+            if (c0) o0 *= dr[lane];
+            if (c1) o1 *= dr[lane + 64];
+        }
+        dnode[pair * NP + lane] = c0 ? o0 : 0.0f;
+        if (lane + 64 < NP) dnode[pair * NP + lane + 64] = c1 ? o1 : 0.0f;
+    }
+}
+
 // Dynamic LDS layout (floats):
 //   acts  [R][NL][TS][NP]   outputs of every layer
 //   zt    [TS][KP]          latent rows of the tile
 //   dg    [R][TS][NP]       gradient w.r.t. the final node vectors
 //   dpb   [TS][NP]          current layer's pre-activation gradient
+//   wl    [KP][NP]          weight panel of the layer being worked on (staged by all threads,
+//                           coalesced; per-thread reads from global were latency bound)
 //   dA    [N][lda]          per-sample gradient of the pre-activation sum (lda odd)
 __global__ __launch_bounds__(BWD_NT) void chain_decoder_bwd_kernel(
     DecArgs a, const float* __restrict__ z, const float* __restrict__ wt, const float* __restrict__ wn,
     const float* __restrict__ wd, const float* __restrict__ bi, const float* __restrict__ drop,
     const float* __restrict__ gout, const float* __restrict__ gxlat, float* __restrict__ dz,
-    float* __restrict__ hin, float* __restrict__ dp, float* __restrict__ ga) {
+    float* __restrict__ hin, float* __restrict__ dp, float* __restrict__ ga, const float* __restrict__ dnode) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int N = a.N, L = a.L, D = N * N, R = a.R, NL = a.NL;
     const int lda = (N & 1) ? N + 2 : N + 1;
@@ -239,7 +308,8 @@ __global__ __launch_bounds__(BWD_NT) void chain_decoder_bwd_kernel(
     float* zt = acts + R * NL * BWD_TS * NP;
     float* dg = zt + BWD_TS * KP;
     float* dpb = dg + R * BWD_TS * NP;
-    float* dA = dpb + DPB_FLOATS;
+    float* wl = dpb + DPB_FLOATS;           // [KP][NP] the current layer's weight panel
+    float* dA = wl + KP * NP;               // (sum mode only)
     const int t = threadIdx.x;
     const int n = t % NP, sg = t / NP;      // chain phases: 2 groups of 4 samples (threads < 192)
     const int ntiles = (a.B + BWD_TS - 1) / BWD_TS;
@@ -262,7 +332,12 @@ __global__ __launch_bounds__(BWD_NT) void chain_decoder_bwd_kernel(
         for (int r = 0; r < R; ++r) {
             for (int l = 0; l < NL; ++l) {
                 const int K = (l == 0) ? L : N;
-                const float* w = wt + ((long)(r * NL + l) * KP) * NP;
+                {
+                    const float4* src = reinterpret_cast<const float4*>(wt + ((long)(r * NL + l) * KP) * NP);
+                    for (int i = t; i < KP * NP / 4; i += BWD_NT) reinterpret_cast<float4*>(wl)[i] = src[i];
+                }
+                __syncthreads();
+                const float* w = wl;
                 if (t < 2 * NP) {
                     float acc[4];
                     const float bias = w[(KP - 1) * NP + n];
@@ -292,66 +367,20 @@ __global__ __launch_bounds__(BWD_NT) void chain_decoder_bwd_kernel(
         }
         // ---- phase 2: per sample, gradient w.r.t. the final node vectors
         if (a.comp_mode) {
-            // Component mode: channel r has its own gradient matrix G = gout[b][r].  One wave per
-            // (sample, channel) streams G row by row straight from global memory, 4 rows (8 loads)
-            // in flight; lane c owns columns c and c+64:
-            //   dg[i] = sum_j G[i][j] g[j]  (row sums: DPP wave reduction, total in lane 63)
-            //         + sum_j G[j][i] g[j]  (column sums: accumulated per lane)
-            float* urow = dpb;                                  // [BWD_NT/64][128] row sums per wave
-            const int lane = t & 63, wv = t >> 6;
-            for (int pair = wv; pair < BWD_TS * R; pair += BWD_NT / 64) {
-                const int s = pair / R, r = pair - s * R;
-                const bool c0 = lane < N, c1 = lane + 64 < N;
-                float out0 = 0.0f, out1 = 0.0f;
-                if (b0 + s < a.B) {                             // uniform over the wave
-                    const float* G = gout + ((long)(b0 + s) * R + r) * D;
-                    const float* gv = &ACTS(r, NL - 1, s, 0);
-                    const float* dr = drop ? drop + ((long)r * a.B + b0 + s) * N : nullptr;
-                    float g0 = c0 ? gv[lane] : 0.0f, g1 = c1 ? gv[lane + 64] : 0.0f;
-                    if (dr) {
-                        if (c0) g0 *= dr[lane];
-                        if (c1) g1 *= dr[lane + 64];
+            // component mode: computed beforehand by comp_outer_grad_kernel (dropout applied there)
+            for (int i = t; i < BWD_TS * R * NP; i += BWD_NT) {
+                const int s = i / (R * NP), rem = i - s * (R * NP);
+                const int r = rem / NP, nn = rem - r * NP;
+                float v = 0.0f;
+                if (b0 + s < a.B) {
+                    v = dnode[(long)(b0 + s) * R * NP + rem];
+                    if (gxlat && r < a.xlat_r && nn < N) {
+                        float gx = gxlat[(long)(b0 + s) * N + nn];
+                        if (drop) gx *= drop[((long)r * a.B + b0 + s) * N + nn];
+                        v += gx;
                     }
-                    float v0 = 0.0f, v1 = 0.0f;
-                    for (int j = 0; j < N; j += 4) {
-                        float a0[4], a1[4];
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const bool live_row = j + q < N;
-                            a0[q] = (live_row && c0) ? G[(j + q) * N + lane] : 0.0f;
-                            a1[q] = (live_row && c1) ? G[(j + q) * N + lane + 64] : 0.0f;
-                        }
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            if (j + q < N) {
-                                float gj = gv[j + q];
-                                if (dr) gj *= dr[j + q];
-                                v0 += a0[q] * gj;
-                                v1 += a1[q] * gj;
-                                const float p = wave_sum_dpp(a0[q] * g0 + a1[q] * g1);
-                                if (lane == 63) urow[wv * 128 + j + q] = p;
-                            }
-                        }
-                    }
-                    // urow was written and is read by this wave only; the LDS write of lane 63
-                    // is ordered before the reads below by the wave-level fence
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    if (c0) out0 = v0 + urow[wv * 128 + lane];
-                    if (c1) out1 = v1 + urow[wv * 128 + lane + 64];
-                    if (gxlat && r < a.xlat_r) {
-                        if (c0) out0 += gxlat[(long)(b0 + s) * N + lane];
-                        if (c1) out1 += gxlat[(long)(b0 + s) * N + lane + 64];
-                    }
-                    if (dr) {
-                        if (c0) out0 *= dr[lane];
-                        if (c1) out1 *= dr[lane + 64];
-                    }
-                    __builtin_amdgcn_wave_barrier();
                 }
-                if (lane < NP) dg[(r * BWD_TS + s) * NP + lane] = c0 ? out0 : 0.0f;
-                if (lane + 64 < NP) dg[(r * BWD_TS + s) * NP + lane + 64] = c1 ? out1 : 0.0f;
+                dg[(r * BWD_TS + s) * NP + nn] = v;
             }
             __syncthreads();
         }
@@ -467,12 +496,16 @@ __global__ __launch_bounds__(BWD_NT) void chain_decoder_bwd_kernel(
                         hin[(row0 + s) * KP + k] = v;
                     }
                 }
+                {
+                    const float4* src = reinterpret_cast<const float4*>(wn + ((long)(r * NL + l) * NP) * KP);
+                    for (int i = t; i < NP * KP / 4; i += BWD_NT) reinterpret_cast<float4*>(wl)[i] = src[i];
+                }
                 __syncthreads();
-                // dh_prev[s][k] = sum_n dpb[s][n] * W[k][n]  (Wn[n][k] is read coalesced over k)
+                // dh_prev[s][k] = sum_n dpb[s][n] * W[k][n]  (Wn[n][k], conflict-free over k)
                 if (t < 2 * NP) {
                     const int k = n;
                     const int K = (l == 0) ? L : N;
-                    const float* w = wn + ((long)(r * NL + l) * NP) * KP;
+                    const float* w = wl;
                     float acc[4] = {0.f, 0.f, 0.f, 0.f};
                     if (k < K) {
 #pragma unroll 4
@@ -555,7 +588,8 @@ static int check_dec(const char* fn, int B, int N, int L, int R, int NL) {
 
 static size_t bwd_lds_bytes(int N, int R, int NL) {
     const int lda = (N & 1) ? N + 2 : N + 1;
-    size_t fl = (size_t)R * NL * BWD_TS * NP + BWD_TS * KP + (size_t)R * BWD_TS * NP + DPB_FLOATS + (size_t)N * lda;
+    size_t fl = (size_t)R * NL * BWD_TS * NP + BWD_TS * KP + (size_t)R * BWD_TS * NP + DPB_FLOATS + (size_t)KP * NP +
+                (size_t)N * lda;
     return fl * sizeof(float);
 }
 
@@ -612,7 +646,7 @@ int mdnvae_decoder_unpack_gcn_grad(const float* dwt, const int* adj, int N, int 
 
 int mdnvae_decoder_fwd(const float* z, const float* wt, int B, int N, int L, int R, int NL, int acts, int epi_act,
                        const float* icpt_w, const float* icpt_b, int do_exp, const float* drop, int xlat_channels,
-                       int components, float* out, float* xlat, void* stream) {
+                       int components, float* out, float* xlat, float* nodes, void* stream) {
     if (int rc = check_dec("mdnvae_decoder_fwd", B, N, L, R, NL)) return rc;
     if (B == 0) return 0;
     MV_REQUIRE(z && wt && out, E_ARG, "mdnvae_decoder_fwd: null pointer");
@@ -624,7 +658,7 @@ int mdnvae_decoder_fwd(const float* z, const float* wt, int B, int N, int L, int
     const int ntiles = (B + FWD_TS - 1) / FWD_TS;
     const int grid = ntiles < 2048 ? ntiles : 2048;
     hipLaunchKernelGGL(chain_decoder_fwd_kernel, dim3(grid), dim3(FWD_NT), 0, (hipStream_t)stream, a, z, wt, icpt_w,
-                       icpt_b, drop, out, xlat_channels ? xlat : nullptr);
+                       icpt_b, drop, out, xlat_channels ? xlat : nullptr, nodes);
     MV_LAUNCH_CHECK("chain_decoder_fwd_kernel");
     return 0;
 }
@@ -634,7 +668,8 @@ size_t mdnvae_decoder_bwd_rows_floats(int B, int R, int NL) { return (size_t)R *
 int mdnvae_decoder_bwd(const float* z, const float* wt, const float* wn, int B, int N, int L, int R, int NL, int acts,
                        int epi_act, const float* icpt_w, const float* icpt_b, int do_exp, const float* drop,
                        int xlat_channels, int components, const float* grad_out, const float* grad_xlat, float* grad_z,
-                       float* layer_in, float* layer_dpre, float* grad_times_act, void* stream) {
+                       float* layer_in, float* layer_dpre, float* grad_times_act, const float* nodes,
+                       float* node_grad, void* stream) {
     if (int rc = check_dec("mdnvae_decoder_bwd", B, N, L, R, NL)) return rc;
     if (B == 0) return 0;
     MV_REQUIRE(z && wt && wn && grad_out && grad_z && layer_in && layer_dpre, E_ARG, "mdnvae_decoder_bwd: null pointer");
@@ -642,6 +677,8 @@ int mdnvae_decoder_bwd(const float* z, const float* wt, const float* wn, int B, 
     MV_REQUIRE(!icpt_w || grad_times_act, E_ARG, "mdnvae_decoder_bwd: intercept gradient needs grad_times_act");
     MV_REQUIRE(!components || (!icpt_w && !do_exp && epi_act == 0), E_ARG,
                "mdnvae_decoder_bwd: component output takes no epilogue");
+    MV_REQUIRE(!components || (nodes && node_grad), E_ARG,
+               "mdnvae_decoder_bwd: component mode needs the forward's node vectors and a node_grad workspace");
     DecArgs a{B, N, L, R, NL, acts, epi_act, icpt_w != nullptr, do_exp, xlat_channels, components};
     const size_t lds = bwd_lds_bytes(N, R, NL);
     MV_REQUIRE(lds <= 160 * 1024, E_SHAPE, "mdnvae_decoder_bwd: needs %zu bytes of LDS", lds);
@@ -651,11 +688,18 @@ int mdnvae_decoder_bwd(const float* z, const float* wt, const float* wn, int B, 
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
+    if (components) {
+        const long pairs = (long)B * R;
+        const unsigned og_grid = (unsigned)((pairs + 3) / 4 < 4096 ? (pairs + 3) / 4 : 4096);
+        hipLaunchKernelGGL(comp_outer_grad_kernel, dim3(og_grid), dim3(256), 0, (hipStream_t)stream, grad_out, nodes,
+                           drop, B, R, N, node_grad);
+        MV_LAUNCH_CHECK("comp_outer_grad_kernel");
+    }
     const int ntiles = (B + BWD_TS - 1) / BWD_TS;
     const int grid = ntiles < 1024 ? ntiles : 1024;
     hipLaunchKernelGGL(chain_decoder_bwd_kernel, dim3(grid), dim3(BWD_NT), lds, (hipStream_t)stream, a, z, wt, wn,
                        icpt_w, icpt_b, drop, grad_out, xlat_channels ? grad_xlat : nullptr, grad_z, layer_in,
-                       layer_dpre, grad_times_act);
+                       layer_dpre, grad_times_act, node_grad);
     MV_LAUNCH_CHECK("chain_decoder_bwd_kernel");
     return 0;
 }

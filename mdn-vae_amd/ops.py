@@ -280,11 +280,12 @@ class _ChainDecoder(torch.autograd.Function):
         D = spec.N * spec.N
         out = torch.empty((B, spec.R, D) if spec.components else (B, D), dtype=torch.float32, device=dev)
         xlat = torch.empty(B, spec.N, dtype=torch.float32, device=dev) if spec.xlat_channels else None
+        nodes = torch.empty(B, spec.R, DEC_NP, dtype=torch.float32, device=dev) if spec.components else None
         call("mdnvae_decoder_fwd", ptr(z, "z"), ptr(wt), B, spec.N, spec.L, spec.R, spec.NL, spec.acts, spec.epi_act,
              ptr(icpt_w, "icpt_w"), ptr(icpt_b, "icpt_b"), int(spec.do_exp), ptr(drop, "drop"), spec.xlat_channels,
-             int(spec.components), ptr(out), ptr(xlat), stream())
+             int(spec.components), ptr(out), ptr(xlat), ptr(nodes), stream())
         ctx.spec = spec
-        ctx.save_for_backward(z, wt, wn, icpt_w, icpt_b, drop)
+        ctx.save_for_backward(z, wt, wn, icpt_w, icpt_b, drop, nodes)
         ctx.param_shapes = [tuple(p.shape) if p is not None else None for p in params]
         if xlat is None:
             xlat = torch.zeros(B, 0, dtype=torch.float32, device=dev)
@@ -294,7 +295,7 @@ class _ChainDecoder(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gout, gxlat):
         spec = ctx.spec
-        z, wt, wn, icpt_w, icpt_b, drop = ctx.saved_tensors
+        z, wt, wn, icpt_w, icpt_b, drop, nodes = ctx.saved_tensors
         B = z.shape[0]
         dev = z.device
         gout = _c(gout)
@@ -307,10 +308,11 @@ class _ChainDecoder(torch.autograd.Function):
         dp = torch.empty(RL, B, DEC_NP, dtype=torch.float32, device=dev)
         gz = torch.empty_like(z)
         ga = torch.empty_like(gout) if icpt_w is not None else None
+        node_grad = torch.empty_like(nodes) if nodes is not None else None
         call("mdnvae_decoder_bwd", ptr(z), ptr(wt), ptr(wn), B, spec.N, spec.L, spec.R, spec.NL, spec.acts,
              spec.epi_act, ptr(icpt_w), ptr(icpt_b), int(spec.do_exp), ptr(drop), spec.xlat_channels,
              int(spec.components), ptr(gout),
-             ptr(gxlat), ptr(gz), ptr(hin), ptr(dp), ptr(ga), stream())
+             ptr(gxlat), ptr(gz), ptr(hin), ptr(dp), ptr(ga), ptr(nodes), ptr(node_grad), stream())
         # weight (+bias, last row) gradient of every layer: [KP x B] . [B x NP] library GEMMs
         dwt = torch.bmm(hin.transpose(1, 2), dp)
         grads = []
