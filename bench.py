@@ -8,6 +8,10 @@
 One step = zero_grad + forward + loss + backward + SUM all-reduce + Adam on one batch of
 synthetic 87x87 connectomes that is already resident in HBM.  Weak scaling: every rank trains
 on its own shard with the same per-GPU batch.  Rank 0 prints ONE JSON line.
+
+The default workload is the trait-gated mixture VAE (FNN encoder, GCN decoder, fused MDN/KL loss;
+`--model mdn_gate`).  On one GPU the line also carries, under "also", a short run of the conv-encoder
+VAE (`--model cnn_gcn`), whose step is dominated by the hand-written MFMA convolutions.
 """
 import argparse
 import json
@@ -26,6 +30,10 @@ from mdnvae_amd import ops  # noqa: E402
 
 PEAK_FP32_MATRIX_TFLOPS = 157.3   # v_mfma_f32_32x32x2_f32, dense
 PEAK_HBM_GBPS = 8000.0
+HBM_KERNELS = ("loss_stream_kernel", "mdn_fwd_kernel", "mdn_bwd_stream_kernel", "chain_decoder_fwd_kernel",
+               "chain_decoder_bwd_kernel")
+# HBM bytes per launch from the rocprofv3 TCC counters (profiles/), where collected; None otherwise
+TRAFFIC_BYTES = {}
 
 MODELS = {
     # name: (constructor kwargs, loss mode, data kind)
@@ -190,12 +198,95 @@ def install_clock(clock):
         return clock.bracket("mdn_bwd_stream_kernel", nbytes, lambda: orig_mb(ctx, gout))
 
     F.forward, F.backward = staticmethod(mdn_fwd), staticmethod(mdn_bwd)
+    # chain decoder: what it must move is the [B,(R,)N*N] output (forward) / its gradient (backward)
+    C = ops._ChainDecoder
+    orig_cf, orig_cb = C.forward, C.backward
+
+    def dec_fwd(ctx, z, spec, icpt_w, icpt_b, drop, *params):
+        rows = spec.R if spec.components else 1
+        nbytes = 4.0 * z.shape[0] * (rows * spec.N * spec.N + spec.L)
+        return clock.bracket("chain_decoder_fwd_kernel", nbytes,
+                             lambda: orig_cf(ctx, z, spec, icpt_w, icpt_b, drop, *params))
+
+    def dec_bwd(ctx, gout, gxlat):
+        spec = ctx.spec
+        rows = spec.R if spec.components else 1
+        nbytes = 4.0 * gout.shape[0] * (rows * spec.N * spec.N + spec.R * spec.NL * (ops.DEC_KP + ops.DEC_NP))
+        return clock.bracket("chain_decoder_bwd_kernel", nbytes, lambda: orig_cb(ctx, gout, gxlat))
+
+    C.forward, C.backward = staticmethod(dec_fwd), staticmethod(dec_bwd)
 
     def restore():
         L.fwd, L.dgrad, L.wgrad = orig_fwd, orig_dgrad, orig_wgrad
         ops.vae_loss_and_grads = orig_loss
         F.forward, F.backward = staticmethod(orig_mf), staticmethod(orig_mb)
+        C.forward, C.backward = staticmethod(orig_cf), staticmethod(orig_cb)
     return restore
+
+
+def default_batch(model_name):
+    return 8192 if model_name in ("mm_gate", "mdn_gate") else 1024
+
+
+def kernel_table(clock, elapsed):
+    """Per tagged kernel: achieved rate from the HIP-event brackets inside the timed region."""
+    kernels = {}
+    for tag, r in clock.summary().items():
+        per_launch = r["seconds"] / max(r["launches"], 1)
+        hbm = tag in HBM_KERNELS
+        rate = r["work"] / r["seconds"] / (1e9 if hbm else 1e12)
+        peak = PEAK_HBM_GBPS if hbm else PEAK_FP32_MATRIX_TFLOPS
+        kernels[tag] = dict(bound="hbm" if hbm else "mfma", achieved=rate, peak=peak, unit="GB/s" if hbm else "TFLOP/s",
+                            frac=rate / peak, launches=r["launches"], avg_ms=per_launch * 1e3,
+                            share_of_step=r["seconds"] / elapsed, traffic=TRAFFIC_BYTES.get(tag))
+    return kernels
+
+
+def run_workload(model_name, batch, nodes, steps, warmup, pool_batches, device, rank, world, use_clock):
+    """Warm up, then time exactly `steps` steps between barrier + synchronize pairs; returns
+    (elapsed seconds: max over ranks, final loss, kernel clock, workload description)."""
+    model, mode, kind = build(model_name, nodes, device)
+    gen = M.data.synthetic_sc if kind == "sc" else M.data.synthetic_fc
+    # each rank owns its shard of the synthetic subjects (seed differs per rank)
+    pool = gen(batch * pool_batches, nodes, seed=1234 + rank, device=device)
+    extra_inputs = ()
+    if model_name in ("cnn_gcn", "cnn_gcn_fc"):
+        mask = rank_mask_from(gen(256, nodes, seed=1234, device=device), nodes)
+        model.set_mask([mask] * 5)
+    if model_name in ("mm_gate", "mdn_gate"):
+        extra_inputs = (knn_adjacency_from(gen(256, nodes, seed=1234, device=device), nodes),)
+    if model_name == "mdn_gate":
+        extra_inputs += (torch.randn(batch, 4, device=device, generator=torch.Generator(device=device).manual_seed(7)),)
+    trainer = M.Trainer(model, mode)
+    eps_gen = torch.Generator(device=device).manual_seed(99 + rank)
+
+    def one_step(i):
+        x = pool[(i % pool_batches) * batch:(i % pool_batches + 1) * batch]
+        eps = torch.randn(batch, 68, device=device, generator=eps_gen)
+        return trainer.step((x,) + extra_inputs, x, eps=eps)
+
+    for i in range(warmup):
+        one_step(i)
+    clock = KernelClock()
+    restore = install_clock(clock) if use_clock else (lambda: None)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    loss = None
+    for i in range(steps):
+        loss = one_step(warmup + i)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    restore()
+    el = torch.tensor([elapsed], device=device, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    what = (f"synthetic {nodes}x{nodes} {kind.upper()} connectomes, {model_name} VAE ({mode} + KL), fwd+bwd+Adam, "
+            "data-parallel over subjects")
+    return float(el.item()), float(loss.item()), clock, what
 
 
 def main():
@@ -203,8 +294,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--model", default="cnn_gcn", choices=list(MODELS))
-    ap.add_argument("--batch", type=int, default=1024, help="per-GPU batch")
+    ap.add_argument("--model", default="mdn_gate", choices=list(MODELS))
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default 8192 for the FNN-encoder models, "
+                                                          "1024 for the conv-encoder models)")
+    ap.add_argument("--also", default="cnn_gcn", help="second workload reported under 'also' on one GPU ('' = none)")
     ap.add_argument("--nodes", type=int, default=87)
     ap.add_argument("--pool", type=int, default=2, help="resident synthetic batches per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -222,82 +315,42 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=device)
 
-    model, mode, kind = build(args.model, args.nodes, device)
-    gen = M.data.synthetic_sc if kind == "sc" else M.data.synthetic_fc
-    # each rank owns its shard of the synthetic subjects (seed differs per rank)
-    pool = gen(args.batch * args.pool, args.nodes, seed=1234 + rank, device=device)
-    extra_inputs = ()
-    if args.model in ("cnn_gcn", "cnn_gcn_fc"):
-        mask = rank_mask_from(gen(256, args.nodes, seed=1234, device=device), args.nodes)
-        model.set_mask([mask] * 5)
-    if args.model in ("mm_gate", "mdn_gate"):
-        extra_inputs = (knn_adjacency_from(gen(256, args.nodes, seed=1234, device=device), args.nodes),)
-    if args.model == "mdn_gate":
-        extra_inputs += (torch.randn(args.batch, 4, device=device, generator=torch.Generator(device=device).manual_seed(7)),)
-    trainer = M.Trainer(model, mode)
-    eps_gen = torch.Generator(device=device).manual_seed(99 + rank)
-
-    def one_step(i):
-        x = pool[(i % args.pool) * args.batch:(i % args.pool + 1) * args.batch]
-        eps = torch.randn(args.batch, 68, device=device, generator=eps_gen)
-        return trainer.step((x,) + extra_inputs, x, eps=eps)
-
-    for i in range(args.warmup):
-        one_step(i)
-    clock = KernelClock()
-    restore = (lambda: None) if args.no_kernel_clock else install_clock(clock)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    loss = None
-    for i in range(args.steps):
-        loss = one_step(args.warmup + i)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    restore()
-    el = torch.tensor([elapsed], device=device, dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-    elapsed = float(el.item())
-    final_loss = float(loss.item())
-
+    batch = args.batch or default_batch(args.model)
+    elapsed, final_loss, clock, what = run_workload(args.model, batch, args.nodes, args.steps, args.warmup, args.pool,
+                                                    device, rank, world, not args.no_kernel_clock)
     if rank == 0:
-        value = world * args.batch * args.steps / elapsed
         line = {
             "metric": "train samples/sec (fwd+bwd, 87x87 connectome)" if args.nodes == 87 else
                       f"train samples/sec (fwd+bwd, {args.nodes}x{args.nodes} connectome)",
-            "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"synthetic {args.nodes}x{args.nodes} {kind.upper()} connectomes, {args.model} VAE "
-                                   f"({mode} + KL), fwd+bwd+Adam, data-parallel over subjects",
-                       "per_gpu_batch": args.batch, "global_batch": args.batch * world, "n_nodes": args.nodes,
-                       "parallelism": f"dp{world}", "final_loss_per_sample": final_loss / args.batch},
+            "value": world * batch * args.steps / elapsed, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": what, "per_gpu_batch": batch, "global_batch": batch * world,
+                       "n_nodes": args.nodes, "parallelism": f"dp{world}", "final_loss_per_sample": final_loss / batch},
         }
-        ks = clock.summary()
-        kernels = {}
-        for tag, r in ks.items():
-            per_launch = r["seconds"] / max(r["launches"], 1)
-            if tag in ("loss_stream_kernel", "mdn_fwd_kernel", "mdn_bwd_stream_kernel"):
-                kernels[tag] = dict(bound="hbm", achieved=r["work"] / r["seconds"] / 1e9, peak=PEAK_HBM_GBPS, unit="GB/s",
-                                    frac=r["work"] / r["seconds"] / 1e9 / PEAK_HBM_GBPS, launches=r["launches"],
-                                    avg_ms=per_launch * 1e3, share_of_step=r["seconds"] / elapsed, traffic=None)
-            else:
-                kernels[tag] = dict(bound="mfma", achieved=r["work"] / r["seconds"] / 1e12, peak=PEAK_FP32_MATRIX_TFLOPS,
-                                    unit="TFLOP/s", frac=r["work"] / r["seconds"] / 1e12 / PEAK_FP32_MATRIX_TFLOPS,
-                                    launches=r["launches"], avg_ms=per_launch * 1e3,
-                                    share_of_step=r["seconds"] / elapsed, traffic=None)
+        kernels = kernel_table(clock, elapsed)
         if kernels:
             dominant = max(kernels, key=lambda k: kernels[k]["share_of_step"])
-            rf = dict(kernels[dominant])
-            rf["kernel"] = dominant
-            line["roofline"] = rf
+            line["roofline"] = dict(kernels[dominant], kernel=dominant)
             line["kernels"] = kernels
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(args.model, args.nodes)
+    if world == 1 and args.also and args.also != args.model:
+        ab = default_batch(args.also)
+        steps = max(2, min(args.steps, 4))
+        el2, loss2, clock2, what2 = run_workload(args.also, ab, args.nodes, steps, 2, args.pool, device, rank, world,
+                                                 not args.no_kernel_clock)
+        k2 = kernel_table(clock2, el2)
+        also = {"workload": what2, "value": ab * steps / el2, "unit": "samples/s", "per_gpu_batch": ab, "steps": steps,
+                "warmup": 2, "ms_per_step": el2 / steps * 1e3, "dtype": "f32", "final_loss_per_sample": loss2 / ab,
+                "kernels": k2}
+        if k2:
+            dom2 = max(k2, key=lambda k: k2[k]["share_of_step"])
+            also["roofline"] = dict(k2[dom2], kernel=dom2)
+        if not args.no_cpu_baseline:
+            also["cpu_baseline"] = cpu_baseline(args.also, args.nodes, seconds_budget=12.0)
+        line["also"] = also
+    if rank == 0:
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
