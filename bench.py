@@ -32,8 +32,9 @@ PEAK_FP32_MATRIX_TFLOPS = 157.3   # v_mfma_f32_32x32x2_f32, dense
 PEAK_HBM_GBPS = 8000.0
 HBM_KERNELS = ("loss_stream_kernel", "mdn_fwd_kernel", "mdn_bwd_stream_kernel", "chain_decoder_fwd_kernel",
                "chain_decoder_bwd_kernel")
-# HBM bytes per launch from the rocprofv3 TCC counters (profiles/), where collected; None otherwise
-TRAFFIC_BYTES = {}
+# fabric-side bytes / algorithmic bytes from the rocprofv3 TCC counters (FETCH_SIZE x2 + WRITE_SIZE,
+# separate passes; profiles/r01_c_loss_pmc_traffic.md); kernels without a collected pass report null
+TRAFFIC_RATIO = {"loss_stream_kernel": 1.00, "mdn_fwd_kernel": 1.10, "mdn_bwd_stream_kernel": 1.27}
 
 MODELS = {
     # name: (constructor kwargs, loss mode, data kind)
@@ -238,7 +239,9 @@ def kernel_table(clock, elapsed):
         peak = PEAK_HBM_GBPS if hbm else PEAK_FP32_MATRIX_TFLOPS
         kernels[tag] = dict(bound="hbm" if hbm else "mfma", achieved=rate, peak=peak, unit="GB/s" if hbm else "TFLOP/s",
                             frac=rate / peak, launches=r["launches"], avg_ms=per_launch * 1e3,
-                            share_of_step=r["seconds"] / elapsed, traffic=TRAFFIC_BYTES.get(tag))
+                            share_of_step=r["seconds"] / elapsed,
+                            traffic=(TRAFFIC_RATIO[tag] * r["work"] / max(r["launches"], 1)) if tag in TRAFFIC_RATIO
+                            else None)
     return kernels
 
 
