@@ -101,7 +101,7 @@ int mdnvae_decoder_unpack_gcn_grad(const float* dwt, const int* adj, int N, int 
  * xlat [B,N] = sum of the first xlat_channels node vectors (the reference returns h1+h2+h3+h4).
  * components = 1: out is [B,R,N*N] with out[b,r] = g_r g_r^T, the per-channel matrices that the
  * trait-gated mixture head uses as component means (no epilogue; build-defined, no reference code).
- * nodes (optional) [B,R,MDNVAE_DEC_NP]: the final node vectors g_r, needed by the component-mode backward. */
+ * nodes [B,R,MDNVAE_DEC_NP] (required): the final node vectors g_r; the backward takes them back. */
 int mdnvae_decoder_fwd(const float* z, const float* wt, int B, int N, int L, int R, int NL, int acts,
                        int epi_act, const float* icpt_w, const float* icpt_b, int do_exp, const float* drop,
                        int xlat_channels, int components, float* out, float* xlat, float* nodes, void* stream);
@@ -112,8 +112,8 @@ size_t mdnvae_decoder_bwd_rows_floats(int B, int R, int NL);
  * layer_in [R][NL][B][KP] (column KP-1 = 1) and pre-activation gradients layer_dpre [R][NL][B][NP],
  * from which the packed weight gradient of layer (r,l) is layer_in^T . layer_dpre (a library GEMM);
  * with an intercept, grad_times_act [B,N*N] = (grad_out [*out if do_exp]) * act(sum), whose column
- * sums are the intercept-weight gradient.  Component mode (grad_out [B,R,N*N]) also takes the
- * forward's nodes [B,R,MDNVAE_DEC_NP] and a node_grad workspace of the same size. */
+ * sums are the intercept-weight gradient.  grad_out is [B,R,N*N] in component mode.  nodes
+ * [B,R,MDNVAE_DEC_NP] are the forward's node vectors, node_grad a workspace of the same size. */
 int mdnvae_decoder_bwd(const float* z, const float* wt, const float* wn, int B, int N, int L, int R, int NL,
                        int acts, int epi_act, const float* icpt_w, const float* icpt_b, int do_exp,
                        const float* drop, int xlat_channels, int components, const float* grad_out, const float* grad_xlat,

@@ -13,9 +13,9 @@
 // adjacency and the 0/1 masks are applied when the panel is packed (scatter / multiply),
 // once per step, which is what the reference redoes on every forward.
 //
-// The backward kernel recomputes the chain per tile (saves nothing but inputs), forms the
-// symmetric pre-activation gradient of sum_r g_r g_r^T in LDS one sample at a time, walks
-// the chains backwards, and emits per-layer (input activation, pre-activation gradient)
+// The backward saves only the inputs and the final node vectors: one streaming kernel turns the
+// output gradient into the gradient of the node vectors, a second one recomputes each chain per
+// tile, walks it backwards, and emits per-layer (input activation, pre-activation gradient)
 // rows; the weight/bias gradients are then [K x B].[B x N] library GEMMs over those rows.
 #include "common.h"
 #include "../../include/mdnvae_hip.h"
@@ -27,7 +27,6 @@ constexpr int KP = MDNVAE_DEC_KP;   // padded fan-in; row KP-1 = bias
 constexpr int MAXL = 4;             // layers per channel
 constexpr int MAXR = 8;
 static_assert(NP == KP, "layer outputs are reused as the next layer's input rows");
-constexpr int DPB_FLOATS = 1024;   // >= BWD_TS*NP and >= MAXR*128
 
 constexpr int ACT_NONE = 0, ACT_SIGMOID = 1, ACT_TANH = 2;
 
@@ -114,8 +113,14 @@ __global__ void unpack_gcn_grad_kernel(const float* __restrict__ dwt, const int*
 }
 
 // ---------------------------------------------------------------------------------------
-// forward
+// kernels
 // ---------------------------------------------------------------------------------------
+// Forward  = chain_fwd_mfma_kernel (z -> final node vectors, x_latent)
+//          + outer_epilogue_kernel (node vectors -> out, HBM-write bound).
+// Backward = outer_grad_kernel (grad_out, node vectors -> gradient of the node vectors, HBM-read
+//            bound) + chain_bwd_mfma_kernel (recompute each chain, walk it backwards).
+// The chain kernels run every layer as a [32 samples x 96] . [96 x 96] product on the fp32
+// matrix cores (v_mfma_f32_32x32x2_f32); three waves own the three 32-column tiles of the output.
 struct DecArgs {
     int B, N, L, R, NL;
     int acts;        // 2 bits per layer
@@ -126,415 +131,373 @@ struct DecArgs {
     int comp_mode;   // 1: out[b][r][e] = g_r[i]*g_r[j] per channel (mixture components), no epilogue
 };
 
-constexpr int FWD_TS = 16;    // samples per tile
-constexpr int FWD_NT = 256;
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+constexpr int CH_TS = 32;            // samples per tile = MFMA rows
+constexpr int CH_NT = 192;           // three waves, one per 32-column tile of the layer output
+constexpr int CH_LD = CH_TS + 1;     // row stride of the k-major activation buffers (conflict-free)
 
-__global__ __launch_bounds__(FWD_NT) void chain_decoder_fwd_kernel(
-    DecArgs a, const float* __restrict__ z, const float* __restrict__ wt, const float* __restrict__ wd,
-    const float* __restrict__ bi, const float* __restrict__ drop, float* __restrict__ out,
-    float* __restrict__ xlat, float* __restrict__ nodes) {
-    __shared__ float abuf[2][KP][FWD_TS];          // layer input, [k][sample]
-    __shared__ float gfin[FWD_TS][MAXR][NP];       // final node vectors per channel
-    __shared__ __attribute__((aligned(16))) float wl[KP * NP];   // the current layer's weight panel
-    const int t = threadIdx.x;
-    const int n = t % NP, sg = t / NP;             // chain phase: 2 sample groups of 8 (threads < 192)
-    const int N = a.N, L = a.L, D = N * N;
-    const int ntiles = (a.B + FWD_TS - 1) / FWD_TS;
+// sample row of accumulator register j (column = lane & 31)
+__device__ __forceinline__ int acc_row(int j, int lane) { return (j & 3) + 8 * (j >> 2) + 4 * (lane >> 5); }
 
+// acc[s][n] = sum_k in[k][s] * w[k][n0 + n] over the whole padded panel (row KP-1 of `in` is 1,
+// so the bias row of the panel is added by the product itself)
+__device__ __forceinline__ f32x16 panel_product(const float* __restrict__ in, const float* __restrict__ w, int n0,
+                                                int lane) {
+    f32x16 acc;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = 0.0f;
+    const int h = lane >> 5, l32 = lane & 31;
+#pragma unroll 8
+    for (int k = 0; k < KP; k += 2) {
+        const float av = in[(k + h) * CH_LD + l32];
+        const float bv = w[(k + h) * NP + n0 + l32];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+    }
+    return acc;
+}
+
+__device__ __forceinline__ void stage_panel(const float* __restrict__ src, float* __restrict__ wl) {
+    const float4* s4 = reinterpret_cast<const float4*>(src);
+    for (int i = threadIdx.x; i < KP * NP / 4; i += CH_NT) reinterpret_cast<float4*>(wl)[i] = s4[i];
+}
+
+// z tile -> k-major rows with the ones row at KP-1
+__device__ __forceinline__ void load_latent_tile(const float* __restrict__ z, int b0, int B, int L,
+                                                 float* __restrict__ zt) {
+    for (int i = threadIdx.x; i < KP * CH_TS; i += CH_NT) {
+        const int s = i / KP, k = i - s * KP;              // consecutive threads read consecutive k
+        float v = 0.0f;
+        if (k == KP - 1) v = 1.0f;
+        else if (k < L && b0 + s < B) v = z[(long)(b0 + s) * L + k];
+        zt[k * CH_LD + s] = v;
+    }
+}
+
+__global__ __launch_bounds__(CH_NT) void chain_fwd_mfma_kernel(DecArgs a, const float* __restrict__ z,
+                                                               const float* __restrict__ wt,
+                                                               const float* __restrict__ drop,
+                                                               float* __restrict__ nodes, float* __restrict__ xlat) {
+    __shared__ float abuf[2][KP * CH_LD];
+    __shared__ __attribute__((aligned(16))) float wl[KP * NP];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int n = wave * 32 + (lane & 31);
+    const int N = a.N;
+    const int ntiles = (a.B + CH_TS - 1) / CH_TS;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int b0 = tile * FWD_TS;
+        const int b0 = tile * CH_TS;
+        float xl[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) xl[j] = 0.0f;
         for (int r = 0; r < a.R; ++r) {
-            __syncthreads();
-            for (int i = t; i < L * FWD_TS; i += FWD_NT) {
-                const int s = i / L, k = i - s * L;
-                abuf[0][k][s] = (b0 + s < a.B) ? z[(long)(b0 + s) * L + k] : 0.0f;
-            }
-            __syncthreads();
+            load_latent_tile(z, b0, a.B, a.L, abuf[0]);      // every reader of abuf has passed a barrier
             int cur = 0;
             for (int l = 0; l < a.NL; ++l) {
-                const int K = (l == 0) ? L : N;
-                {   // staged by all threads, coalesced: per-thread reads from global were latency bound
-                    const float4* src = reinterpret_cast<const float4*>(wt + ((long)(r * a.NL + l) * KP) * NP);
-                    for (int i = t; i < KP * NP / 4; i += FWD_NT) reinterpret_cast<float4*>(wl)[i] = src[i];
-                }
+                stage_panel(wt + ((long)(r * a.NL + l) * KP) * NP, wl);
                 __syncthreads();
-                const float* w = wl;
-                if (t < 2 * NP) {
-                    float acc[8];
-                    const float bias = w[(KP - 1) * NP + n];
+                const f32x16 acc = panel_product(abuf[cur], wl, wave * 32, lane);
+                const int act = layer_act(a.acts, l);
+                if (l == a.NL - 1) {
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) acc[i] = bias;
-#pragma unroll 4
-                    for (int k = 0; k < K; ++k) {
-                        const float wv = w[k * NP + n];
-                        const float4 a0 = *reinterpret_cast<const float4*>(&abuf[cur][k][sg * 8]);
-                        const float4 a1 = *reinterpret_cast<const float4*>(&abuf[cur][k][sg * 8 + 4]);
-                        acc[0] += wv * a0.x; acc[1] += wv * a0.y; acc[2] += wv * a0.z; acc[3] += wv * a0.w;
-                        acc[4] += wv * a1.x; acc[5] += wv * a1.y; acc[6] += wv * a1.z; acc[7] += wv * a1.w;
-                    }
-                    const int act = layer_act(a.acts, l);
-                    if (l == a.NL - 1) {
-#pragma unroll
-                        for (int i = 0; i < 8; ++i) {
-                            const int s = sg * 8 + i;
-                            float v = (n < N) ? act_apply(act, acc[i]) : 0.0f;
-                            if (drop && n < N && b0 + s < a.B) v *= drop[((long)r * a.B + b0 + s) * N + n];
-                            gfin[s][r][n] = v;
+                    for (int j = 0; j < 16; ++j) {
+                        const int s = acc_row(j, lane);
+                        if (b0 + s < a.B) {
+                            float v = (n < N) ? act_apply(act, acc[j]) : 0.0f;
+                            if (drop && n < N) v *= drop[((long)r * a.B + b0 + s) * N + n];
+                            nodes[((long)(b0 + s) * a.R + r) * NP + n] = v;
+                            if (r < a.xlat_r) xl[j] += v;
                         }
-                    } else {
+                    }
+                } else {
 #pragma unroll
-                        for (int i = 0; i < 8; ++i) abuf[cur ^ 1][n][sg * 8 + i] = act_apply(act, acc[i]);
+                    for (int j = 0; j < 16; ++j) {
+                        float v = (n < N) ? act_apply(act, acc[j]) : 0.0f;
+                        if (n == KP - 1) v = 1.0f;
+                        abuf[cur ^ 1][n * CH_LD + acc_row(j, lane)] = v;
                     }
                 }
                 __syncthreads();
                 cur ^= 1;
             }
         }
-        if (nodes) {                                   // final node vectors [B][R][NP]
-            for (int i = t; i < FWD_TS * a.R * NP; i += FWD_NT) {
-                const int s = i / (a.R * NP), rem = i - s * (a.R * NP);
-                if (b0 + s < a.B) nodes[(long)(b0 + s) * a.R * NP + rem] = gfin[s][rem / NP][rem % NP];
-            }
-        }
-        // epilogue: out[b][i*N+j] = f(sum_r g_r[i] g_r[j])
-        const int di = FWD_NT / N, dj = FWD_NT - di * N;
-        for (int s = 0; s < FWD_TS && b0 + s < a.B; ++s) {
-            float* orow = out + (long)(b0 + s) * D;
-            int i = t / N, j = t - i * N;
-            for (int e = t; e < D; e += FWD_NT) {
-                if (a.comp_mode) {
-                    float* crow = out + (long)(b0 + s) * a.R * D;
-                    for (int r = 0; r < a.R; ++r) crow[(long)r * D + e] = gfin[s][r][i] * gfin[s][r][j];
-                } else {
-                    float sum = 0.0f;
-                    for (int r = 0; r < a.R; ++r) sum += gfin[s][r][i] * gfin[s][r][j];
-                    float v = act_apply(a.epi_act, sum);
-                    if (a.has_icpt) v = v * wd[e] + bi[e];
-                    if (a.do_exp) v = expf(v);
-                    orow[e] = v;
-                }
-                i += di;
-                j += dj;
-                if (j >= N) { j -= N; ++i; }
-            }
-            if (xlat && t < N) {
-                float sum = 0.0f;
-                for (int r = 0; r < a.xlat_r; ++r) sum += gfin[s][r][t];
-                xlat[(long)(b0 + s) * N + t] = sum;
+        if (xlat && n < N) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int s = acc_row(j, lane);
+                if (b0 + s < a.B) xlat[(long)(b0 + s) * N + n] = xl[j];
             }
         }
     }
 }
 
-// ---------------------------------------------------------------------------------------
-// backward
-// ---------------------------------------------------------------------------------------
-constexpr int BWD_TS = 8;
-constexpr int BWD_NT = 256;
+// out[b][i*N+j] = f(sum_r g_r[i] g_r[j])  (one wave per sample), or in component mode
+// out[b][r][i*N+j] = g_r[i] g_r[j] (one wave per (sample, channel)).  The wave keeps its node
+// vectors in LDS and writes the N*N matrix as one flat run of 16-byte quads (the matrix starts at
+// a 4-byte phase when N*N is odd; the hardware takes unaligned 16-byte stores), HBM-write bound.
+__global__ __launch_bounds__(256) void outer_epilogue_kernel(DecArgs a, const float* __restrict__ nodes,
+                                                             const float* __restrict__ wd,
+                                                             const float* __restrict__ bi, unsigned magicN,
+                                                             float* __restrict__ out) {
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    typedef v4f v4fu __attribute__((aligned(4)));
+    __shared__ float gl[4][MAXR * NP];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long wave = (long)blockIdx.x * 4 + wv, nwaves = (long)gridDim.x * 4;
+    const int N = a.N, D = N * N, nq = D >> 2;
+    const int per = a.comp_mode ? 1 : a.R;                  // node vectors per output matrix
+    const long nout = a.comp_mode ? (long)a.B * a.R : a.B;
+    float* g = gl[wv];
+    for (long m = wave; m < nout; m += nwaves) {
+        const float* gv = nodes + m * per * NP;
+        __builtin_amdgcn_wave_barrier();                    // the previous matrix is done with g
+        for (int i = lane; i < per * NP; i += 64) g[i] = gv[i];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        float* orow = out + m * D;
+        auto value = [&](int i, int j, int e) {
+            float s = 0.0f;
+            for (int r = 0; r < per; ++r) s += g[r * NP + i] * g[r * NP + j];
+            if (!a.comp_mode) {
+                s = act_apply(a.epi_act, s);
+                if (a.has_icpt) s = s * wd[e] + bi[e];
+                if (a.do_exp) s = expf(s);
+            }
+            return s;
+        };
+        for (int q = lane; q < nq; q += 64) {
+            const int e0 = q << 2;
+            int i = (int)__umulhi((unsigned)e0, magicN);    // e0 / N  (e0 * N < 2^32)
+            int j = e0 - i * N;
+            v4f o;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                o[c] = value(i, j, e0 + c);
+                if (++j == N) { j = 0; ++i; }
+            }
+            __builtin_nontemporal_store(o, reinterpret_cast<v4fu*>(orow) + q);
+        }
+        const int e = (nq << 2) + lane;                     // the (at most 3) elements past the last quad
+        if (e < D) {
+            const int i = (int)__umulhi((unsigned)e, magicN);
+            orow[e] = value(i, e - i * N, e);
+        }
+    }
+}
 
-
-// Component mode, gradient w.r.t. the final node vectors: channel r of sample b has its own
-// gradient matrix G = gout[b][r] (N x N), and
-//   dnode[i] = sum_j G[i][j] g[j]  (row sums: DPP wave reduction, total in lane 63)
-//            + sum_j G[j][i] g[j]  (column sums: accumulated per lane).
-// One wave per (sample, channel) streams G row by row, 16 rows (32 loads) in flight; lane c owns
+// Gradient of the node vectors.  Per output matrix the pre-activation gradient A (N x N) is
+//   component mode: A = grad_out[b][r] as it stands (one wave per (sample, channel));
+//   sum mode:       A = grad_out[b] chained through exp / intercept / activation of sum_r g_r g_r^T
+//                   (one wave per sample, A feeds every channel; grad_times_act is emitted for the
+//                   intercept-weight gradient),
+// and  dnode_r[i] = sum_j A[i][j] g_r[j]  (row sums: DPP wave reduction, total in lane 63)
+//                 + sum_j A[j][i] g_r[j]  (column sums: accumulated per lane),
+// times the dropout multiplier.  A is streamed row by row, OG_ROWS rows in flight; lane c owns
 // columns c and c+64 (N <= 95).  No LDS; the grid fills the chip, so the pass is HBM bound.
-constexpr int OG_ROWS = 16;
-__global__ __launch_bounds__(256) void comp_outer_grad_kernel(const float* __restrict__ gout,
-                                                              const float* __restrict__ nodes,
-                                                              const float* __restrict__ drop, int B, int R, int N,
-                                                              float* __restrict__ dnode) {
+constexpr int OG_ROWS = 8;
+template <bool COMP>
+__global__ __launch_bounds__(256) void outer_grad_kernel(DecArgs a, const float* __restrict__ gout,
+                                                         const float* __restrict__ nodes,
+                                                         const float* __restrict__ wd, const float* __restrict__ bi,
+                                                         const float* __restrict__ drop, float* __restrict__ ga,
+                                                         float* __restrict__ dnode) {
+    constexpr int RR = COMP ? 1 : MAXR;
     const int lane = threadIdx.x & 63;
     const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long)gridDim.x * 4;
+    const int N = a.N, D = N * N;
     const bool c0 = lane < N, c1 = lane + 64 < N;
-    const int D = N * N;
-    for (long pair = wave; pair < (long)B * R; pair += nwaves) {
-        const float* G = gout + pair * D;
-        const float* gv = nodes + pair * NP;
-        const float g0 = c0 ? gv[lane] : 0.0f, g1 = c1 ? gv[lane + 64] : 0.0f;
-        float v0 = 0.0f, v1 = 0.0f, u0 = 0.0f, u1 = 0.0f;
-        for (int j = 0; j < N; j += OG_ROWS) {
+    const int per = COMP ? 1 : a.R;
+    const long nmat = COMP ? (long)a.B * a.R : a.B;
+    for (long m = wave; m < nmat; m += nwaves) {
+        const float* G = gout + m * D;
+        const float* gv = nodes + m * per * NP;
+        float g0[RR], g1[RR], v0[RR], v1[RR], u0[RR], u1[RR];
+#pragma unroll
+        for (int r = 0; r < RR; ++r) {
+            g0[r] = (r < per && c0) ? gv[r * NP + lane] : 0.0f;
+            g1[r] = (r < per && c1) ? gv[r * NP + lane + 64] : 0.0f;
+            v0[r] = v1[r] = u0[r] = u1[r] = 0.0f;
+        }
+        for (int i0 = 0; i0 < N; i0 += OG_ROWS) {
             float a0[OG_ROWS], a1[OG_ROWS];
 #pragma unroll
             for (int q = 0; q < OG_ROWS; ++q) {
-                const bool live_row = j + q < N;
-                a0[q] = (live_row && c0) ? __builtin_nontemporal_load(G + (j + q) * N + lane) : 0.0f;
-                a1[q] = (live_row && c1) ? __builtin_nontemporal_load(G + (j + q) * N + lane + 64) : 0.0f;
+                const bool live_row = i0 + q < N;
+                a0[q] = (live_row && c0) ? __builtin_nontemporal_load(G + (i0 + q) * N + lane) : 0.0f;
+                a1[q] = (live_row && c1) ? __builtin_nontemporal_load(G + (i0 + q) * N + lane + 64) : 0.0f;
             }
 #pragma unroll
             for (int q = 0; q < OG_ROWS; ++q) {
-                const int row = j + q;                                  // uniform over the wave
-                if (row < N) {
-                    const float gj = __int_as_float(
-                        __builtin_amdgcn_readlane(__float_as_int(row < 64 ? g0 : g1), row & 63));
-                    v0 += a0[q] * gj;
-                    v1 += a1[q] * gj;
-                    const float p = wave_sum_dpp(a0[q] * g0 + a1[q] * g1);
-                    const float tot = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p), 63));
-                    if (row < 64) u0 = (lane == row) ? tot : u0;
-                    else u1 = (lane == row - 64) ? tot : u1;
+                const int i = i0 + q;                               // uniform over the wave
+                if (i < N) {
+                    float gi[RR];
+#pragma unroll
+                    for (int r = 0; r < RR; ++r)
+                        gi[r] = (r < per) ? __int_as_float(__builtin_amdgcn_readlane(
+                                                __float_as_int(i < 64 ? g0[r] : g1[r]), i & 63))
+                                          : 0.0f;
+                    float e0 = a0[q], e1 = a1[q];
+                    if (!COMP) {
+                        float s0 = 0.0f, s1 = 0.0f;
+#pragma unroll
+                        for (int r = 0; r < RR; ++r) {
+                            s0 += gi[r] * g0[r];
+                            s1 += gi[r] * g1[r];
+                        }
+                        const float av0 = act_apply(a.epi_act, s0), av1 = act_apply(a.epi_act, s1);
+                        const int e = i * N + lane;
+                        float w0 = 1.0f, w1 = 1.0f;
+                        if (a.has_icpt) {
+                            w0 = c0 ? wd[e] : 0.0f;
+                            w1 = c1 ? wd[e + 64] : 0.0f;
+                        }
+                        if (a.do_exp) {
+                            float o0 = av0, o1 = av1;
+                            if (a.has_icpt) {
+                                o0 = o0 * w0 + (c0 ? bi[e] : 0.0f);
+                                o1 = o1 * w1 + (c1 ? bi[e + 64] : 0.0f);
+                            }
+                            e0 *= expf(o0);
+                            e1 *= expf(o1);
+                        }
+                        if (a.has_icpt) {
+                            if (c0) ga[m * D + e] = e0 * av0;
+                            if (c1) ga[m * D + e + 64] = e1 * av1;
+                            e0 *= w0;
+                            e1 *= w1;
+                        }
+                        e0 = c0 ? e0 * act_slope(a.epi_act, av0) : 0.0f;
+                        e1 = c1 ? e1 * act_slope(a.epi_act, av1) : 0.0f;
+                    }
+#pragma unroll
+                    for (int r = 0; r < RR; ++r) {
+                        if (r < per) {
+                            v0[r] += e0 * gi[r];
+                            v1[r] += e1 * gi[r];
+                            const float p = wave_sum_dpp(e0 * g0[r] + e1 * g1[r]);
+                            const float tot = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p), 63));
+                            if (i < 64) u0[r] = (lane == i) ? tot : u0[r];
+                            else u1[r] = (lane == i - 64) ? tot : u1[r];
+                        }
+                    }
                 }
             }
         }
-        float o0 = u0 + v0, o1 = u1 + v1;
-        if (drop) {
-            const int b = (int)(pair / R), r = (int)(pair - (long)b * R);
-            const float* dr = drop + ((long)r * B + b) * N;
-            if (c0) o0 *= dr[lane];
-            if (c1) o1 *= dr[lane + 64];
+#pragma unroll
+        for (int r = 0; r < RR; ++r) {
+            if (r < per) {
+                float o0 = u0[r] + v0[r], o1 = u1[r] + v1[r];
+                const long b = COMP ? m / a.R : m;
+                const int ch = COMP ? (int)(m - b * a.R) : r;
+                if (drop) {
+                    const float* dr = drop + ((long)ch * a.B + b) * N;
+                    if (c0) o0 *= dr[lane];
+                    if (c1) o1 *= dr[lane + 64];
+                }
+                float* dst = dnode + (b * a.R + ch) * NP;
+                dst[lane] = c0 ? o0 : 0.0f;
+                if (lane + 64 < NP) dst[lane + 64] = c1 ? o1 : 0.0f;
+            }
         }
-        dnode[pair * NP + lane] = c0 ? o0 : 0.0f;
-        if (lane + 64 < NP) dnode[pair * NP + lane + 64] = c1 ? o1 : 0.0f;
     }
 }
 
-// Dynamic LDS layout (floats):
-//   acts  [R][NL][TS][NP]   outputs of every layer
-//   zt    [TS][KP]          latent rows of the tile
-//   dg    [R][TS][NP]       gradient w.r.t. the final node vectors
-//   dpb   [TS][NP]          current layer's pre-activation gradient
-//   wl    [KP][NP]          weight panel of the layer being worked on (staged by all threads,
-//                           coalesced; per-thread reads from global were latency bound)
-//   dA    [N][lda]          per-sample gradient of the pre-activation sum (lda odd)
-__global__ __launch_bounds__(BWD_NT) void chain_decoder_bwd_kernel(
-    DecArgs a, const float* __restrict__ z, const float* __restrict__ wt, const float* __restrict__ wn,
-    const float* __restrict__ wd, const float* __restrict__ bi, const float* __restrict__ drop,
-    const float* __restrict__ gout, const float* __restrict__ gxlat, float* __restrict__ dz,
-    float* __restrict__ hin, float* __restrict__ dp, float* __restrict__ ga, const float* __restrict__ dnode) {
+// Chain backward for a tile of 32 samples: per channel, recompute the layer outputs (k-major in
+// LDS), then walk the layers backwards: dpre = dh * act'(h) goes to layer_dpre and, n-major in
+// LDS, is the A operand of dh_prev = dpre . W (panel Wn[n][k]); the layer's input rows go to
+// layer_in.  The latent gradient accumulates over the channels in the MFMA accumulators.
+__global__ __launch_bounds__(CH_NT) void chain_bwd_mfma_kernel(DecArgs a, const float* __restrict__ z,
+                                                               const float* __restrict__ wt,
+                                                               const float* __restrict__ wn,
+                                                               const float* __restrict__ drop,
+                                                               const float* __restrict__ dnode,
+                                                               const float* __restrict__ gxlat, float* __restrict__ dz,
+                                                               float* __restrict__ hin, float* __restrict__ dp) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int N = a.N, L = a.L, D = N * N, R = a.R, NL = a.NL;
-    const int lda = (N & 1) ? N + 2 : N + 1;
-    float* acts = smem;
-    float* zt = acts + R * NL * BWD_TS * NP;
-    float* dg = zt + BWD_TS * KP;
-    float* dpb = dg + R * BWD_TS * NP;
-    float* wl = dpb + DPB_FLOATS;           // [KP][NP] the current layer's weight panel
-    float* dA = wl + KP * NP;               // (sum mode only)
-    const int t = threadIdx.x;
-    const int n = t % NP, sg = t / NP;      // chain phases: 2 groups of 4 samples (threads < 192)
-    const int ntiles = (a.B + BWD_TS - 1) / BWD_TS;
-#define ACTS(r, l, s, nn) acts[(((r) * NL + (l)) * BWD_TS + (s)) * NP + (nn)]
-
+    float* wl = smem;                                   // [KP][NP]
+    float* zt = wl + KP * NP;                           // [KP][CH_LD]
+    float* dpb = zt + KP * CH_LD;                       // [NP][CH_LD]
+    float* acts = dpb + NP * CH_LD;                     // [NL][KP][CH_LD]
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int n = wave * 32 + (lane & 31);
+    const int N = a.N, R = a.R, NL = a.NL;
+    const int ntiles = (a.B + CH_TS - 1) / CH_TS;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int b0 = tile * BWD_TS;
+        const int b0 = tile * CH_TS;
         __syncthreads();
-        for (int i = t; i < BWD_TS * KP; i += BWD_NT) {
-            const int s = i / KP, k = i - s * KP;
-            float v = 0.0f;
-            if (b0 + s < a.B) {
-                if (k < L) v = z[(long)(b0 + s) * L + k];
-                else if (k == KP - 1) v = 1.0f;
-            }
-            zt[i] = v;
-        }
-        __syncthreads();
-        // ---- phase 1: recompute every chain, keeping all layer outputs
+        load_latent_tile(z, b0, a.B, a.L, zt);
+        f32x16 dzacc;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) dzacc[j] = 0.0f;
         for (int r = 0; r < R; ++r) {
+            // recompute the chain of channel r
             for (int l = 0; l < NL; ++l) {
-                const int K = (l == 0) ? L : N;
-                {
-                    const float4* src = reinterpret_cast<const float4*>(wt + ((long)(r * NL + l) * KP) * NP);
-                    for (int i = t; i < KP * NP / 4; i += BWD_NT) reinterpret_cast<float4*>(wl)[i] = src[i];
-                }
+                stage_panel(wt + ((long)(r * NL + l) * KP) * NP, wl);
                 __syncthreads();
-                const float* w = wl;
-                if (t < 2 * NP) {
-                    float acc[4];
-                    const float bias = w[(KP - 1) * NP + n];
+                const f32x16 acc = panel_product(l == 0 ? zt : acts + (l - 1) * KP * CH_LD, wl, wave * 32, lane);
+                const int act = layer_act(a.acts, l);
+                float* dst = acts + l * KP * CH_LD;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) acc[i] = bias;
-                    if (l == 0) {
-#pragma unroll 4
-                        for (int k = 0; k < K; ++k) {
-                            const float wv = w[k * NP + n];
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) acc[i] += wv * zt[(sg * 4 + i) * KP + k];
-                        }
-                    } else {
-#pragma unroll 4
-                        for (int k = 0; k < K; ++k) {
-                            const float wv = w[k * NP + n];
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) acc[i] += wv * ACTS(r, l - 1, sg * 4 + i, k);
-                        }
-                    }
-                    const int act = layer_act(a.acts, l);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) ACTS(r, l, sg * 4 + i, n) = (n < N) ? act_apply(act, acc[i]) : 0.0f;
+                for (int j = 0; j < 16; ++j) {
+                    float v = (n < N) ? act_apply(act, acc[j]) : 0.0f;
+                    if (n == KP - 1) v = 1.0f;
+                    dst[n * CH_LD + acc_row(j, lane)] = v;
                 }
                 __syncthreads();
             }
-        }
-        // ---- phase 2: per sample, gradient w.r.t. the final node vectors
-        if (a.comp_mode) {
-            // component mode: computed beforehand by comp_outer_grad_kernel (dropout applied there)
-            for (int i = t; i < BWD_TS * R * NP; i += BWD_NT) {
-                const int s = i / (R * NP), rem = i - s * (R * NP);
-                const int r = rem / NP, nn = rem - r * NP;
+            // gradient w.r.t. the final node vector (dropout already applied to dnode)
+            f32x16 dh;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int s = acc_row(j, lane);
                 float v = 0.0f;
-                if (b0 + s < a.B) {
-                    v = dnode[(long)(b0 + s) * R * NP + rem];
-                    if (gxlat && r < a.xlat_r && nn < N) {
-                        float gx = gxlat[(long)(b0 + s) * N + nn];
-                        if (drop) gx *= drop[((long)r * a.B + b0 + s) * N + nn];
+                if (b0 + s < a.B && n < N) {
+                    v = dnode[((long)(b0 + s) * R + r) * NP + n];
+                    if (gxlat && r < a.xlat_r) {
+                        float gx = gxlat[(long)(b0 + s) * N + n];
+                        if (drop) gx *= drop[((long)r * a.B + b0 + s) * N + n];
                         v += gx;
                     }
                 }
-                dg[(r * BWD_TS + s) * NP + nn] = v;
-            }
-            __syncthreads();
-        }
-        const int di = BWD_NT / N, dj = BWD_NT - di * N;
-        for (int s = 0; s < (a.comp_mode ? 0 : BWD_TS); ++s) {
-            const bool live = b0 + s < a.B;       // uniform over the workgroup
-            // sum mode: one pass with the gradient of the summed matrix feeding every channel;
-            // component mode: one pass per channel with that channel's own gradient matrix
-            const int npass = a.comp_mode ? R : 1;
-            for (int pass = 0; pass < npass; ++pass) {
-                if (live) {
-                    const float* grow = a.comp_mode ? gout + ((long)(b0 + s) * R + pass) * D : gout + (long)(b0 + s) * D;
-                    float* garow = ga ? ga + (long)(b0 + s) * D : nullptr;
-                    int i = t / N, j = t - i * N;
-                    for (int e = t; e < D; e += BWD_NT) {
-                        float g = grow[e];
-                        if (!a.comp_mode) {
-                            float sum = 0.0f;
-                            for (int r = 0; r < R; ++r) {
-                                float gi = ACTS(r, NL - 1, s, i), gj = ACTS(r, NL - 1, s, j);
-                                if (drop) {
-                                    gi *= drop[((long)r * a.B + b0 + s) * N + i];
-                                    gj *= drop[((long)r * a.B + b0 + s) * N + j];
-                                }
-                                sum += gi * gj;
-                            }
-                            const float av = act_apply(a.epi_act, sum);
-                            if (a.do_exp) {
-                                float o = av;
-                                if (a.has_icpt) o = o * wd[e] + bi[e];
-                                g *= expf(o);
-                            }
-                            if (a.has_icpt) {
-                                if (garow) garow[e] = g * av;
-                                g *= wd[e];
-                            }
-                            g *= act_slope(a.epi_act, av);
-                        }
-                        dA[i * lda + j] = g;
-                        i += di;
-                        j += dj;
-                        if (j >= N) { j -= N; ++i; }
-                    }
-                }
-                __syncthreads();
-                if (live) {
-                    // dgr[i] = sum_j (dA[i][j] + dA[j][i]) * g_r[j]; two threads per row, j split in halves
-                    const int i = t & 127, half = t >> 7;
-                    float acc[MAXR];
-#pragma unroll
-                    for (int r = 0; r < MAXR; ++r) acc[r] = 0.0f;
-                    const int r_lo = a.comp_mode ? pass : 0, r_hi = a.comp_mode ? pass + 1 : R;
-                    if (i < N) {
-                        const int jh = (N + 1) / 2;
-                        const int j0 = half * jh, j1 = (half == 0) ? jh : N;
-                        for (int j = j0; j < j1; ++j) {
-                            const float v = dA[i * lda + j] + dA[j * lda + i];
-#pragma unroll
-                            for (int r = 0; r < MAXR; ++r)
-                                if (r >= r_lo && r < r_hi) {
-                                    float gj = ACTS(r, NL - 1, s, j);
-                                    if (drop) gj *= drop[((long)r * a.B + b0 + s) * N + j];
-                                    acc[r] += v * gj;
-                                }
-                        }
-                    }
-                    // combine the two halves through dpb (free at this point)
-                    if (half == 1 && i < N)
-                        for (int r = r_lo; r < r_hi; ++r) dpb[r * 128 + i] = acc[r];
-                    __syncthreads();
-                    if (half == 0 && i < N) {
-                        for (int r = r_lo; r < r_hi; ++r) {
-                            float v = acc[r] + dpb[r * 128 + i];
-                            if (gxlat && r < a.xlat_r) v += gxlat[(long)(b0 + s) * N + i];
-                            if (drop) v *= drop[((long)r * a.B + b0 + s) * N + i];
-                            dg[(r * BWD_TS + s) * NP + i] = v;
-                        }
-                    }
-                } else if (pass == 0) {
-                    for (int i = t; i < R * NP; i += BWD_NT) dg[((i / NP) * BWD_TS + s) * NP + (i % NP)] = 0.0f;
-                }
-                __syncthreads();
-            }
-        }
-        // ---- phase 3: walk each chain backwards
-        float dzacc[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int r = 0; r < R; ++r) {
-            float dh[4];
-            if (t < 2 * NP) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) dh[i] = (n < N) ? dg[(r * BWD_TS + sg * 4 + i) * NP + n] : 0.0f;
+                dh[j] = v;
             }
             for (int l = NL - 1; l >= 0; --l) {
                 const int act = layer_act(a.acts, l);
                 const long row0 = ((long)(r * NL + l) * a.B + b0);
-                if (t < 2 * NP) {
+                const float* hl = acts + l * KP * CH_LD;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int s = sg * 4 + i;
-                        const float h = ACTS(r, l, s, n);
-                        const float v = (n < N) ? dh[i] * act_slope(act, h) : 0.0f;
-                        dpb[s * NP + n] = v;
-                        if (b0 + s < a.B) dp[(row0 + s) * NP + n] = v;
-                    }
+                for (int j = 0; j < 16; ++j) {
+                    const int s = acc_row(j, lane);
+                    const float v = (n < N) ? dh[j] * act_slope(act, hl[n * CH_LD + s]) : 0.0f;
+                    dpb[n * CH_LD + s] = v;
+                    if (b0 + s < a.B) dp[(row0 + s) * NP + n] = v;
                 }
                 // the layer's input rows (with the ones column that yields the bias gradient)
-                for (int i = t; i < BWD_TS * KP; i += BWD_NT) {
+                const float* src = (l == 0) ? zt : acts + (l - 1) * KP * CH_LD;
+                for (int i = t; i < CH_TS * KP; i += CH_NT) {
                     const int s = i / KP, k = i - s * KP;
-                    if (b0 + s < a.B) {
-                        float v;
-                        if (l == 0) v = zt[i];
-                        else v = (k == KP - 1) ? 1.0f : ACTS(r, l - 1, s, k);   // KP == NP
-                        hin[(row0 + s) * KP + k] = v;
-                    }
+                    if (b0 + s < a.B) hin[(row0 + s) * KP + k] = src[k * CH_LD + s];
                 }
-                {
-                    const float4* src = reinterpret_cast<const float4*>(wn + ((long)(r * NL + l) * NP) * KP);
-                    for (int i = t; i < NP * KP / 4; i += BWD_NT) reinterpret_cast<float4*>(wl)[i] = src[i];
-                }
+                stage_panel(wn + ((long)(r * NL + l) * NP) * KP, wl);
                 __syncthreads();
-                // dh_prev[s][k] = sum_n dpb[s][n] * W[k][n]  (Wn[n][k], conflict-free over k)
-                if (t < 2 * NP) {
-                    const int k = n;
-                    const int K = (l == 0) ? L : N;
-                    const float* w = wl;
-                    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-                    if (k < K) {
-#pragma unroll 4
-                        for (int nn = 0; nn < N; ++nn) {
-                            const float wv = w[nn * KP + k];
+                // dh_prev[s][k] = sum_n dpre[s][n] * Wn[n][k]
+                const f32x16 acc = panel_product(dpb, wl, wave * 32, lane);
+                if (l == 0) {
 #pragma unroll
-                            for (int i = 0; i < 4; ++i) acc[i] += wv * dpb[(sg * 4 + i) * NP + nn];
-                        }
-                    }
-                    if (l == 0) {
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) dzacc[i] += acc[i];
-                    } else {
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) dh[i] = acc[i];
-                    }
+                    for (int j = 0; j < 16; ++j) dzacc[j] += acc[j];
+                } else {
+                    dh = acc;
                 }
                 __syncthreads();
             }
         }
-        if (t < 2 * NP && n < L) {
+        if (n < a.L) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int s = sg * 4 + i;
-                if (b0 + s < a.B) dz[(long)(b0 + s) * L + n] = dzacc[i];
+            for (int j = 0; j < 16; ++j) {
+                const int s = acc_row(j, lane);
+                if (b0 + s < a.B) dz[(long)(b0 + s) * a.L + n] = dzacc[j];
             }
         }
     }
-#undef ACTS
 }
 
 // column sums over the batch: out0[e] = sum_b a[b][e], out1[e] = sum_b c[b][e]  (fixed order)
@@ -586,11 +549,13 @@ static int check_dec(const char* fn, int B, int N, int L, int R, int NL) {
     return 0;
 }
 
-static size_t bwd_lds_bytes(int N, int R, int NL) {
-    const int lda = (N & 1) ? N + 2 : N + 1;
-    size_t fl = (size_t)R * NL * BWD_TS * NP + BWD_TS * KP + (size_t)R * BWD_TS * NP + DPB_FLOATS + (size_t)KP * NP +
-                (size_t)N * lda;
-    return fl * sizeof(float);
+static size_t chain_bwd_lds_bytes(int NL) {
+    return sizeof(float) * ((size_t)KP * NP + (size_t)KP * CH_LD + (size_t)NP * CH_LD + (size_t)NL * KP * CH_LD);
+}
+
+static unsigned wave_grid(long items) {          // one wave per item, four waves per workgroup
+    const long blocks = (items + 3) / 4;
+    return (unsigned)(blocks < 1 ? 1 : (blocks > 8192 ? 8192 : blocks));
 }
 
 }  // namespace mdnvae
@@ -654,12 +619,16 @@ int mdnvae_decoder_fwd(const float* z, const float* wt, int B, int N, int L, int
     MV_REQUIRE(xlat_channels >= 0 && xlat_channels <= R, E_ARG, "mdnvae_decoder_fwd: xlat_channels %d", xlat_channels);
     MV_REQUIRE(!components || (!icpt_w && !do_exp && epi_act == 0), E_ARG,
                "mdnvae_decoder_fwd: component output takes no epilogue");
+    MV_REQUIRE(nodes, E_ARG, "mdnvae_decoder_fwd: nodes [B,R,%d] is required", NP);
+    MV_REQUIRE(!xlat_channels || xlat, E_ARG, "mdnvae_decoder_fwd: xlat is null");
     DecArgs a{B, N, L, R, NL, acts, epi_act, icpt_w != nullptr, do_exp, xlat_channels, components};
-    const int ntiles = (B + FWD_TS - 1) / FWD_TS;
-    const int grid = ntiles < 2048 ? ntiles : 2048;
-    hipLaunchKernelGGL(chain_decoder_fwd_kernel, dim3(grid), dim3(FWD_NT), 0, (hipStream_t)stream, a, z, wt, icpt_w,
-                       icpt_b, drop, out, xlat_channels ? xlat : nullptr, nodes);
-    MV_LAUNCH_CHECK("chain_decoder_fwd_kernel");
+    const int ntiles = (B + CH_TS - 1) / CH_TS;
+    hipLaunchKernelGGL(chain_fwd_mfma_kernel, dim3(ntiles < 2048 ? ntiles : 2048), dim3(CH_NT), 0, (hipStream_t)stream,
+                       a, z, wt, drop, nodes, xlat_channels ? xlat : nullptr);
+    MV_LAUNCH_CHECK("chain_fwd_mfma_kernel");
+    hipLaunchKernelGGL(outer_epilogue_kernel, dim3(wave_grid(components ? (long)B * R : B)), dim3(256), 0,
+                       (hipStream_t)stream, a, nodes, icpt_w, icpt_b, (unsigned)(0x100000000ull / (unsigned)N) + 1u, out);
+    MV_LAUNCH_CHECK("outer_epilogue_kernel");
     return 0;
 }
 
@@ -677,30 +646,31 @@ int mdnvae_decoder_bwd(const float* z, const float* wt, const float* wn, int B, 
     MV_REQUIRE(!icpt_w || grad_times_act, E_ARG, "mdnvae_decoder_bwd: intercept gradient needs grad_times_act");
     MV_REQUIRE(!components || (!icpt_w && !do_exp && epi_act == 0), E_ARG,
                "mdnvae_decoder_bwd: component output takes no epilogue");
-    MV_REQUIRE(!components || (nodes && node_grad), E_ARG,
-               "mdnvae_decoder_bwd: component mode needs the forward's node vectors and a node_grad workspace");
+    MV_REQUIRE(nodes && node_grad, E_ARG,
+               "mdnvae_decoder_bwd: needs the forward's node vectors and a node_grad workspace, [B,R,%d] each", NP);
     DecArgs a{B, N, L, R, NL, acts, epi_act, icpt_w != nullptr, do_exp, xlat_channels, components};
-    const size_t lds = bwd_lds_bytes(N, R, NL);
+    const size_t lds = chain_bwd_lds_bytes(NL);
     MV_REQUIRE(lds <= 160 * 1024, E_SHAPE, "mdnvae_decoder_bwd: needs %zu bytes of LDS", lds);
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(chain_decoder_bwd_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(chain_bwd_mfma_kernel),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        MV_REQUIRE(e == hipSuccess, (int)e, "mdnvae_decoder_bwd: cannot raise the LDS limit: %s", hipGetErrorString(e));
         attr_set = true;
     }
+    hipStream_t st = (hipStream_t)stream;
     if (components) {
-        const long pairs = (long)B * R;
-        const unsigned og_grid = (unsigned)((pairs + 3) / 4 < 4096 ? (pairs + 3) / 4 : 4096);
-        hipLaunchKernelGGL(comp_outer_grad_kernel, dim3(og_grid), dim3(256), 0, (hipStream_t)stream, grad_out, nodes,
-                           drop, B, R, N, node_grad);
-        MV_LAUNCH_CHECK("comp_outer_grad_kernel");
+        hipLaunchKernelGGL(outer_grad_kernel<true>, dim3(wave_grid((long)B * R)), dim3(256), 0, st, a, grad_out, nodes,
+                           icpt_w, icpt_b, drop, grad_times_act, node_grad);
+    } else {
+        hipLaunchKernelGGL(outer_grad_kernel<false>, dim3(wave_grid(B)), dim3(256), 0, st, a, grad_out, nodes, icpt_w,
+                           icpt_b, drop, grad_times_act, node_grad);
     }
-    const int ntiles = (B + BWD_TS - 1) / BWD_TS;
-    const int grid = ntiles < 1024 ? ntiles : 1024;
-    hipLaunchKernelGGL(chain_decoder_bwd_kernel, dim3(grid), dim3(BWD_NT), lds, (hipStream_t)stream, a, z, wt, wn,
-                       icpt_w, icpt_b, drop, grad_out, xlat_channels ? grad_xlat : nullptr, grad_z, layer_in,
-                       layer_dpre, grad_times_act, node_grad);
-    MV_LAUNCH_CHECK("chain_decoder_bwd_kernel");
+    MV_LAUNCH_CHECK("outer_grad_kernel");
+    const int ntiles = (B + CH_TS - 1) / CH_TS;
+    hipLaunchKernelGGL(chain_bwd_mfma_kernel, dim3(ntiles < 2048 ? ntiles : 2048), dim3(CH_NT), lds, st, a, z, wt, wn,
+                       drop, node_grad, xlat_channels ? grad_xlat : nullptr, grad_z, layer_in, layer_dpre);
+    MV_LAUNCH_CHECK("chain_bwd_mfma_kernel");
     return 0;
 }
 

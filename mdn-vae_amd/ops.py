@@ -139,7 +139,8 @@ class _LinearAct(torch.autograd.Function):
         else:
             gpre = gy
         gx = torch.mm(gpre, weight) if ctx.needs_input_grad[0] else None
-        gw = torch.mm(gpre.t(), x) if ctx.needs_input_grad[1] else None
+        # [K,B].[B,H] then a transposed view: the library runs this layout ~20% faster than gpre^T . x
+        gw = torch.mm(x.t(), gpre).t() if ctx.needs_input_grad[1] else None
         gb = _colsum(gpre) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         return gx, gw, gb, None
 
@@ -280,7 +281,7 @@ class _ChainDecoder(torch.autograd.Function):
         D = spec.N * spec.N
         out = torch.empty((B, spec.R, D) if spec.components else (B, D), dtype=torch.float32, device=dev)
         xlat = torch.empty(B, spec.N, dtype=torch.float32, device=dev) if spec.xlat_channels else None
-        nodes = torch.empty(B, spec.R, DEC_NP, dtype=torch.float32, device=dev) if spec.components else None
+        nodes = torch.empty(B, spec.R, DEC_NP, dtype=torch.float32, device=dev)
         call("mdnvae_decoder_fwd", ptr(z, "z"), ptr(wt), B, spec.N, spec.L, spec.R, spec.NL, spec.acts, spec.epi_act,
              ptr(icpt_w, "icpt_w"), ptr(icpt_b, "icpt_b"), int(spec.do_exp), ptr(drop, "drop"), spec.xlat_channels,
              int(spec.components), ptr(out), ptr(xlat), ptr(nodes), stream())
@@ -308,7 +309,7 @@ class _ChainDecoder(torch.autograd.Function):
         dp = torch.empty(RL, B, DEC_NP, dtype=torch.float32, device=dev)
         gz = torch.empty_like(z)
         ga = torch.empty_like(gout) if icpt_w is not None else None
-        node_grad = torch.empty_like(nodes) if nodes is not None else None
+        node_grad = torch.empty_like(nodes)
         call("mdnvae_decoder_bwd", ptr(z), ptr(wt), ptr(wn), B, spec.N, spec.L, spec.R, spec.NL, spec.acts,
              spec.epi_act, ptr(icpt_w), ptr(icpt_b), int(spec.do_exp), ptr(drop), spec.xlat_channels,
              int(spec.components), ptr(gout),
