@@ -59,8 +59,19 @@ def allreduce_sum(flat, group=None, bucket_floats=8 << 20):
         w.wait()
 
 
+def _distributed(group=None):
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+
+
 class Trainer:
-    def __init__(self, model, loss_mode, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, group=None, fused_loss=True):
+    """`overlap_floats`: with more than one rank, a parameter of at least this many elements has
+    its gradient all-reduced from a post-accumulate hook, i.e. as soon as backward has produced it,
+    so the transfer of the large encoder matrices runs under the rest of the backward pass (every
+    rank runs the same graph, so the hooks fire in the same order everywhere).  The remaining
+    ranges of the flat gradient buffer are reduced in buckets after backward."""
+
+    def __init__(self, model, loss_mode, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, group=None, fused_loss=True,
+                 overlap_floats=1 << 20):
         self.model, self.loss_mode, self.group = model, loss_mode, group
         self.lr, self.betas, self.eps = lr, betas, eps
         self.buf = FlatBuffers(model)
@@ -68,6 +79,34 @@ class Trainer:
         self.exp_avg_sq = torch.zeros_like(self.buf.flat_p)
         self.steps = 0
         self.fused_loss = fused_loss
+        self._pending = []          # async all-reduces launched from hooks during backward
+        self._rest = [(0, self.buf.numel)]   # flat ranges still to be reduced after backward
+        if _distributed(group) and overlap_floats:
+            self._install_overlap_hooks(overlap_floats)
+
+    def _install_overlap_hooks(self, min_floats):
+        early = []
+        for p, o in zip(self.buf.params, self.buf.offsets):
+            if p.numel() >= min_floats:
+                early.append((o, o + p.numel()))
+                p.register_post_accumulate_grad_hook(self._make_hook(o, p.numel()))
+        rest, pos = [], 0
+        for lo, hi in sorted(early):
+            if lo > pos:
+                rest.append((pos, lo))
+            pos = hi
+        if pos < self.buf.numel:
+            rest.append((pos, self.buf.numel))
+        self._rest = rest
+
+    def _make_hook(self, offset, numel):
+        def hook(param):
+            flat = self.buf.flat_g[offset:offset + numel]
+            if param.grad.data_ptr() != flat.data_ptr():      # autograd replaced the view: copy back
+                flat.copy_(param.grad.reshape(-1))
+                param.grad = flat.view(param.shape)
+            self._pending.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        return hook
 
     def forward_backward(self, inputs, target, eps=None):
         """inputs: positional arguments of model.forward; returns the detached loss (0-dim).
@@ -91,7 +130,11 @@ class Trainer:
         return loss.detach()
 
     def optimizer_step(self):
-        allreduce_sum(self.buf.flat_g, self.group)
+        for lo, hi in self._rest:
+            allreduce_sum(self.buf.flat_g[lo:hi], self.group)
+        for w in self._pending:
+            w.wait()
+        self._pending.clear()
         self.steps += 1
         call("mdnvae_adam_step", ptr(self.buf.flat_p), ptr(self.buf.flat_g), ptr(self.exp_avg), ptr(self.exp_avg_sq),
              self.buf.numel, self.steps, float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps),

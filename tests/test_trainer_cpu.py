@@ -113,3 +113,37 @@ def test_two_rank_feature_stats_allreduce():
         assert n == 10
         assert torch.allclose(s, xc.sum(0), rtol=1e-14)
         assert torch.allclose(g, xc.T @ xc, rtol=1e-14)
+
+
+def _overlap_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(3)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 40), torch.nn.Tanh(), torch.nn.Linear(40, 2))
+    tr = M.Trainer(net, "mse", overlap_floats=200)         # the 6x40 weight goes through the hook path
+    assert tr._rest != [(0, tr.buf.numel)]
+    x = torch.arange(8 * 6, dtype=torch.float32).reshape(8, 6) / 10.0
+    lo, hi = M.data.shard_range(8, rank, world)
+    tr.buf.zero_grad()
+    (net(x[lo:hi]) ** 2).sum().backward()
+    assert len(tr._pending) == 1
+    for a, b in tr._rest:
+        M.allreduce_sum(tr.buf.flat_g[a:b])
+    for w in tr._pending:
+        w.wait()
+    out[rank] = tr.buf.flat_g.clone()
+    dist.destroy_process_group()
+
+
+def test_two_rank_overlapped_allreduce_equals_single_process_gradient():
+    world = 2
+    out = mp.Manager().dict()
+    mp.spawn(_overlap_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    torch.manual_seed(3)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 40), torch.nn.Tanh(), torch.nn.Linear(40, 2))
+    buf = M.FlatBuffers(net)
+    x = torch.arange(8 * 6, dtype=torch.float32).reshape(8, 6) / 10.0
+    (net(x) ** 2).sum().backward()
+    for r in range(world):
+        assert torch.allclose(out[r], buf.flat_g, rtol=1e-6, atol=1e-7)
