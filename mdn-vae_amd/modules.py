@@ -118,7 +118,8 @@ def _dev_int(a, device):
 # conv-encoder VAE family
 # ---------------------------------------------------------------------------------------
 class ConvVAE(nn.Module):
-    """Conv/ResNet encoder + five-branch rank-1 decoder.
+    """Conv/ResNet encoder (or, with encoder='fnn', the two-tower FNN encoder of
+    function_FC/MM_Gate_test.py) + five-branch rank-1 decoder.
 
     decoder:  'nn'   plain second layers                          (VAE_CNN_NN scripts)
               'gcn'  GraphCNN second layers + diagonal intercept  (VAE-CNN-GCN scripts)
@@ -126,26 +127,38 @@ class ConvVAE(nn.Module):
     """
 
     def __init__(self, decoder="nn", intercept="dense", final="exp", dropout=0.0, n_nodes=68, latent_dim=68,
-                 act="sigmoid"):
+                 act="sigmoid", encoder="conv"):
         super().__init__()
         self.n_nodes, self.latent_dim = n_nodes, latent_dim
         self.decoder_kind, self.intercept_kind, self.final, self.act = decoder, intercept, final, act
-        init_depth = 48
-        ch = init_depth * 4
-        ec = [(1, nn.Conv2d(1, init_depth, 7)), (4, nn.Conv2d(init_depth, init_depth * 2, 3, stride=2, padding=1)),
-              (7, nn.Conv2d(init_depth * 2, ch, 3, stride=2, padding=1))]
-        ec += [(10 + i, _ResBlockParams(ch)) for i in range(5)]
-        self.ec = _Slots(ec)
-        self.n_res = 5
-        s = (n_nodes + 1) // 2
-        s = (s + 1) // 2
-        pooled = s // 8
-        if pooled < 1:
-            raise ValueError(f"n_nodes={n_nodes} is too small for the 8x8 max pool")
-        flat = ch * pooled * pooled
-        self.fc_mean = Linear(flat, latent_dim)
-        self.fc_log_var = Linear(flat, latent_dim)
+        self.encoder_kind = encoder
         N = n_nodes
+        if encoder == "fnn":
+            # two ReLU towers D->1024->128->L (function_FC/MM_Gate_test.py:87-92,104-109)
+            self.fc11 = Linear(N * N, 1024)
+            self.fc12 = Linear(N * N, 1024)
+            self.fc111 = Linear(1024, 128)
+            self.fc222 = Linear(1024, 128)
+            self.fc21 = Linear(128, latent_dim)
+            self.fc22 = Linear(128, latent_dim)
+        elif encoder == "conv":
+            init_depth = 48
+            ch = init_depth * 4
+            ec = [(1, nn.Conv2d(1, init_depth, 7)), (4, nn.Conv2d(init_depth, init_depth * 2, 3, stride=2, padding=1)),
+                  (7, nn.Conv2d(init_depth * 2, ch, 3, stride=2, padding=1))]
+            ec += [(10 + i, _ResBlockParams(ch)) for i in range(5)]
+            self.ec = _Slots(ec)
+            self.n_res = 5
+            s = (n_nodes + 1) // 2
+            s = (s + 1) // 2
+            pooled = s // 8
+            if pooled < 1:
+                raise ValueError(f"n_nodes={n_nodes} is too small for the 8x8 max pool")
+            flat = ch * pooled * pooled
+            self.fc_mean = Linear(flat, latent_dim)
+            self.fc_log_var = Linear(flat, latent_dim)
+        else:
+            raise ValueError(f"unknown encoder {encoder!r}")
         for name in ("fc3", "fc32", "fc33", "fc34", "fc35"):
             setattr(self, name, Linear(latent_dim, N))
         second = GraphCNN if decoder == "gcn" else Linear
@@ -167,8 +180,12 @@ class ConvVAE(nn.Module):
         return p
 
     def encode(self, x):
-        feat = ops.conv_encoder(x.reshape(-1, self.n_nodes * self.n_nodes), self.n_nodes,
-                                [(m.weight, m.bias) for m in self.conv_params()])
+        x = x.reshape(-1, self.n_nodes * self.n_nodes)
+        if self.encoder_kind == "fnn":
+            h11 = self.fc111(self.fc11(x, act="relu"), act="relu")
+            h12 = self.fc222(self.fc12(x, act="relu"), act="relu")
+            return self.fc21(h11), self.fc22(h12)
+        feat = ops.conv_encoder(x, self.n_nodes, [(m.weight, m.bias) for m in self.conv_params()])
         return self.fc_mean(feat), self.fc_log_var(feat)
 
     def reparameterize(self, mu, logvar, eps=None):

@@ -264,6 +264,7 @@ VARIANTS = {
     "cnn_gcn_sc": ("conv", dict(intercept="diag", final="none"), "poisson_log"),      # function/VAE-CNN-GCN.py
     "cnn_gcn_fc": ("conv", dict(intercept="diag", final="none"), "mse"),              # function_FC/VAE_CNN_GCN.py
     "cnn_nn_fc": ("conv", dict(intercept="none", final="none"), "mse"),               # function_FC/VAE_CNN_NN.py (eval)
+    "fnn_gcn_fc": ("fnn", dict(intercept="diag", final="none", act=torch.tanh), "mse"),   # function_FC/MM_Gate_test.py
 }
 
 
@@ -273,7 +274,7 @@ def vae_forward(variant, p, x, eps, mask=None, adjacency=None, n_nodes=68):
         z = reparameterize(mu, logvar, eps)
         return gcn_decode(p, z, adjacency), mu, logvar, z, None
     enc, dkw, _ = VARIANTS[variant]
-    mu, logvar = conv_encode(p, x, n_nodes)
+    mu, logvar = fnn_encode(p, x) if enc == "fnn" else conv_encode(p, x, n_nodes)
     z = reparameterize(mu, logvar, eps)
     recon, x_latent = rank1_decode(p, z, mask=mask, n_nodes=n_nodes, **dkw)
     return recon, mu, logvar, z, x_latent

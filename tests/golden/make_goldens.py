@@ -128,7 +128,7 @@ def conv_vae_fixture(tag, relpath, x, masks=None, eval_mode=False):
     if masks is not None:
         model.set_mask([torch.from_numpy(np.float32(m)) for m in masks])
     xt = torch.from_numpy(x)
-    L = model.fc_mean.out_features
+    L = (model.fc_mean if hasattr(model, "fc_mean") else model.fc21).out_features
     eps = draw_eps(EPS_SEED, (x.shape[0], L))
     recon, mu, logvar, x_latent = run_with_eps(model, (xt,), EPS_SEED)
     loss = ns["loss_function"](recon, xt, mu, logvar)
@@ -192,6 +192,14 @@ def make_cnn_gcn_fc():
 def make_cnn_nn_fc():
     x, _ = fc_inputs()
     conv_vae_fixture("cnn_nn_fc", "function_FC/VAE_CNN_NN.py", x[:B], eval_mode=True)
+
+
+def make_fnn_gcn_fc():
+    """function_FC/MM_Gate_test.py: FNN towers + tanh masked decoder + identity-masked intercept."""
+    x, A_mat = fc_inputs()
+    m = rank_mask(A_mat)
+    conv_vae_fixture("fnn_gcn_fc", "function_FC/MM_Gate_test.py", x[:B],
+                     masks=[m] * 5 + [np.identity(68 * 68)])
 
 
 def make_mm_gate():
@@ -356,7 +364,7 @@ def make_prep():
 
 
 ALL = dict(cnn_nn_sc=make_cnn_nn_sc, cnn_gcn_sc=make_cnn_gcn_sc, cnn_gcn_fc=make_cnn_gcn_fc,
-           cnn_nn_fc=make_cnn_nn_fc, mm_gate=make_mm_gate, cvae=make_cvae, ec87=make_ec87,
+           cnn_nn_fc=make_cnn_nn_fc, mm_gate=make_mm_gate, fnn_gcn_fc=make_fnn_gcn_fc, cvae=make_cvae, ec87=make_ec87,
            losses=make_losses, fid=make_fid, prep=make_prep)
 
 if __name__ == "__main__":

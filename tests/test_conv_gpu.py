@@ -163,6 +163,8 @@ VARIANT_CTOR = {
     "cnn_gcn_sc": dict(decoder="gcn", intercept="diag", final="none"),
     "cnn_gcn_fc": dict(decoder="gcn", intercept="diag", final="none"),
     "cnn_nn_fc": dict(decoder="nn", intercept="none", final="none", dropout=0.5),
+    # function_FC/MM_Gate_test.py: FNN towers, tanh masked decoder, identity-masked intercept
+    "fnn_gcn_fc": dict(encoder="fnn", decoder="gcn", intercept="diag", final="none", act="tanh"),
 }
 
 

@@ -44,7 +44,7 @@ def _check_grads(fix, params, skip_noise=True):
         recipe.check_grad(fix, name, p.grad, GRAD_RTOL, "oracle")
 
 
-@pytest.mark.parametrize("variant", ["cnn_nn_sc", "cnn_gcn_sc", "cnn_gcn_fc", "cnn_nn_fc"])
+@pytest.mark.parametrize("variant", ["cnn_nn_sc", "cnn_gcn_sc", "cnn_gcn_fc", "cnn_nn_fc", "fnn_gcn_fc"])
 def test_conv_vae_variants(variant):
     fix = load_fixture(variant)
     p = _leaf(fixture_params(fix))
