@@ -128,7 +128,9 @@ typedef float f32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
 #define MV_GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 #define MV_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 
-template <int CK, int SI>
+// TAPS > 0: tap count known at compile time (loop unrolled); PLAIN: the input is used as it stands
+// (no normalisation / ReLU on load), which leaves the tap loop free of branches
+template <int CK, int SI, int TAPS, bool PLAIN>
 __global__ __launch_bounds__(256, (SI > 8 ? 2 : 3)) void conv_mfma_kernel(ConvGeom g, const float* __restrict__ x,
                                                             const float* __restrict__ stats,
                                                             const float* __restrict__ wp,
@@ -165,7 +167,7 @@ __global__ __launch_bounds__(256, (SI > 8 ? 2 : 3)) void conv_mfma_kernel(ConvGe
     const int seg1 = two ? (fdiv(pe1, g.m_sw) * g.S + g.KHe) * g.IWp : 0;
     const int slab_elems = seg0 + seg1;                   // <= slab_stride; also the channel stride
     const int in_plane = g.H * g.W;
-    const bool norm = stats != nullptr;
+    const bool norm = !PLAIN && stats != nullptr;
 
     // Wave w stages channel c0 + w of every chunk; lane l owns slab positions l, l+64, ...  Their
     // source offsets (relative to channel 0 of sample s0; -1 = padding, -2 = past the slab) are the
@@ -265,7 +267,8 @@ __global__ __launch_bounds__(256, (SI > 8 ? 2 : 3)) void conv_mfma_kernel(ConvGe
                     rstd[m][cp] = st[(lane_seg[m] * CK + 2 * cp + h) * 2 + 1];
                 }
         }
-        for (int t = 0; t < g.ntaps; ++t) {
+#pragma unroll
+        for (int t = 0; t < (TAPS > 0 ? TAPS : g.ntaps); ++t) {
             const float* sl = slab + g.tap_off[t];
             const float* wr = wl + (t * CK + h) * NTILE + l32;
             float A[CP][WM], Bv[CP][WN];
@@ -276,7 +279,8 @@ __global__ __launch_bounds__(256, (SI > 8 ? 2 : 3)) void conv_mfma_kernel(ConvGe
 #pragma unroll
                 for (int n = 0; n < WN; ++n) Bv[cp][n] = wr[cp * 2 * NTILE + n * 32];
             }
-            if (norm) {
+            if (PLAIN) {
+            } else if (norm) {
 #pragma unroll
                 for (int cp = 0; cp < CP; ++cp)
 #pragma unroll
@@ -813,15 +817,15 @@ static void finish_geom(ConvGeom& g, int KWe) {
     g.m_sw = magic_of(g.SW);
 }
 
-template <int CK, int SI>
+template <int CK, int SI, int TAPS, bool PLAIN>
 static void launch_conv_t(const ConvGeom& g, size_t lds, const float* x, const float* stats, const float* wp,
                           const float* bias, float* out, hipStream_t st) {
     constexpr int PT = 256, NTILE = 96;
     static bool once = false;
-    if (!once) { set_attr_once(reinterpret_cast<const void*>(conv_mfma_kernel<CK, SI>)); once = true; }
+    if (!once) { set_attr_once(reinterpret_cast<const void*>(conv_mfma_kernel<CK, SI, TAPS, PLAIN>)); once = true; }
     const long Q = (long)g.B * g.SH * g.SW;
     dim3 grid((unsigned)((Q + PT - 1) / PT), g.CoutP / NTILE, 1);
-    hipLaunchKernelGGL((conv_mfma_kernel<CK, SI>), grid, dim3(256), lds, st, g, x, stats, wp, bias, out);
+    hipLaunchKernelGGL((conv_mfma_kernel<CK, SI, TAPS, PLAIN>), grid, dim3(256), lds, st, g, x, stats, wp, bias, out);
 }
 
 // One grid over all (sample, grid pixel) rows of the launch.
@@ -841,8 +845,17 @@ static int launch_conv(ConvGeom g, const float* x, const float* stats, const flo
     // 4 input channels per chunk keeps three workgroups resident per CU
     const size_t lds = ((size_t)2 * MAX_TAPS * 4 * 96 + (size_t)2 * 4 * g.slab_stride + 2 * 4 * 4) * 4;
     MV_REQUIRE(lds <= 160 * 1024, E_SHAPE, "mdnvae_conv2d: tile needs %zu bytes of LDS", lds);
-    if (g.slab_stride <= 7 * 64) launch_conv_t<4, 7>(g, lds, x, stats, wp, bias, out, st);
-    else launch_conv_t<4, 24>(g, lds, x, stats, wp, bias, out, st);
+    const bool plain = stats == nullptr && !g.relu_in;
+    if (g.slab_stride <= 7 * 64) {
+        if (g.ntaps == 9 && plain) launch_conv_t<4, 7, 9, true>(g, lds, x, stats, wp, bias, out, st);
+        else if (g.ntaps == 9) launch_conv_t<4, 7, 9, false>(g, lds, x, stats, wp, bias, out, st);
+        else if (plain) launch_conv_t<4, 7, 0, true>(g, lds, x, stats, wp, bias, out, st);
+        else launch_conv_t<4, 7, 0, false>(g, lds, x, stats, wp, bias, out, st);
+    } else if (plain) {
+        launch_conv_t<4, 24, 0, true>(g, lds, x, stats, wp, bias, out, st);
+    } else {
+        launch_conv_t<4, 24, 0, false>(g, lds, x, stats, wp, bias, out, st);
+    }
     MV_LAUNCH_CHECK("conv_mfma_kernel");
     return 0;
 }
