@@ -657,6 +657,142 @@ __global__ __launch_bounds__(WG_NT, 2) void conv_wgrad_kernel(ConvGeom g, const 
     }
 }
 
+// Weight gradient of the 3x3 / stride 1 / reflect-pad-1 convolutions (the ten residual-block convs,
+// function/VAE_CNN_NN.py:86-93) with "flat" staging: the input rows a chunk needs are one contiguous
+// run of the plane, and so is the chunk of every grad_out row, so both tiles are copied by 16-byte
+// LDS-DMA from 16-byte aligned source addresses (a quarter of the DMA instructions of the 4-byte
+// gather).  Nothing is padded in LDS: the reflected row / column of a border pixel is resolved in the
+// B operand's address (three row offsets + three column offsets per K step).  A plane whose size is
+// not a multiple of 4 floats starts at a 4-byte phase that differs per channel; the phase is added to
+// the lane's base address.
+template <int DUMMY>
+__global__ __launch_bounds__(WG_NT, 2) void conv_wgrad_flat_kernel(int B, int Cin, int Cout, int H, int W,
+                                                                   const float* __restrict__ x,
+                                                                   const float* __restrict__ gout, int nr, int GS,
+                                                                   int SS, int samples_per_group,
+                                                                   float* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int KKT = 9;
+    const int gbuf = 64 * GS, sbuf = 64 * SS;        // GS, SS are multiples of 4
+    float* gl0 = smem;                               // [2][64][GS]
+    float* slab0 = smem + 2 * gbuf;                  // [2][64][SS]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, l32 = lane & 31;
+    const int wn = wave >> 1, wc = wave & 1;
+    const int n0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+    const int P = H * W;
+    const int b_begin = blockIdx.z * samples_per_group;
+    const int b_end = min(B, b_begin + samples_per_group);
+    const int npc = (H + nr - 1) / nr;               // chunks per plane
+    const int nchunks = (b_end - b_begin) * npc;
+    const unsigned m_g4 = magic_of(GS >> 2), m_s4 = magic_of(SS >> 2), m_w = magic_of(W);
+
+    f32x16 acc[KKT];
+#pragma unroll
+    for (int t = 0; t < KKT; ++t)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[t][j] = 0.0f;
+    // lanes of a channel / output row that does not exist read row 0 (their products are discarded)
+    const int crow = (c0 + wc * 32 + l32 < Cin) ? wc * 32 + l32 : 0;
+    const int nrow = (n0 + wn * 32 + l32 < Cout) ? wn * 32 + l32 : 0;
+
+    auto issue = [&](int ci) {                       // DMA of chunk ci into buffer ci & 1
+        if (ci >= nchunks) return;
+        const int b = b_begin + ci / npc, j = ci % npc;
+        const int a0 = j * nr, nrows = min(nr, H - a0);
+        const int p0 = a0 * W, count = nrows * W;
+        float* gdst = gl0 + (ci & 1) * gbuf;
+        for (int base = 0; base < (gbuf >> 2); base += WG_NT) {
+            const int i4 = base + tid;
+            if (i4 < (gbuf >> 2)) {
+                const int n = fdiv(i4, m_g4), q = i4 - n * (GS >> 2);
+                const long src = ((long)b * Cout + n0 + n) * P + p0;          // first float of the row's chunk
+                const int ph = (int)(src & 3);
+                if (n0 + n < Cout && 4 * q < ph + count)
+                    __builtin_amdgcn_global_load_lds(MV_GLOBAL_PTR(gout + (src - ph) + 4 * q),
+                                                     MV_LDS_PTR(gdst + (base + wave * 64) * 4), 16, 0, 0);
+            }
+        }
+        const int r_lo = max(a0 - 1, 0), r_hi = min(a0 + nrows, H - 1);
+        const int span = (r_hi - r_lo + 1) * W;
+        float* sdst = slab0 + (ci & 1) * sbuf;
+        for (int base = 0; base < (sbuf >> 2); base += WG_NT) {
+            const int i4 = base + tid;
+            if (i4 < (sbuf >> 2)) {
+                const int c = fdiv(i4, m_s4), q = i4 - c * (SS >> 2);
+                const long src = ((long)b * Cin + c0 + c) * P + r_lo * W;
+                const int ph = (int)(src & 3);
+                if (c0 + c < Cin && 4 * q < ph + span)
+                    __builtin_amdgcn_global_load_lds(MV_GLOBAL_PTR(x + (src - ph) + 4 * q),
+                                                     MV_LDS_PTR(sdst + (base + wave * 64) * 4), 16, 0, 0);
+            }
+        }
+    };
+
+    issue(0);
+    for (int ci = 0; ci < nchunks; ++ci) {
+        __syncthreads();            // chunk ci has landed (the barrier drains the DMA); the other buffers are free
+        issue(ci + 1);
+        const int b = b_begin + ci / npc, j = ci % npc;
+        const int a0 = j * nr, nrows = min(nr, H - a0);
+        const int p0 = a0 * W, count = nrows * W;
+        const int r_lo = max(a0 - 1, 0);
+        const int phA = (int)((((long)b * Cout + n0 + nrow) * P + p0) & 3);
+        const int phB = (int)((((long)b * Cin + c0 + crow) * P + r_lo * W) & 3);
+        const float* ga = gl0 + (ci & 1) * gbuf + nrow * GS + phA + h;
+        const float* sb = slab0 + (ci & 1) * sbuf + crow * SS + phB - r_lo * W;   // sb[iy*W + ix]
+        const int npairs = (count + 1) >> 1;
+        // grid pixel p0 + 2k + h walks the chunk two pixels per step
+        int oy = a0 + fdiv(min(h, count - 1), m_w), ox = min(h, count - 1) - (oy - a0) * W;
+        float av0, bv0[KKT], av1, bv1[KKT];
+        // load_k only issues LDS reads (nothing consumes them), so the wait for step k+1's operands
+        // lands after step k's MFMAs have been issued
+        auto load_k = [&](int k, float& av, float (&bv)[KKT]) {
+            av = ga[2 * k];
+            const int oyc = min(oy, a0 + nrows - 1);                 // a step past the chunk's end re-reads its last row
+            const int y0 = (oyc == 0 ? 1 : oyc - 1) * W, y1 = oyc * W, y2 = (oyc == H - 1 ? H - 2 : oyc + 1) * W;
+            const int x0 = (ox == 0 ? 1 : ox - 1), x2 = (ox == W - 1 ? W - 2 : ox + 1);
+            bv[0] = sb[y0 + x0]; bv[1] = sb[y0 + ox]; bv[2] = sb[y0 + x2];
+            bv[3] = sb[y1 + x0]; bv[4] = sb[y1 + ox]; bv[5] = sb[y1 + x2];
+            bv[6] = sb[y2 + x0]; bv[7] = sb[y2 + ox]; bv[8] = sb[y2 + x2];
+            ox += 2;
+            if (ox >= W) {
+                ox -= W;
+                ++oy;
+            }
+        };
+        auto mma_k = [&](int k, float av, float (&bv)[KKT]) {
+            av = (2 * k + h < count) ? av : 0.0f;          // past the end of the chunk: zero gradient
+            if (2 * k + h >= count) {
+#pragma unroll
+                for (int t = 0; t < KKT; ++t) bv[t] = 0.0f;    // (whatever was read there may be NaN)
+            }
+#pragma unroll
+            for (int t = 0; t < KKT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[t], acc[t], 0, 0, 0);
+        };
+        load_k(0, av0, bv0);
+        for (int k = 0; k < npairs; k += 2) {
+            if (k + 1 < npairs) load_k(k + 1, av1, bv1);
+            mma_k(k, av0, bv0);
+            if (k + 1 < npairs) {
+                if (k + 2 < npairs) load_k(k + 2, av0, bv0);
+                mma_k(k + 1, av1, bv1);
+            }
+        }
+    }
+    // partial[z][tap][n][c]
+    float* dst = partial + (long)blockIdx.z * KKT * Cout * Cin;
+    const int c = c0 + wc * 32 + l32;
+    if (c < Cin) {
+#pragma unroll
+        for (int t = 0; t < KKT; ++t)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int n = n0 + wn * 32 + (j & 3) + 8 * (j >> 2) + 4 * h;
+                if (n < Cout) dst[((long)t * Cout + n) * Cin + c] = acc[t][j];
+            }
+    }
+}
+
 // dW[n][c][tap] = sum_z partial[z][tap][n][c]
 __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __restrict__ partial, int G, int KK,
                                                                 int Cout, int Cin, float* __restrict__ dw) {
@@ -1036,6 +1172,32 @@ int mdnvae_conv2d_wgrad(const float* x, const float* in_stats, int relu_in, cons
         MV_LAUNCH_CHECK("sum_partials_kernel");
         return 0;
     }
+    const int ntiles = ((Cout + 63) / 64) * ((Cin + 63) / 64);
+    const int Gz0 = wgrad_groups(B, ntiles);
+    const int spg = (B + Gz0 - 1) / Gz0, Gz = (B + spg - 1) / spg;
+    const long total = (long)KK * Cout * Cin;
+    if (KS == 3 && stride == 1 && pad == 1 && reflect && !in_stats && !relu_in && H >= 3 && W >= 3 && W <= 64) {
+        // flat 16-byte staging: whole grid rows per chunk, as many as leave room for two workgroups per CU
+        int nr = 0, GS = 0, SS = 0;
+        size_t lds = 0;
+        for (int k = 1; k <= H && k * W <= 128; ++k) {
+            const int gs = (k * W + 3 + 3) & ~3, ss = ((k + 2) * W + 3 + 3) & ~3;
+            const size_t need = ((size_t)2 * 64 * gs + (size_t)2 * 64 * ss) * 4;
+            if (need <= 80 * 1024) { nr = k; GS = gs; SS = ss; lds = need; }
+        }
+        if (nr > 0) {
+            static bool once_flat = false;
+            if (!once_flat) { set_attr_once(reinterpret_cast<const void*>(conv_wgrad_flat_kernel<0>)); once_flat = true; }
+            dim3 grid((Cout + 63) / 64, (Cin + 63) / 64, Gz);
+            hipLaunchKernelGGL(conv_wgrad_flat_kernel<0>, grid, dim3(WG_NT), lds, st, B, Cin, Cout, H, W, x, grad_out, nr,
+                               GS, SS, spg, workspace);
+            MV_LAUNCH_CHECK("conv_wgrad_flat_kernel");
+            hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+                               workspace, Gz, KK, Cout, Cin, grad_w);
+            MV_LAUNCH_CHECK("conv_wgrad_reduce_kernel");
+            return 0;
+        }
+    }
     // pixel chunk = whole grid rows (so every chunk of a plane has the same slab shape); the
     // largest one whose double-buffered tiles leave room for two workgroups per CU, else for one
     const int cslab = Cin < 64 ? Cin : 64;
@@ -1060,9 +1222,6 @@ int mdnvae_conv2d_wgrad(const float* x, const float* in_stats, int relu_in, cons
     g.slab_stride = (((rows_touched(ptw, OW, OH) - 1) * stride + KS) * g.IWp) | 1;   // odd: conflict-free B reads
     MV_REQUIRE(g.slab_stride <= 8 * 64, E_SHAPE, "mdnvae_conv2d_wgrad: slab of %d floats per channel is too large",
                g.slab_stride);
-    const int ntiles = ((Cout + 63) / 64) * ((Cin + 63) / 64);
-    const int Gz0 = wgrad_groups(B, ntiles);
-    const int spg = (B + Gz0 - 1) / Gz0, Gz = (B + spg - 1) / spg;
     static bool once = false;
     if (!once) {
         set_attr_once(reinterpret_cast<const void*>(conv_wgrad_kernel<false>));
@@ -1077,7 +1236,6 @@ int mdnvae_conv2d_wgrad(const float* x, const float* in_stats, int relu_in, cons
         hipLaunchKernelGGL(conv_wgrad_kernel<false>, grid, dim3(WG_NT), best_lds, st, g, x, in_stats, grad_out, ptw,
                            cslab, spg, workspace);
     MV_LAUNCH_CHECK("conv_wgrad_kernel");
-    const long total = (long)KK * Cout * Cin;
     hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, workspace, Gz,
                        KK, Cout, Cin, grad_w);
     MV_LAUNCH_CHECK("conv_wgrad_reduce_kernel");
