@@ -245,7 +245,8 @@ def kernel_table(clock, elapsed):
     return kernels
 
 
-def run_workload(model_name, batch, nodes, steps, warmup, pool_batches, device, rank, world, use_clock):
+def run_workload(model_name, batch, nodes, steps, warmup, pool_batches, device, rank, world, use_clock,
+                 overlap=True):
     """Warm up, then time exactly `steps` steps between barrier + synchronize pairs; returns
     (elapsed seconds: max over ranks, final loss, kernel clock, workload description)."""
     model, mode, kind = build(model_name, nodes, device)
@@ -260,7 +261,7 @@ def run_workload(model_name, batch, nodes, steps, warmup, pool_batches, device, 
         extra_inputs = (knn_adjacency_from(gen(256, nodes, seed=1234, device=device), nodes),)
     if model_name == "mdn_gate":
         extra_inputs += (torch.randn(batch, 4, device=device, generator=torch.Generator(device=device).manual_seed(7)),)
-    trainer = M.Trainer(model, mode)
+    trainer = M.Trainer(model, mode) if overlap else M.Trainer(model, mode, overlap_floats=0)
     eps_gen = torch.Generator(device=device).manual_seed(99 + rank)
 
     def one_step(i):
@@ -305,6 +306,10 @@ def main():
     ap.add_argument("--pool", type=int, default=2, help="resident synthetic batches per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-clock", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true", help="all-reduce every gradient after backward")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL).  gloo on device tensors "
+                                                      "hung in this image when two ranks shared one GPU, so the "
+                                                      "multi-rank path is rehearsed on the CPU by tests/test_trainer_cpu.py")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -312,15 +317,21 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N > 1")
+    if args.backend != "nccl":
+        local_rank %= torch.cuda.device_count()          # rehearsal: ranks may share a GPU
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=device)
+        else:
+            dist.init_process_group(backend=args.backend)
 
     batch = args.batch or default_batch(args.model)
     elapsed, final_loss, clock, what = run_workload(args.model, batch, args.nodes, args.steps, args.warmup, args.pool,
-                                                    device, rank, world, not args.no_kernel_clock)
+                                                    device, rank, world, not args.no_kernel_clock,
+                                                    not args.no_overlap)
     if rank == 0:
         line = {
             "metric": "train samples/sec (fwd+bwd, 87x87 connectome)" if args.nodes == 87 else
