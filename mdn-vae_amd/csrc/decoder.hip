@@ -173,48 +173,78 @@ __device__ __forceinline__ void load_latent_tile(const float* __restrict__ z, in
     }
 }
 
+// The next layer's panel is fetched into registers before the current layer's MFMA loop and written
+// to the other LDS panel buffer after it, so its global-memory latency hides under the MFMAs and a
+// layer costs one barrier.
+constexpr int PANEL_Q = KP * NP / 4 / CH_NT;     // float4 per thread per panel
+static_assert(PANEL_Q * CH_NT * 4 == KP * NP, "the panel must divide evenly over the workgroup");
+
+__device__ __forceinline__ void panel_fetch(const float* __restrict__ src, float4 (&pre)[PANEL_Q]) {
+    const float4* s4 = reinterpret_cast<const float4*>(src);
+#pragma unroll
+    for (int i = 0; i < PANEL_Q; ++i) pre[i] = s4[i * CH_NT + threadIdx.x];
+}
+__device__ __forceinline__ void panel_commit(const float4 (&pre)[PANEL_Q], float* __restrict__ wl) {
+#pragma unroll
+    for (int i = 0; i < PANEL_Q; ++i) reinterpret_cast<float4*>(wl)[i * CH_NT + threadIdx.x] = pre[i];
+}
+
 __global__ __launch_bounds__(CH_NT) void chain_fwd_mfma_kernel(DecArgs a, const float* __restrict__ z,
                                                                const float* __restrict__ wt,
                                                                const float* __restrict__ drop,
                                                                float* __restrict__ nodes, float* __restrict__ xlat) {
-    __shared__ float abuf[2][KP * CH_LD];
-    __shared__ __attribute__((aligned(16))) float wl[KP * NP];
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* wl0 = smem;                                  // [2][KP][NP]
+    float* abuf0 = smem + 2 * KP * NP;                  // [2][KP][CH_LD]
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int n = wave * 32 + (lane & 31);
     const int N = a.N;
     const int ntiles = (a.B + CH_TS - 1) / CH_TS;
+    const int S = a.R * a.NL;                           // layer steps per tile
+    if ((int)blockIdx.x >= ntiles) return;
+    float4 pre[PANEL_Q];
+    panel_fetch(wt, pre);
+    panel_commit(pre, wl0);
+    int cur = 0;
+    load_latent_tile(z, blockIdx.x * CH_TS, a.B, a.L, abuf0);
+    __syncthreads();
+    long g = 0;                                         // layer steps done by this workgroup
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int b0 = tile * CH_TS;
         float xl[16];
 #pragma unroll
         for (int j = 0; j < 16; ++j) xl[j] = 0.0f;
         for (int r = 0; r < a.R; ++r) {
-            load_latent_tile(z, b0, a.B, a.L, abuf[0]);      // every reader of abuf has passed a barrier
-            int cur = 0;
-            for (int l = 0; l < a.NL; ++l) {
-                stage_panel(wt + ((long)(r * a.NL + l) * KP) * NP, wl);
-                __syncthreads();
-                const f32x16 acc = panel_product(abuf[cur], wl, wave * 32, lane);
+            for (int l = 0; l < a.NL; ++l, ++g) {
+                const int s = r * a.NL + l;
+                const bool last_step = s == S - 1;
+                const bool more = !last_step || tile + (int)gridDim.x < ntiles;
+                if (more) panel_fetch(wt + ((long)((s + 1) % S) * KP) * NP, pre);
+                const f32x16 acc = panel_product(abuf0 + cur * KP * CH_LD, wl0 + (g & 1) * KP * NP, wave * 32, lane);
                 const int act = layer_act(a.acts, l);
+                float* nxt = abuf0 + (cur ^ 1) * KP * CH_LD;
                 if (l == a.NL - 1) {
 #pragma unroll
                     for (int j = 0; j < 16; ++j) {
-                        const int s = acc_row(j, lane);
-                        if (b0 + s < a.B) {
+                        const int sr = acc_row(j, lane);
+                        if (b0 + sr < a.B) {
                             float v = (n < N) ? act_apply(act, acc[j]) : 0.0f;
-                            if (drop && n < N) v *= drop[((long)r * a.B + b0 + s) * N + n];
-                            nodes[((long)(b0 + s) * a.R + r) * NP + n] = v;
+                            if (drop && n < N) v *= drop[((long)r * a.B + b0 + sr) * N + n];
+                            nodes[((long)(b0 + sr) * a.R + r) * NP + n] = v;
                             if (r < a.xlat_r) xl[j] += v;
                         }
                     }
+                    // the buffer this layer would have written is free: it takes the next chain's input
+                    if (more) load_latent_tile(z, (last_step ? tile + (int)gridDim.x : tile) * CH_TS, a.B, a.L, nxt);
                 } else {
 #pragma unroll
                     for (int j = 0; j < 16; ++j) {
                         float v = (n < N) ? act_apply(act, acc[j]) : 0.0f;
                         if (n == KP - 1) v = 1.0f;
-                        abuf[cur ^ 1][n * CH_LD + acc_row(j, lane)] = v;
+                        nxt[n * CH_LD + acc_row(j, lane)] = v;
                     }
                 }
+                if (more) panel_commit(pre, wl0 + ((g + 1) & 1) * KP * NP);
                 __syncthreads();
                 cur ^= 1;
             }
@@ -222,8 +252,8 @@ __global__ __launch_bounds__(CH_NT) void chain_fwd_mfma_kernel(DecArgs a, const 
         if (xlat && n < N) {
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
-                const int s = acc_row(j, lane);
-                if (b0 + s < a.B) xlat[(long)(b0 + s) * N + n] = xl[j];
+                const int sr = acc_row(j, lane);
+                if (b0 + sr < a.B) xlat[(long)(b0 + sr) * N + n] = xl[j];
             }
         }
     }
@@ -413,27 +443,40 @@ __global__ __launch_bounds__(CH_NT) void chain_bwd_mfma_kernel(DecArgs a, const 
                                                                const float* __restrict__ gxlat, float* __restrict__ dz,
                                                                float* __restrict__ hin, float* __restrict__ dp) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* wl = smem;                                   // [KP][NP]
-    float* zt = wl + KP * NP;                           // [KP][CH_LD]
+    float* wl0 = smem;                                  // [2][KP][NP] panel double buffer
+    float* zt = wl0 + 2 * KP * NP;                      // [KP][CH_LD]
     float* dpb = zt + KP * CH_LD;                       // [NP][CH_LD]
     float* acts = dpb + NP * CH_LD;                     // [NL][KP][CH_LD]
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int n = wave * 32 + (lane & 31);
     const int N = a.N, R = a.R, NL = a.NL;
     const int ntiles = (a.B + CH_TS - 1) / CH_TS;
+    if ((int)blockIdx.x >= ntiles) return;
+    const int S = R * 2 * NL;                           // panel steps per tile
+    // step q of a tile: channel q / 2NL; first NL steps recompute layers 0..NL-1 (panels Wt),
+    // the next NL walk layers NL-1..0 backwards (panels Wn)
+    auto panel_of = [&](int q) {
+        const int r = q / (2 * NL), i = q - r * 2 * NL;
+        return i < NL ? wt + ((long)(r * NL + i) * KP) * NP : wn + ((long)(r * NL + (2 * NL - 1 - i)) * NP) * KP;
+    };
+    float4 pre[PANEL_Q];
+    panel_fetch(panel_of(0), pre);
+    panel_commit(pre, wl0);
+    load_latent_tile(z, blockIdx.x * CH_TS, a.B, a.L, zt);
+    __syncthreads();
+    long g = 0;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int b0 = tile * CH_TS;
-        __syncthreads();
-        load_latent_tile(z, b0, a.B, a.L, zt);
+        const bool more_tiles = tile + (int)gridDim.x < ntiles;
         f32x16 dzacc;
 #pragma unroll
         for (int j = 0; j < 16; ++j) dzacc[j] = 0.0f;
         for (int r = 0; r < R; ++r) {
             // recompute the chain of channel r
-            for (int l = 0; l < NL; ++l) {
-                stage_panel(wt + ((long)(r * NL + l) * KP) * NP, wl);
-                __syncthreads();
-                const f32x16 acc = panel_product(l == 0 ? zt : acts + (l - 1) * KP * CH_LD, wl, wave * 32, lane);
+            for (int l = 0; l < NL; ++l, ++g) {
+                panel_fetch(panel_of(r * 2 * NL + l + 1), pre);          // a backward step always follows
+                const f32x16 acc = panel_product(l == 0 ? zt : acts + (l - 1) * KP * CH_LD, wl0 + (g & 1) * KP * NP,
+                                                 wave * 32, lane);
                 const int act = layer_act(a.acts, l);
                 float* dst = acts + l * KP * CH_LD;
 #pragma unroll
@@ -442,6 +485,7 @@ __global__ __launch_bounds__(CH_NT) void chain_bwd_mfma_kernel(DecArgs a, const 
                     if (n == KP - 1) v = 1.0f;
                     dst[n * CH_LD + acc_row(j, lane)] = v;
                 }
+                panel_commit(pre, wl0 + ((g + 1) & 1) * KP * NP);
                 __syncthreads();
             }
             // gradient w.r.t. the final node vector (dropout already applied to dnode)
@@ -460,7 +504,10 @@ __global__ __launch_bounds__(CH_NT) void chain_bwd_mfma_kernel(DecArgs a, const 
                 }
                 dh[j] = v;
             }
-            for (int l = NL - 1; l >= 0; --l) {
+            for (int l = NL - 1; l >= 0; --l, ++g) {
+                const int q = r * 2 * NL + (2 * NL - 1 - l);
+                const bool more = q + 1 < S || more_tiles;
+                if (more) panel_fetch(panel_of((q + 1) % S), pre);
                 const int act = layer_act(a.acts, l);
                 const long row0 = ((long)(r * NL + l) * a.B + b0);
                 const float* hl = acts + l * KP * CH_LD;
@@ -477,16 +524,17 @@ __global__ __launch_bounds__(CH_NT) void chain_bwd_mfma_kernel(DecArgs a, const 
                     const int s = i / KP, k = i - s * KP;
                     if (b0 + s < a.B) hin[(row0 + s) * KP + k] = src[k * CH_LD + s];
                 }
-                stage_panel(wn + ((long)(r * NL + l) * NP) * KP, wl);
                 __syncthreads();
                 // dh_prev[s][k] = sum_n dpre[s][n] * Wn[n][k]
-                const f32x16 acc = panel_product(dpb, wl, wave * 32, lane);
+                const f32x16 acc = panel_product(dpb, wl0 + (g & 1) * KP * NP, wave * 32, lane);
                 if (l == 0) {
 #pragma unroll
                     for (int j = 0; j < 16; ++j) dzacc[j] += acc[j];
                 } else {
                     dh = acc;
                 }
+                if (more) panel_commit(pre, wl0 + ((g + 1) & 1) * KP * NP);
+                if (q == S - 1 && more_tiles) load_latent_tile(z, (tile + (int)gridDim.x) * CH_TS, a.B, a.L, zt);
                 __syncthreads();
             }
         }
@@ -550,7 +598,7 @@ static int check_dec(const char* fn, int B, int N, int L, int R, int NL) {
 }
 
 static size_t chain_bwd_lds_bytes(int NL) {
-    return sizeof(float) * ((size_t)KP * NP + (size_t)KP * CH_LD + (size_t)NP * CH_LD + (size_t)NL * KP * CH_LD);
+    return sizeof(float) * ((size_t)2 * KP * NP + (size_t)KP * CH_LD + (size_t)NP * CH_LD + (size_t)NL * KP * CH_LD);
 }
 
 static unsigned wave_grid(long items) {          // one wave per item, four waves per workgroup
@@ -623,8 +671,16 @@ int mdnvae_decoder_fwd(const float* z, const float* wt, int B, int N, int L, int
     MV_REQUIRE(!xlat_channels || xlat, E_ARG, "mdnvae_decoder_fwd: xlat is null");
     DecArgs a{B, N, L, R, NL, acts, epi_act, icpt_w != nullptr, do_exp, xlat_channels, components};
     const int ntiles = (B + CH_TS - 1) / CH_TS;
-    hipLaunchKernelGGL(chain_fwd_mfma_kernel, dim3(ntiles < 2048 ? ntiles : 2048), dim3(CH_NT), 0, (hipStream_t)stream,
-                       a, z, wt, drop, nodes, xlat_channels ? xlat : nullptr);
+    const size_t fwd_lds = sizeof(float) * ((size_t)2 * KP * NP + (size_t)2 * KP * CH_LD);
+    static bool fwd_attr_set = false;
+    if (!fwd_attr_set) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(chain_fwd_mfma_kernel),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        MV_REQUIRE(e == hipSuccess, (int)e, "mdnvae_decoder_fwd: cannot raise the LDS limit: %s", hipGetErrorString(e));
+        fwd_attr_set = true;
+    }
+    hipLaunchKernelGGL(chain_fwd_mfma_kernel, dim3(ntiles < 2048 ? ntiles : 2048), dim3(CH_NT), fwd_lds,
+                       (hipStream_t)stream, a, z, wt, drop, nodes, xlat_channels ? xlat : nullptr);
     MV_LAUNCH_CHECK("chain_fwd_mfma_kernel");
     hipLaunchKernelGGL(outer_epilogue_kernel, dim3(wave_grid(components ? (long)B * R : B)), dim3(256), 0,
                        (hipStream_t)stream, a, nodes, icpt_w, icpt_b, (unsigned)(0x100000000ull / (unsigned)N) + 1u, out);
