@@ -114,6 +114,12 @@ def _colsum(a):
     return out
 
 
+def _library_gemm(a, b):
+    """Plain dense product of the nn.Linear layers: a rocBLAS/hipBLASLt GEMM (one call site, so a
+    benchmark can time it)."""
+    return torch.mm(a, b)
+
+
 class _LinearAct(torch.autograd.Function):
     """act(x @ W^T + b): the product is a rocBLAS GEMM, bias+activation and the backward's
     elementwise / column-sum parts are HIP kernels."""
@@ -122,7 +128,7 @@ class _LinearAct(torch.autograd.Function):
     def forward(ctx, x, weight, bias, act):
         x, weight = _c(x), _c(weight)
         ptr(x, "x"), ptr(weight, "weight")
-        y = torch.mm(x, weight.t())
+        y = _library_gemm(x, weight.t())
         call("mdnvae_bias_act", ptr(y), ptr(bias, "bias"), y.shape[0], y.shape[1], act, stream())
         ctx.save_for_backward(x, weight, y)
         ctx.act = act
@@ -138,9 +144,9 @@ class _LinearAct(torch.autograd.Function):
             call("mdnvae_act_bwd", ptr(y), ptr(gy), ptr(gpre), gy.numel(), ctx.act, stream())
         else:
             gpre = gy
-        gx = torch.mm(gpre, weight) if ctx.needs_input_grad[0] else None
+        gx = _library_gemm(gpre, weight) if ctx.needs_input_grad[0] else None
         # [K,B].[B,H] then a transposed view: the library runs this layout ~20% faster than gpre^T . x
-        gw = torch.mm(x.t(), gpre).t() if ctx.needs_input_grad[1] else None
+        gw = _library_gemm(x.t(), gpre).t() if ctx.needs_input_grad[1] else None
         gb = _colsum(gpre) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         return gx, gw, gb, None
 
