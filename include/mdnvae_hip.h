@@ -253,6 +253,16 @@ int mdnvae_div_clamp(const float* x, const float* denom, int clamp, float lo, lo
 /* out[r] = mean over cols of (a[r][c]-b[r][c])^2. */
 int mdnvae_row_mse(const float* a, const float* b, long rows, int cols, float* out, void* stream);
 
+/* ---- connectome preparation ---------------------------------------------------------------------
+ * Per subject: m = raw + raw^T, diagonal := column means, crop [crop_lo, crop_hi)^2, scale, flatten.
+ * function/VAE_CNN_NN.py:32-39 (DIVIDE by offset), function_FC/VAE_CNN_GCN.py:35-43 (UNIT: (x+1)/2),
+ * function/Full_NN.py:106-112 (LOG1P), function_fc_new/ResNet.py:17-19,33-41 (FISHER z);
+ * RAW: crop only (the group-mean matrix of function/VAE_CNN_NN.py:21 averages raw crops).
+ * raw [B,n,n] -> out [B,(crop_hi-crop_lo)^2]. */
+enum { MDNVAE_PREP_DIVIDE = 0, MDNVAE_PREP_UNIT = 1, MDNVAE_PREP_LOG1P = 2, MDNVAE_PREP_FISHER = 3, MDNVAE_PREP_RAW = 4 };
+int mdnvae_prep_connectome(const float* raw, long B, int n, int crop_lo, int crop_hi, int mode, float offset,
+                           float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

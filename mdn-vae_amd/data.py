@@ -6,17 +6,74 @@ optional crop [18:86], / 200  (function/VAE_CNN_NN.py:33-38).
 FC-like: correlation matrices of a rank-8 factor model, then (x + x^T with the diagonal rule,
 crop) mapped to [0,1] by (x+1)/2  (function_FC/VAE_CNN_GCN.py:35-41).
 """
+import numpy as np
 import torch
 
+from . import _lib
 
-def _prepare(t, crop, n_nodes):
-    t = t + t.transpose(1, 2)
-    col_mean = t.mean(dim=1)                        # np.mean(ith, 0): column means
-    idx = torch.arange(t.shape[1], device=t.device)
-    t[:, idx, idx] = col_mean
-    if crop:
-        t = t[:, 18:86, 18:86]
-    return t.reshape(t.shape[0], -1)
+PREP_MODES = {"divide": 0, "unit": 1, "log1p": 2, "fisher": 3, "raw": 4}
+CORTICAL_CROP = (18, 86)       # the 68 cortical Desikan regions of the 87-region matrices
+
+
+def prepare_connectomes(raw, mode, crop=CORTICAL_CROP, offset=200.0):
+    """raw [B, n, n] fp32 on the device -> prepared rows [B, w*w] (w = crop width, or n).
+
+    Per subject: raw + raw^T, diagonal := column means, crop, scale, flatten - the loops of
+    function/VAE_CNN_NN.py:32-39 ('divide': / offset), function_FC/VAE_CNN_GCN.py:35-43 ('unit':
+    (x+1)/2), function/Full_NN.py:106-112 ('log1p', crop=None), function_fc_new/ResNet.py:33-41
+    ('fisher'); 'raw' only crops."""
+    if raw.dim() != 3 or raw.shape[1] != raw.shape[2]:
+        raise ValueError(f"expected raw connectomes [B, n, n], got {tuple(raw.shape)}")
+    raw = raw.contiguous()
+    n = raw.shape[1]
+    lo, hi = (0, n) if crop is None else crop
+    out = torch.empty(raw.shape[0], (hi - lo) ** 2, dtype=torch.float32, device=raw.device)
+    _lib.call("mdnvae_prep_connectome", _lib.ptr(raw, "raw"), raw.shape[0], n, lo, hi, PREP_MODES[mode], float(offset),
+              _lib.ptr(out, "out"), _lib.stream())
+    return out
+
+
+def prepare_sc(raw, offset=200.0, crop=CORTICAL_CROP):
+    return prepare_connectomes(raw, "divide", crop, offset)
+
+
+def prepare_fc(raw, crop=CORTICAL_CROP):
+    return prepare_connectomes(raw, "unit", crop)
+
+
+def group_mean_matrix(raw, crop=CORTICAL_CROP, symmetrise=True):
+    """A_mat of the scripts: the mean over subjects of the cropped raw matrices, plus its transpose
+    for the SC scripts (function/VAE_CNN_NN.py:21-22; function_FC/VAE_CNN_GCN.py:31 has no
+    transpose).  Returned as float64 numpy, the form the mask / adjacency recipes take."""
+    from .ops import _colsum
+    rows = prepare_connectomes(raw, "raw", crop)
+    w = int(round(rows.shape[1] ** 0.5))
+    a = (_colsum(rows) / rows.shape[0]).reshape(w, w).double().cpu().numpy()
+    return a + a.T if symmetrise else a
+
+
+def rank_mask(a_mat, n_size=32):
+    """0/1 mask of the n_size+1 smallest entries of every row (function/VAE-CNN-GCN.py:209); host
+    side, like the reference (a 68x68 argsort done once)."""
+    a_mat = np.asarray(a_mat)
+    return torch.from_numpy(np.float32(np.argsort(np.argsort(a_mat, axis=-1), axis=-1) < n_size + 1))
+
+
+def knn_adjacency(a_mat, k=32):
+    """Per node: itself, then its k-1 strongest other neighbours (function/MM_Gate.py:55-65)."""
+    a_mat = np.asarray(a_mat)
+    adj = []
+    for u in range(a_mat.shape[0]):
+        desc = np.argsort(a_mat[u, :])[::-1][:k]
+        desc = desc[desc != u][: k - 1]
+        adj.append([u] + [int(v) for v in desc])
+    return adj
+
+
+def train_test_split(rows, train_fraction=0.8):
+    """First 80 % of the subjects train, the rest test (function/VAE_CNN_NN.py:43-48)."""
+    n_train = int(train_fraction * rows.shape[0])
+    return rows[:n_train], rows[n_train:]
 
 
 def synthetic_sc(n, n_nodes=87, seed=1234, device="cuda", offset=200.0):
@@ -26,10 +83,9 @@ def synthetic_sc(n, n_nodes=87, seed=1234, device="cuda", offset=200.0):
     shape = torch.full((n, raw_n, raw_n), 0.3, device=device)
     counts = torch.round(torch._standard_gamma(shape, generator=g) * 240.0)
     counts = torch.triu(counts, diagonal=1)
-    x = _prepare(counts, n_nodes == 68, n_nodes) / offset
     if n_nodes not in (68, 87):
         raise ValueError("n_nodes must be 87 (raw Desikan size) or 68 (cortical crop)")
-    return x.contiguous().float()
+    return prepare_sc(counts, offset, CORTICAL_CROP if n_nodes == 68 else None)
 
 
 def synthetic_fc(n, n_nodes=87, seed=1234, device="cuda"):
@@ -40,8 +96,7 @@ def synthetic_fc(n, n_nodes=87, seed=1234, device="cuda"):
     d = torch.rsqrt(torch.diagonal(c, dim1=1, dim2=2))
     c = c * d.unsqueeze(1) * d.unsqueeze(2)
     c = torch.triu(c, diagonal=1) * 0.5              # t + t^T then restores the off-diagonal value
-    x = (_prepare(c, n_nodes == 68, n_nodes) + 1.0) / 2.0
-    return x.contiguous().float()
+    return prepare_fc(c, CORTICAL_CROP if n_nodes == 68 else None)
 
 
 def shard_range(n, rank, world):

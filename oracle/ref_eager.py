@@ -49,6 +49,17 @@ def prepare_fc(raw: np.ndarray, crop=(18, 86)) -> np.ndarray:
     return ((symmetrise_fill_crop(raw, crop) + 1.0) / 2.0).flatten().astype(np.float32)
 
 
+def prepare_log(raw: np.ndarray) -> np.ndarray:
+    """function/Full_NN.py:106-112: full 87x87 matrix, log(x+1)."""
+    return np.log(symmetrise_fill_crop(raw, None).flatten() + 1).astype(np.float32)
+
+
+def prepare_fisher(raw: np.ndarray, crop=(18, 86), eps=1e-7) -> np.ndarray:
+    """function_fc_new/ResNet.py:17-19,33-41: Fisher z of the clipped correlations."""
+    r = np.clip(symmetrise_fill_crop(raw, crop), -1 + eps, 1 - eps)
+    return (0.5 * np.log((1 + r) / (1 - r))).flatten().astype(np.float32)
+
+
 def rank_mask(A_mat: np.ndarray, n_size: int = 32) -> np.ndarray:
     """function/VAE-CNN-GCN.py:209: ascending rank of each row entry < n_size+1."""
     order = np.argsort(A_mat, axis=-1)

@@ -355,12 +355,46 @@ def make_fid():
     save("fid", **out)
 
 
+def _run_reference_loop(relpath, names, inside=None):
+    """Executes, unmodified, the data-preparation `for` loop of a reference script (the first
+    top-level For statement, or the first one inside function `inside`) in the namespace `names`
+    (which provides `tensor`, `net_data = []` and whatever constants the loop reads)."""
+    tree = ast.parse(open(os.path.join(REF, relpath)).read())
+    body = tree.body
+    defs = [n for n in body if isinstance(n, ast.FunctionDef)]
+    if inside is not None:
+        body = [n for n in defs if n.name == inside][0].body
+    loop = [n for n in body if isinstance(n, ast.For)][0]
+    mod = ast.Module(body=[d for d in defs if d.name != inside] + [loop], type_ignores=[])
+    ns = dict(np=np, torch=torch, nn=nn, F=F, optim=optim, Variable=Variable)
+    ns.update(names)
+    exec(compile(mod, relpath, "exec"), ns)
+    return np.array(ns["net_data"], dtype=np.float32)
+
+
 def make_prep():
-    """Data preparation outputs (adjacency list, rank mask) for the real 100-subject sample."""
-    _, A_mat, _, _ = sc_inputs()
+    """Data preparation: adjacency list and rank mask for the real 100-subject sample, and the
+    reference's own preprocessing loops run on 4 subjects (raw inputs + the rows they produce)."""
+    _, A_mat, _, tensor = sc_inputs()
     ns = load_defs("function/MM_Gate.py")
     adjacency = np.array([list(map(int, a)) for a in ns["build_knn_adjacency"](A_mat, k=32)], dtype=np.int64)
-    save("prep", A_mat=A_mat, adjacency=adjacency, rank_mask=rank_mask(A_mat))
+    t4 = np.ascontiguousarray(tensor[:, :, :, :4]).astype(np.float64)
+    rows_sc = _run_reference_loop("function/VAE_CNN_NN.py", dict(tensor=t4, offset=200, net_data=[]))
+    rows_log = _run_reference_loop("function/Full_NN.py", dict(tensor=t4, net_data=[]))
+    rng = np.random.RandomState(7)
+    fc = []
+    for _ in range(4):                      # correlation-like matrices, as the (absent) FC file holds
+        u = rng.randn(87, 8)
+        c = u @ u.T + 0.5 * np.eye(87)
+        d = 1.0 / np.sqrt(np.diag(c))
+        fc.append(c * d[:, None] * d[None, :])
+    fc = np.stack(fc, axis=-1)
+    rows_fc = _run_reference_loop("function_FC/VAE_CNN_GCN.py", dict(tensor=fc, net_data=[]))
+    rows_fz = _run_reference_loop("function_fc_new/ResNet.py", dict(tensor=fc, net_data=[]), inside="load_data")
+    save("prep", A_mat=A_mat, adjacency=adjacency, rank_mask=rank_mask(A_mat),
+         raw_sc0=np.float32(np.moveaxis(t4[:, :, 0, :], -1, 0)), raw_sc1=np.float32(np.moveaxis(t4[:, :, 1, :], -1, 0)),
+         raw_fc=np.float32(np.moveaxis(fc, -1, 0)), rows_sc=rows_sc, rows_log=rows_log, rows_fc=rows_fc,
+         rows_fisher=rows_fz)
 
 
 ALL = dict(cnn_nn_sc=make_cnn_nn_sc, cnn_gcn_sc=make_cnn_gcn_sc, cnn_gcn_fc=make_cnn_gcn_fc,

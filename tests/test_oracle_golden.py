@@ -150,3 +150,17 @@ def test_prep_masks_and_adjacency():
     assert np.array_equal(R.rank_mask(fix["A_mat"]), fix["rank_mask"])
     assert np.array_equal(R.knn_adjacency(fix["A_mat"], 32), fix["adjacency"])
     assert (fix["rank_mask"].sum(axis=1) == 33).all()
+
+
+def test_preparation_loops_of_the_reference():
+    """The oracle's preparation against rows produced by the reference's own loops."""
+    fix = load_fixture("prep")
+    for i in range(4):
+        np.testing.assert_allclose(R.prepare_sc(fix["raw_sc0"][i].astype(np.float64) / 1.0), fix["rows_sc"][i],
+                                   rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(R.prepare_log(fix["raw_sc1"][i].astype(np.float64)), fix["rows_log"][i],
+                                   rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(R.prepare_fc(fix["raw_fc"][i].astype(np.float64)), fix["rows_fc"][i],
+                                   rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(R.prepare_fisher(fix["raw_fc"][i].astype(np.float64)), fix["rows_fisher"][i],
+                                   rtol=1e-3, atol=1e-3)
