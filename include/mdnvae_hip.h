@@ -263,6 +263,15 @@ enum { MDNVAE_PREP_DIVIDE = 0, MDNVAE_PREP_UNIT = 1, MDNVAE_PREP_LOG1P = 2, MDNV
 int mdnvae_prep_connectome(const float* raw, long B, int n, int crop_lo, int crop_hi, int mode, float offset,
                            float* out, void* stream);
 
+/* ---- batched evaluation metrics -----------------------------------------------------------------
+ * out [count,k] = the k largest eigenvalues, descending, of each symmetric n x n matrix (n <= 96):
+ * compute_spectral_features, function/VAE_CNN_NN.py:302-308, for symmetric input (the matrix is
+ * symmetrised as (A + A^T)/2 on load). */
+int mdnvae_spectrum_topk(const float* mats, long count, int n, int k, float* out, void* stream);
+/* out [count] = mean SSIM of each image pair: 7x7 uniform window, sample covariance, K1 0.01, K2 0.03
+ * (the skimage defaults behind compute_ssim_average, function/VAE_CNN_NN.py:291-297). */
+int mdnvae_ssim(const float* a, const float* b, long count, int n, float data_range, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

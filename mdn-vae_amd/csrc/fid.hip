@@ -63,6 +63,54 @@ __global__ __launch_bounds__(256) void gram_chunk_kernel(const float* __restrict
     }
 }
 
+// Small feature dimensions (the d = 5, 10, 30 of the scripts): the Gram matrix entirely in float64,
+// products included.  Their covariances are often degenerate, and float32 products would leave
+// eigenvalues of order -1e-7 that the square-root iteration cannot take.
+constexpr int G64_MAXD = 128;
+constexpr int G64_ROWS = 1024;    // rows per workgroup
+constexpr int G64_KT = 32;        // rows staged per LDS tile
+__global__ __launch_bounds__(256) void gram_f64_chunk_kernel(const float* __restrict__ x, const float* __restrict__ shift,
+                                                             long n, int d, double* __restrict__ partial) {
+    __shared__ double tile[G64_KT * G64_MAXD];
+    const long r0 = (long)blockIdx.x * G64_ROWS, r1 = min(n, r0 + G64_ROWS);
+    const int tid = threadIdx.x, npairs = d * d;
+    constexpr int PER = (G64_MAXD * G64_MAXD + 255) / 256;
+    double acc[PER];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) acc[u] = 0.0;
+    for (long rr = r0; rr < r1; rr += G64_KT) {
+        __syncthreads();
+        for (int idx = tid; idx < G64_KT * d; idx += 256) {
+            const int k = idx / d, c = idx - k * d;
+            tile[k * d + c] = (rr + k < r1) ? (double)x[(rr + k) * d + c] - (double)shift[c] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int pr = tid + u * 256;
+            if (pr < npairs) {
+                const int i = pr / d, j = pr - i * d;
+                double s = acc[u];
+                for (int k = 0; k < G64_KT; ++k) s += tile[k * d + i] * tile[k * d + j];
+                acc[u] = s;
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const int pr = tid + u * 256;
+        if (pr < npairs) partial[(long)blockIdx.x * npairs + pr] = acc[u];
+    }
+}
+__global__ __launch_bounds__(256) void gram_f64_reduce_kernel(const double* __restrict__ partial, int nchunks, int d,
+                                                              double* __restrict__ gram) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= d * d) return;
+    double s = 0.0;
+    for (int c = 0; c < nchunks; ++c) s += partial[(long)c * d * d + idx];
+    gram[idx] += s;
+}
+
 // gram[i][j] += sum_chunks partial (float64), mirrored below the diagonal
 __global__ __launch_bounds__(256) void gram_reduce_kernel(const float* __restrict__ partial, int nchunks, int d,
                                                           double* __restrict__ gram) {
@@ -77,15 +125,26 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(const float* __restric
     gram[idx] += s;
 }
 
-// sum[c] += sum_rows (x[row][c] - shift[c]) in float64, one thread per column, fixed order
-__global__ __launch_bounds__(256) void shifted_colsum_kernel(const float* __restrict__ x,
-                                                             const float* __restrict__ shift, long n, int d,
-                                                             double* __restrict__ sum) {
+// sum[c] += sum_rows (x[row][c] - shift[c]) in float64: per 1024-row chunk one partial per column
+// (thread = column, coalesced over columns), then the chunk partials are added in a fixed order
+constexpr int CS_ROWS = 1024;
+__global__ __launch_bounds__(256) void shifted_colsum_chunk_kernel(const float* __restrict__ x,
+                                                                   const float* __restrict__ shift, long n, int d,
+                                                                   double* __restrict__ partial) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= d) return;
+    const long r0 = (long)blockIdx.y * CS_ROWS, r1 = min(n, r0 + CS_ROWS);
+    double s = 0.0;
+    const float sh = shift[c];
+    for (long r = r0; r < r1; ++r) s += (double)(x[r * d + c] - sh);
+    partial[(long)blockIdx.y * d + c] = s;
+}
+__global__ __launch_bounds__(256) void shifted_colsum_reduce_kernel(const double* __restrict__ partial, int nchunks,
+                                                                    int d, double* __restrict__ sum) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= d) return;
     double s = 0.0;
-    const float sh = shift[c];
-    for (long r = 0; r < n; ++r) s += (double)(x[r * d + c] - sh);
+    for (int k = 0; k < nchunks; ++k) s += partial[(long)k * d + c];
     sum[c] += s;
 }
 
@@ -141,12 +200,35 @@ using namespace mdnvae;
 
 static unsigned grid_for(long n) { return (unsigned)((n + 255) / 256); }
 
+// column sums of x - shift over n rows, 64 chunks of 1024 rows per launch; `part` holds 64*d doubles
+static int launch_shifted_colsum(const float* x, const float* shift, long n, int d, double* part, double* sum,
+                                 hipStream_t st) {
+    const long rows_per_launch = 64L * CS_ROWS;
+    for (long r0 = 0; r0 < n; r0 += rows_per_launch) {
+        const long rows = (n - r0 < rows_per_launch) ? n - r0 : rows_per_launch;
+        const int nch = (int)((rows + CS_ROWS - 1) / CS_ROWS);
+        hipLaunchKernelGGL(shifted_colsum_chunk_kernel, dim3(grid_for(d), nch), dim3(256), 0, st, x + r0 * d, shift, rows,
+                           d, part);
+        MV_LAUNCH_CHECK("shifted_colsum_chunk_kernel");
+        hipLaunchKernelGGL(shifted_colsum_reduce_kernel, dim3(grid_for(d)), dim3(256), 0, st, part, nch, d, sum);
+        MV_LAUNCH_CHECK("shifted_colsum_reduce_kernel");
+    }
+    return 0;
+}
+
 extern "C" {
 
 size_t mdnvae_fid_gram_workspace_floats(long n, int d) {
+    const size_t colsum = (size_t)2 * 64 * d;        // 64 chunk partials per column, float64
+    if (d <= G64_MAXD) {                             // float64 partials, two floats each
+        const long nch = (n + G64_ROWS - 1) / G64_ROWS;
+        const size_t gram = (size_t)2 * (nch < 64 ? nch : 64) * d * d;
+        return gram > colsum ? gram : colsum;
+    }
     const long nch = (n + GR_ROWS - 1) / GR_ROWS;
     const long cap = nch < 64 ? nch : 64;            // chunks processed per launch
-    return (size_t)cap * d * d;
+    const size_t gram = (size_t)cap * d * d;
+    return gram > colsum ? gram : colsum;
 }
 
 int mdnvae_fid_accumulate(const float* x, const float* shift, long n, int d, float* workspace, double* sum,
@@ -156,6 +238,21 @@ int mdnvae_fid_accumulate(const float* x, const float* shift, long n, int d, flo
     if (n == 0) return 0;
     MV_REQUIRE(x && shift && workspace && sum && gram, E_ARG, "mdnvae_fid_accumulate: null pointer");
     hipStream_t st = (hipStream_t)stream;
+    if (d <= G64_MAXD) {
+        MV_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 7u) == 0, E_ALIGN,
+                   "mdnvae_fid_accumulate: workspace must be 8-byte aligned");
+        double* part = reinterpret_cast<double*>(workspace);
+        const long rows_per_launch = 64L * G64_ROWS;
+        for (long r0 = 0; r0 < n; r0 += rows_per_launch) {
+            const long rows = (n - r0 < rows_per_launch) ? n - r0 : rows_per_launch;
+            const int nch = (int)((rows + G64_ROWS - 1) / G64_ROWS);
+            hipLaunchKernelGGL(gram_f64_chunk_kernel, dim3(nch), dim3(256), 0, st, x + r0 * d, shift, rows, d, part);
+            MV_LAUNCH_CHECK("gram_f64_chunk_kernel");
+            hipLaunchKernelGGL(gram_f64_reduce_kernel, dim3(grid_for((long)d * d)), dim3(256), 0, st, part, nch, d, gram);
+            MV_LAUNCH_CHECK("gram_f64_reduce_kernel");
+        }
+        return launch_shifted_colsum(x, shift, n, d, part, sum, st);
+    }
     const int tiles = (d + 63) / 64;
     const long rows_per_launch = 64L * GR_ROWS;
     for (long r0 = 0; r0 < n; r0 += rows_per_launch) {
@@ -167,9 +264,9 @@ int mdnvae_fid_accumulate(const float* x, const float* shift, long n, int d, flo
         hipLaunchKernelGGL(gram_reduce_kernel, dim3(grid_for((long)d * d)), dim3(256), 0, st, workspace, nch, d, gram);
         MV_LAUNCH_CHECK("gram_reduce_kernel");
     }
-    hipLaunchKernelGGL(shifted_colsum_kernel, dim3(grid_for(d)), dim3(256), 0, st, x, shift, n, d, sum);
-    MV_LAUNCH_CHECK("shifted_colsum_kernel");
-    return 0;
+    MV_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 7u) == 0, E_ALIGN,
+               "mdnvae_fid_accumulate: workspace must be 8-byte aligned");
+    return launch_shifted_colsum(x, shift, n, d, reinterpret_cast<double*>(workspace), sum, st);
 }
 
 int mdnvae_fid_finalize(const double* gram, const double* sum, const float* shift, double n, int d, double* mean,

@@ -97,3 +97,60 @@ def compute_psnr(real, generated, max_value=1.0):
     """Average PSNR over the matrices with non-zero error (function/VAE_CNN_NN.py:281-286)."""
     v = [20 * math.log10(max_value) - 10 * math.log10(m) for m in matrix_mse(real, generated).tolist() if m > 0]
     return sum(v) / len(v) if v else float("nan")
+
+
+@torch.no_grad()
+def spectral_features(matrices, k=None, symmetry_tol=1e-4):
+    """The k largest eigenvalues of every matrix, descending: compute_spectral_features of
+    function/VAE_CNN_NN.py:302-308, batched on the device (Jacobi rotations in LDS).
+
+    matrices [count, n, n] or [count, n*n] must be symmetric (the scripts' real connectomes and the
+    outputs of the symmetrising decoders are); an asymmetric batch is refused rather than silently
+    given the spectrum of its symmetric part."""
+    m = matrices.detach()
+    if m.dim() == 2:
+        n = int(round(m.shape[1] ** 0.5))
+        if n * n != m.shape[1]:
+            raise ValueError(f"rows of {m.shape[1]} entries are not square matrices")
+        m = m.reshape(m.shape[0], n, n)
+    m = m.contiguous()
+    n = m.shape[1]
+    if m.shape[0] and symmetry_tol is not None:
+        asym = _max((m - m.transpose(1, 2)).abs().contiguous())          # one scalar check per batch
+        scale = _max(m.abs().contiguous())
+        if float(asym) > symmetry_tol * max(float(scale), 1e-30):
+            raise ValueError("spectral_features needs symmetric matrices (max |A - A^T| = "
+                             f"{float(asym):.3g} at scale {float(scale):.3g})")
+    k = n if k is None else int(k)
+    out = torch.empty(m.shape[0], k, device=m.device)
+    _lib.call("mdnvae_spectrum_topk", _lib.ptr(m, "matrices"), m.shape[0], n, k, _lib.ptr(out, "out"), _lib.stream())
+    return out
+
+
+@torch.no_grad()
+def matrix_ssim(real, generated, data_range=1.0):
+    """Mean structural similarity of every (real, generated) pair [count] with the skimage defaults
+    the scripts rely on (function/VAE_CNN_NN.py:291-297): 7x7 uniform window, sample covariance."""
+    a, b = real.detach(), generated.detach()
+    if a.dim() == 2:
+        n = int(round(a.shape[1] ** 0.5))
+        a, b = a.reshape(-1, n, n), b.reshape(-1, n, n)
+    if a.shape != b.shape:
+        raise ValueError(f"real {tuple(a.shape)} and generated {tuple(b.shape)} differ in shape")
+    a, b = a.contiguous(), b.contiguous()
+    out = torch.empty(a.shape[0], device=a.device)
+    _lib.call("mdnvae_ssim", _lib.ptr(a, "real"), _lib.ptr(b, "generated"), a.shape[0], a.shape[1], float(data_range),
+              _lib.ptr(out, "out"), _lib.stream())
+    return out
+
+
+def compute_ssim_average(real, generated):
+    """function/VAE_CNN_NN.py:291-297 (data_range 1.0)."""
+    v = matrix_ssim(real, generated, 1.0).tolist()
+    return sum(v) / len(v)
+
+
+def spectral_fid(real, generated, k=10, group=None):
+    """FID between the top-k spectra of real and generated matrices (function/VAE_CNN_NN.py:318-337)."""
+    from . import fid
+    return fid.calculate_fid(spectral_features(real, k), spectral_features(generated, k), group=group)

@@ -17,6 +17,7 @@ import torch
 from . import _lib
 
 _MAX_ITERS = 100
+_RIDGE = 1e-14          # relative to the Frobenius norm of the matrix
 
 
 def _dev_f64(a, device):
@@ -125,6 +126,10 @@ def sqrtm_psd(a):
     if norm == 0.0:
         return torch.zeros_like(a), 0
     y = _symmetrize(a, 1.0 / norm, torch.empty_like(a))
+    # ridge: the iteration's Z = Y^-1 is bounded by 1/sqrt(smallest eigenvalue), so on a singular
+    # covariance (fewer samples than features, degenerate features) it amplifies rounding noise
+    # without limit; 1e-14 keeps Z below 1e7 and moves the trace by at most 1e-7 per null direction
+    y.diagonal().add_(_RIDGE)
     z = torch.eye(d, dtype=torch.float64, device=a.device)
     t = torch.empty_like(a)
     tmp = torch.empty_like(a)

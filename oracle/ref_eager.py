@@ -371,3 +371,28 @@ def compute_psnr(real, generated, max_value=1.0):
     with np.errstate(divide="ignore"):
         psnr = np.where(mse_values == 0, np.inf, 20 * np.log10(max_value) - 10 * np.log10(mse_values))
     return psnr[np.isfinite(psnr)].mean()
+
+
+def compute_spectral_features(matrix, k=None):
+    """function/VAE_CNN_NN.py:302-308."""
+    eigenvalues = np.sort(np.real(np.linalg.eigvals(matrix)))[::-1]
+    return eigenvalues[:k] if k is not None else eigenvalues
+
+
+def ssim(im1, im2, data_range=1.0, win_size=7, K1=0.01, K2=0.03):
+    """Mean SSIM as skimage.metrics.structural_similarity computes it with its defaults (uniform
+    window, use_sample_covariance=True, crop of (win_size-1)//2 before the mean) -- the call at
+    function/VAE_CNN_NN.py:294.  skimage is not installed here: this follows its published
+    algorithm (parity unpinned)."""
+    from scipy.ndimage import uniform_filter
+    im1, im2 = np.asarray(im1, dtype=np.float64), np.asarray(im2, dtype=np.float64)
+    NP = win_size ** im1.ndim
+    cov_norm = NP / (NP - 1)
+    ux, uy = uniform_filter(im1, size=win_size), uniform_filter(im2, size=win_size)
+    uxx, uyy, uxy = (uniform_filter(im1 * im1, size=win_size), uniform_filter(im2 * im2, size=win_size),
+                     uniform_filter(im1 * im2, size=win_size))
+    vx, vy, vxy = cov_norm * (uxx - ux * ux), cov_norm * (uyy - uy * uy), cov_norm * (uxy - ux * uy)
+    C1, C2 = (K1 * data_range) ** 2, (K2 * data_range) ** 2
+    S = ((2 * ux * uy + C1) * (2 * vxy + C2)) / ((ux ** 2 + uy ** 2 + C1) * (vx + vy + C2))
+    pad = (win_size - 1) // 2
+    return S[pad:-pad, pad:-pad].mean()

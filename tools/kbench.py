@@ -72,6 +72,50 @@ def bench_conv(B):
     return out
 
 
+def bench_metrics(count, n=68):
+    """Validation-side kernels: matrices (or pairs) per second."""
+    dev = "cuda:0"
+    a = torch.rand(count, n, n, device=dev)
+    a = (a + a.transpose(1, 2)).contiguous()
+    b = (a + 0.05 * torch.rand_like(a)).contiguous()
+    E = M.evaluate
+    out = []
+    for name, fn in (("spectrum_top10", lambda: E.spectral_features(a, 10, symmetry_tol=None)),
+                     ("ssim", lambda: E.matrix_ssim(a, b)), ("matrix_mse", lambda: E.matrix_mse(a, b))):
+        med, best = timeit(fn, iters=5, warmup=1)
+        out.append(dict(kernel=name, count=count, n=n, ms=med * 1e3, matrices_per_s=count / med))
+    raw = torch.rand(count, 87, 87, device=dev)
+    med, best = timeit(lambda: M.data.prepare_sc(raw), iters=5, warmup=1)
+    out.append(dict(kernel="prep_connectome", count=count, n=87, ms=med * 1e3, matrices_per_s=count / med,
+                    GBps=count * (87 * 87 + 68 * 68) * 4 / med / 1e9))
+    x = torch.randn(count, 30, device=dev)
+    med, best = timeit(lambda: M.feature_stats(x), iters=5, warmup=1)
+    out.append(dict(kernel="fid_moments_d30", count=count, ms=med * 1e3, rows_per_s=count / med))
+    return out
+
+
+def bench_fid(n, d):
+    """FID at scale: moments of two [n,d] feature sets (MFMA Gram) and the two matrix square roots."""
+    dev = "cuda:0"
+    g = torch.Generator(device=dev).manual_seed(0)
+    a = torch.randn(n, d, device=dev, generator=g)
+    b = torch.randn(n, d, device=dev, generator=g) * 1.1 + 0.05
+    out = []
+    med, _ = timeit(lambda: M.feature_stats(a), iters=3, warmup=1)
+    out.append(dict(kernel="fid_moments", n=n, d=d, ms=med * 1e3, TFLOPs=2.0 * n * d * d / med / 1e12,
+                    note="algorithmic 2*n*d^2 (the kernel computes only tiles on/above the diagonal)"))
+    m1, c1 = M.feature_stats(a)
+    m2, c2 = M.feature_stats(b)
+    import time
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    val = M.fid_from_stats(m1, c1, m2, c2)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out.append(dict(kernel="fid_from_stats(2 Newton-Schulz sqrtm, fp64 library GEMMs)", d=d, s=dt, fid=val))
+    return out
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--what", default="loss")
@@ -80,6 +124,12 @@ if __name__ == "__main__":
     a = ap.parse_args()
     if a.what == "loss":
         for row in bench_loss(a.B, a.N):
+            print(json.dumps(row))
+    if a.what == "fid":
+        for row in bench_fid(a.B, a.N):
+            print(json.dumps(row))
+    if a.what == "metrics":
+        for row in bench_metrics(a.B):
             print(json.dumps(row))
     if a.what == "conv":
         for row in bench_conv(a.B):
