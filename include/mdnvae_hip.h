@@ -271,6 +271,11 @@ int mdnvae_spectrum_topk(const float* mats, long count, int n, int k, float* out
 /* out [count] = mean SSIM of each image pair: 7x7 uniform window, sample covariance, K1 0.01, K2 0.03
  * (the skimage defaults behind compute_ssim_average, function/VAE_CNN_NN.py:291-297). */
 int mdnvae_ssim(const float* a, const float* b, long count, int n, float data_range, float* out, void* stream);
+/* out [count,5] = {weighted-degree mean, std, weighted clustering mean, std, average shortest path
+ * length} of each n x n matrix read as a weighted graph (n <= 128): compute_graph_features of
+ * validation/FID.py:6-58 (weighted_paths = 1: edge distance 1/(w + 1e-5)) and of
+ * function/VAE_CNN_NN.py:341-379 (weighted_paths = 0: hop counts, as that script attaches no distance). */
+int mdnvae_graph_features(const float* mats, long count, int n, int weighted_paths, float* out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -158,6 +158,158 @@ __global__ __launch_bounds__(256) void ssim_kernel(const float* __restrict__ a, 
     if (t == 0) out[blockIdx.x] = (float)(acc / ((double)v * v));
 }
 
+// Graph features of one weighted graph per workgroup (n <= 128 nodes):
+//   [weighted-degree mean, std, weighted clustering mean, std, average shortest path length]
+//   reference: compute_graph_features, validation/FID.py:6-58 (weighted = 1: edge distance
+//   1/(w + 1e-5)) and function/VAE_CNN_NN.py:341-379 (weighted = 0: the script attaches no distance,
+//   so paths count hops).  The networkx calls behind it are restated: an edge wherever either
+//   triangle entry of matrix/max is non-zero (weight = the lower entry if non-zero, else the upper),
+//   a self-loop counts twice in the degree, Onnela clustering on weight / max edge weight,
+//   all-pairs shortest paths (Floyd-Warshall in LDS), per-component averages when disconnected.
+constexpr int GF_MAXN = 128;
+__global__ __launch_bounds__(256) void graph_features_kernel(const float* __restrict__ mats, int n, int weighted,
+                                                             float* __restrict__ out) {
+    extern __shared__ float smem[];
+    const int ld = n + 1;
+    float* W = smem;                         // [n][ld] symmetric edge weights (0 = no edge)
+    float* D = W + n * ld;                   // [n][ld] distances
+    __shared__ float deg[GF_MAXN], clu[GF_MAXN], part[GF_MAXN][4];
+    __shared__ int comp[GF_MAXN];
+    __shared__ float redf[4];
+    __shared__ double redd[4];
+    __shared__ float s_max, s_wmax;
+    const int t = threadIdx.x;
+    const float* A = mats + (long)blockIdx.x * n * n;
+    // matrix.max()
+    {
+        float m = -INFINITY;
+        for (int e = t; e < n * n; e += 256) m = fmaxf(m, A[e]);
+        m = wave_max_all(m);
+        if ((t & 63) == 0) redf[t >> 6] = m;
+        __syncthreads();
+        if (t == 0) s_max = fmaxf(fmaxf(redf[0], redf[1]), fmaxf(redf[2], redf[3]));
+        __syncthreads();
+    }
+    const float mx = s_max;
+    float wm = -INFINITY;
+    for (int e = t; e < n * n; e += 256) {
+        const int i = e / n, j = e - i * n;
+        const int hi = max(i, j), lo = min(i, j);
+        float w = 0.0f, up = 0.0f;
+        if (mx > 0.0f) {
+            const float lower = A[hi * n + lo] / mx;
+            up = A[lo * n + hi] / mx;
+            w = (lower != 0.0f) ? lower : up;
+        }
+        W[i * ld + j] = w;
+        if (w != 0.0f) wm = fmaxf(wm, w);
+        float dist = INFINITY;
+        if (i == j) dist = 0.0f;
+        else if (w != 0.0f) dist = weighted ? 1.0f / (up + 1e-5f) : 1.0f;
+        D[i * ld + j] = dist;
+    }
+    wm = wave_max_all(wm);
+    if ((t & 63) == 0) redf[t >> 6] = wm;
+    __syncthreads();
+    if (t == 0) {
+        const float v = fmaxf(fmaxf(redf[0], redf[1]), fmaxf(redf[2], redf[3]));
+        s_wmax = (v == -INFINITY) ? 1.0f : v;
+    }
+    __syncthreads();
+    const float wmax = s_wmax;
+    // weighted degree
+    if (t < n) {
+        float s = 0.0f;
+        for (int j = 0; j < n; ++j)
+            if (j != t) s += W[t * ld + j];
+        deg[t] = s + 2.0f * W[t * ld + t];
+    }
+    // clustering: thread (i, p) takes the neighbours j = p, p + P, ... of node i; pairs j < k
+    const int P = (256 / n) < 4 ? (256 / n) : 4;          // 1..4 threads per node
+    {
+        const int i = t / P, p = t - i * P;
+        if (i < n) {
+            float s = 0.0f;
+            for (int j = p; j < n; j += P) {
+                const float wij = W[i * ld + j];
+                if (j == i || wij == 0.0f) continue;
+                const float hij = wij / wmax;
+                for (int k = j + 1; k < n; ++k) {
+                    const float wik = W[i * ld + k], wjk = W[j * ld + k];
+                    if (k == i || wik == 0.0f || wjk == 0.0f) continue;
+                    s += cbrtf(hij * (wjk / wmax) * (wik / wmax));
+                }
+            }
+            part[i][p] = s;
+        }
+    }
+    __syncthreads();
+    if (t < n) {
+        float tri = 0.0f;
+        for (int p = 0; p < P; ++p) tri += part[t][p];
+        int d = 0;
+        for (int j = 0; j < n; ++j) d += (j != t && W[t * ld + j] != 0.0f);
+        tri *= 2.0f;
+        clu[t] = (tri == 0.0f) ? 0.0f : tri / ((float)d * (float)(d - 1));
+    }
+    // Floyd-Warshall: row k and column k do not change in step k, so the update is done in place
+    for (int k = 0; k < n; ++k) {
+        __syncthreads();
+        for (int e = t; e < n * n; e += 256) {
+            const int i = e / n, j = e - i * n;
+            const float via = D[i * ld + k] + D[k * ld + j];
+            if (via < D[i * ld + j]) D[i * ld + j] = via;
+        }
+    }
+    __syncthreads();
+    if (t < n) {
+        int c = t;
+        for (int j = 0; j < n; ++j)
+            if (D[t * ld + j] < INFINITY) { c = j; break; }
+        comp[t] = c;
+    }
+    __syncthreads();
+    // moments of degree and clustering (population std), in double
+    double s1 = 0.0, s2 = 0.0, c1 = 0.0, c2 = 0.0;
+    if (t < n) {
+        s1 = deg[t]; s2 = (double)deg[t] * deg[t];
+        c1 = clu[t]; c2 = (double)clu[t] * clu[t];
+    }
+    s1 = block_sum<256, double>(s1, redd);
+    s2 = block_sum<256, double>(s2, redd);
+    c1 = block_sum<256, double>(c1, redd);
+    c2 = block_sum<256, double>(c2, redd);
+    // per-node sum of distances inside its component (deg[] is free now)
+    if (t < n) {
+        float s = 0.0f;
+        for (int j = 0; j < n; ++j)
+            if (comp[j] == comp[t]) s += D[t * ld + j];
+        deg[t] = s;
+    }
+    __syncthreads();
+    if (t == 0) {
+        float* o = out + (long)blockIdx.x * 5;
+        const double dm = s1 / n, cm = c1 / n;
+        o[0] = (float)dm;
+        o[1] = (float)sqrt(fmax(s2 / n - dm * dm, 0.0));
+        o[2] = (float)cm;
+        o[3] = (float)sqrt(fmax(c2 / n - cm * cm, 0.0));
+        double total = 0.0;
+        int ncomp = 0, counted = 0;
+        for (int r = 0; r < n; ++r) {
+            if (comp[r] != r) continue;
+            ++ncomp;
+            int size = 0;
+            double s = 0.0;
+            for (int j = 0; j < n; ++j)
+                if (comp[j] == r) { ++size; s += deg[j]; }
+            if (size > 1) { total += s / ((double)size * (size - 1)); ++counted; }
+        }
+        o[4] = counted ? (float)(total / counted) : 0.0f;      // one component: its own average
+        (void)ncomp;
+    }
+}
+
 }  // namespace mdnvae
 using namespace mdnvae;
 
@@ -194,6 +346,27 @@ int mdnvae_ssim(const float* a, const float* b, long count, int n, float data_ra
     hipLaunchKernelGGL(ssim_kernel, dim3((unsigned)count), dim3(256), sizeof(float) * 2 * n * n, (hipStream_t)stream, a, b,
                        n, data_range, out);
     MV_LAUNCH_CHECK("ssim_kernel");
+    return 0;
+}
+
+int mdnvae_graph_features(const float* mats, long count, int n, int weighted_paths, float* out, void* stream) {
+    MV_REQUIRE(count >= 0 && n >= 2, E_ARG, "mdnvae_graph_features: bad size (n=%d)", n);
+    MV_REQUIRE(n <= GF_MAXN, E_SHAPE, "mdnvae_graph_features: n=%d exceeds %d", n, GF_MAXN);
+    MV_REQUIRE(count <= 0x7fffffffL, E_SHAPE, "mdnvae_graph_features: too many matrices for one launch");
+    if (count == 0) return 0;
+    MV_REQUIRE(mats && out, E_ARG, "mdnvae_graph_features: null pointer");
+    static bool attr_set = false;
+    if (!attr_set) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(graph_features_kernel),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024);
+        MV_REQUIRE(e == hipSuccess, (int)e, "mdnvae_graph_features: cannot raise the LDS limit: %s",
+                   hipGetErrorString(e));
+        attr_set = true;
+    }
+    const size_t lds = sizeof(float) * (size_t)2 * n * (n + 1);
+    hipLaunchKernelGGL(graph_features_kernel, dim3((unsigned)count), dim3(256), lds, (hipStream_t)stream, mats, n,
+                       weighted_paths, out);
+    MV_LAUNCH_CHECK("graph_features_kernel");
     return 0;
 }
 

@@ -154,3 +154,29 @@ def spectral_fid(real, generated, k=10, group=None):
     """FID between the top-k spectra of real and generated matrices (function/VAE_CNN_NN.py:318-337)."""
     from . import fid
     return fid.calculate_fid(spectral_features(real, k), spectral_features(generated, k), group=group)
+
+
+@torch.no_grad()
+def graph_features(matrices, weighted_paths=True):
+    """[count, 5] graph features {weighted-degree mean, std, weighted clustering mean, std, average
+    shortest path length} of every matrix read as a weighted graph: compute_graph_features of
+    validation/FID.py:6-58 (weighted_paths=True) or of function/VAE_CNN_NN.py:341-379
+    (weighted_paths=False: that script never attaches the edge distances, so paths count hops).
+    Weights are expected non-negative (as the scripts' normalised, clamped matrices are)."""
+    m = matrices.detach()
+    if m.dim() == 2:
+        n = int(round(m.shape[1] ** 0.5))
+        if n * n != m.shape[1]:
+            raise ValueError(f"rows of {m.shape[1]} entries are not square matrices")
+        m = m.reshape(m.shape[0], n, n)
+    m = m.to(torch.float32).contiguous()
+    out = torch.empty(m.shape[0], 5, device=m.device)
+    _lib.call("mdnvae_graph_features", _lib.ptr(m, "matrices"), m.shape[0], m.shape[1], int(bool(weighted_paths)),
+              _lib.ptr(out, "out"), _lib.stream())
+    return out
+
+
+def graph_fid(real, generated, weighted_paths=False, group=None):
+    """calculate_fid_graph of function/VAE_CNN_NN.py:381-396 on the five graph features."""
+    from . import fid
+    return fid.calculate_fid(graph_features(real, weighted_paths), graph_features(generated, weighted_paths), group=group)

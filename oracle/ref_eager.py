@@ -396,3 +396,51 @@ def ssim(im1, im2, data_range=1.0, win_size=7, K1=0.01, K2=0.03):
     S = ((2 * ux * uy + C1) * (2 * vxy + C2)) / ((ux ** 2 + uy ** 2 + C1) * (vx + vy + C2))
     pad = (win_size - 1) // 2
     return S[pad:-pad, pad:-pad].mean()
+
+
+def graph_features(matrix, weighted_paths=True):
+    """compute_graph_features: validation/FID.py:6-58 (weighted_paths=True: every edge carries
+    distance = 1/(w + 1e-5)) and function/VAE_CNN_NN.py:341-379 (weighted_paths=False: the script
+    never attaches the 'distance' attribute, so path lengths are hop counts).  Restates the networkx
+    3.4 calls it makes: from_numpy_array (an edge wherever either triangle is non-zero; the weight is
+    the lower-triangle entry when that is non-zero), weighted degree (a self-loop counts twice),
+    Onnela's weighted clustering on weights / max edge weight, average shortest path length
+    (per connected component with more than one node when the graph is disconnected).
+    Returns [degree mean, degree std, clustering mean, clustering std, average path length]."""
+    m = np.asarray(matrix, dtype=np.float64)
+    n = m.shape[0]
+    mx = m.max()
+    an = m / mx if mx > 0 else np.zeros_like(m)
+    low = np.tril(an)
+    w = np.where(low != 0, low, np.triu(an).T)            # lower entry, else the upper one
+    w = w + np.tril(w, -1).T                              # symmetric edge weights, diagonal = self-loops
+    edge = w != 0
+    off = edge & ~np.eye(n, dtype=bool)
+    deg = (w * off).sum(axis=1) + 2 * np.diag(w)
+    wmax = w[edge].max() if edge.any() else 1.0
+    wh = np.cbrt(w / wmax)
+    clust = np.zeros(n)
+    for i in range(n):
+        nb = np.flatnonzero(off[i])
+        d = len(nb)
+        if d < 2:
+            continue
+        sub = wh[np.ix_(nb, nb)] * off[np.ix_(nb, nb)]
+        t = (wh[i, nb][:, None] * wh[i, nb][None, :] * sub).sum()      # ordered pairs = 2 x triangles
+        clust[i] = 0.0 if t == 0 else t / (d * (d - 1))
+    upper = np.triu(an) + np.triu(an, 1).T                              # distance_matrix[i, j] with i <= j
+    dist = np.where(off, (1.0 / (upper + 1e-5)) if weighted_paths else 1.0, np.inf)
+    np.fill_diagonal(dist, 0.0)
+    for k in range(n):
+        dist = np.minimum(dist, dist[:, k:k + 1] + dist[k:k + 1, :])
+    comp = np.array([np.flatnonzero(np.isfinite(dist[i]))[0] for i in range(n)])
+    lengths = []
+    for r in np.unique(comp):
+        idx = np.flatnonzero(comp == r)
+        if len(idx) > 1:
+            lengths.append(dist[np.ix_(idx, idx)].sum() / (len(idx) * (len(idx) - 1)))
+    if len(np.unique(comp)) == 1:
+        path = lengths[0] if lengths else 0.0
+    else:
+        path = float(np.mean(lengths)) if lengths else 0.0
+    return np.array([deg.mean(), deg.std(), clust.mean(), clust.std(), path])

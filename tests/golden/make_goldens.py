@@ -355,6 +355,38 @@ def make_fid():
     save("fid", **out)
 
 
+def make_graphs():
+    """Graph features of validation/FID.py (edge 'distance' attached) and of function/VAE_CNN_NN.py
+    (no 'distance' attribute: hop counts) on the SBM graphs of validation/FID.py (its own seeds, stored
+    as packed bits), on four real connectomes and on a disconnected matrix."""
+    t0 = time.time()
+    ns = load_defs("validation/FID.py")
+    ns2 = load_defs("function/VAE_CNN_NN.py")
+    gen = ns["generate_sbm_graphs"]
+    pi = [0.3, 0.4, 0.3]
+    P = dict(real=[[0.8, 0.05, 0.02], [0.05, 0.7, 0.03], [0.02, 0.03, 0.6]],
+             small=[[0.8, 0.10, 0.07], [0.10, 0.7, 0.08], [0.07, 0.08, 0.6]],
+             large=[[0.8, 0.3, 0.3], [0.3, 0.7, 0.3], [0.3, 0.3, 0.6]])
+    out = {}
+    for (name, p), seed in zip(P.items(), (42, 43, 44)):
+        graphs = np.array(gen(50, 100, 3, pi, p, seed=seed))
+        out[f"sbm_{name}_bits"] = np.packbits(graphs.astype(np.uint8).reshape(50, -1), axis=1)
+        out[f"sbm_{name}_features"] = np.array([ns["compute_graph_features"](m) for m in graphs])
+    x, _, _, _ = sc_inputs()
+    mats = x[:4].reshape(4, 68, 68).astype(np.float32)
+    two = np.zeros((10, 10), dtype=np.float32)          # two components + an isolated node
+    two[:4, :4] = np.float32([[0, 1, .5, 0], [1, 0, .25, .75], [.5, .25, 0, 0], [0, .75, 0, 0]])
+    two[4:9, 4:9] = np.float32(np.triu(np.arange(25).reshape(5, 5) % 4, 1) / 4.0)
+    two[4:9, 4:9] += two[4:9, 4:9].T
+    out["connectomes"] = mats
+    out["disconnected"] = two
+    for tag, fn in (("fidpy", ns["compute_graph_features"]), ("script", ns2["compute_graph_features"])):
+        out[f"connectome_features_{tag}"] = np.array([fn(m) for m in mats])
+        out[f"disconnected_features_{tag}"] = np.array(fn(two))
+    print(f"  graph features ({time.time() - t0:.0f}s)")
+    save("graphs", **out)
+
+
 def _run_reference_loop(relpath, names, inside=None):
     """Executes, unmodified, the data-preparation `for` loop of a reference script (the first
     top-level For statement, or the first one inside function `inside`) in the namespace `names`
@@ -399,7 +431,7 @@ def make_prep():
 
 ALL = dict(cnn_nn_sc=make_cnn_nn_sc, cnn_gcn_sc=make_cnn_gcn_sc, cnn_gcn_fc=make_cnn_gcn_fc,
            cnn_nn_fc=make_cnn_nn_fc, mm_gate=make_mm_gate, fnn_gcn_fc=make_fnn_gcn_fc, cvae=make_cvae, ec87=make_ec87,
-           losses=make_losses, fid=make_fid, prep=make_prep)
+           losses=make_losses, fid=make_fid, prep=make_prep, graphs=make_graphs)
 
 if __name__ == "__main__":
     torch.set_num_threads(8)

@@ -77,3 +77,39 @@ def test_ssim_matches_published_algorithm(E, n):
     np.testing.assert_allclose(got, want, rtol=0, atol=1e-5)
     assert got[0] == pytest.approx(1.0, abs=1e-6)
     assert E.compute_ssim_average(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()) == pytest.approx(want.mean(), abs=1e-5)
+
+
+def _sbm(fix, name):
+    return np.unpackbits(fix[f"sbm_{name}_bits"], axis=1)[:, :10000].reshape(-1, 100, 100).astype(np.float32)
+
+
+def test_graph_features_match_the_reference_networkx_outputs(E):
+    """tests/golden/graphs.npz: outputs of the reference's compute_graph_features (both variants) on
+    real connectomes, on a disconnected matrix with an isolated node, and on the SBM graphs of
+    validation/FID.py.  fp32 on the device against networkx's mixed float32/float64: 3e-5 relative."""
+    fix = load_fixture("graphs")
+    for tag, weighted in (("fidpy", True), ("script", False)):
+        got = E.graph_features(torch.from_numpy(fix["connectomes"]).cuda(), weighted).cpu().numpy()
+        np.testing.assert_allclose(got, fix[f"connectome_features_{tag}"], rtol=3e-5, atol=1e-7)
+        got = E.graph_features(torch.from_numpy(fix["disconnected"][None]).cuda(), weighted).cpu().numpy()[0]
+        np.testing.assert_allclose(got, fix[f"disconnected_features_{tag}"], rtol=3e-5, atol=1e-7)
+    for name in ("real", "small", "large"):
+        got = E.graph_features(torch.from_numpy(_sbm(fix, name)).cuda(), True).cpu().numpy()
+        np.testing.assert_allclose(got, fix[f"sbm_{name}_features"], rtol=3e-5, atol=1e-7)
+
+
+def test_fid_script_end_to_end_on_the_device(E):
+    """validation/FID.py from its graphs to its two printed numbers, entirely on the device."""
+    import mdnvae_amd as M
+    fix = load_fixture("graphs")
+    f = {name: E.graph_features(torch.from_numpy(_sbm(fix, name)).cuda(), True) for name in ("real", "small", "large")}
+    assert M.calculate_fid(f["real"], f["small"]) == pytest.approx(10.414893149812082, rel=2e-3)
+    assert M.calculate_fid(f["real"], f["large"]) == pytest.approx(304.06124481745877, rel=2e-3)
+
+
+def test_graph_features_edge_cases(E):
+    z = torch.zeros(2, 12, 12, device="cuda")                      # no edges at all
+    assert torch.equal(E.graph_features(z), torch.zeros(2, 5, device="cuda"))
+    assert E.graph_features(torch.zeros(0, 12, 12, device="cuda")).shape == (0, 5)
+    with pytest.raises(RuntimeError, match="exceeds"):
+        E.graph_features(torch.zeros(1, 129, 129, device="cuda"))

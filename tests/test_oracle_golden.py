@@ -164,3 +164,16 @@ def test_preparation_loops_of_the_reference():
                                    rtol=1e-6, atol=1e-6)
         np.testing.assert_allclose(R.prepare_fisher(fix["raw_fc"][i].astype(np.float64)), fix["rows_fisher"][i],
                                    rtol=1e-3, atol=1e-3)
+
+
+def test_graph_features_against_networkx_outputs_of_the_reference():
+    fix = load_fixture("graphs")
+    for tag, weighted in (("fidpy", True), ("script", False)):
+        for i in range(4):
+            got = R.graph_features(fix["connectomes"][i], weighted)
+            np.testing.assert_allclose(got, fix[f"connectome_features_{tag}"][i], rtol=2e-5, atol=1e-7)
+        np.testing.assert_allclose(R.graph_features(fix["disconnected"], weighted), fix[f"disconnected_features_{tag}"],
+                                   rtol=2e-5, atol=1e-7)
+    bits = np.unpackbits(fix["sbm_real_bits"], axis=1)[:, :10000].reshape(-1, 100, 100).astype(np.float64)
+    for i in range(0, 50, 10):
+        np.testing.assert_allclose(R.graph_features(bits[i], True), fix["sbm_real_features"][i], rtol=2e-5, atol=1e-7)

@@ -81,6 +81,8 @@ def bench_metrics(count, n=68):
     E = M.evaluate
     out = []
     for name, fn in (("spectrum_top10", lambda: E.spectral_features(a, 10, symmetry_tol=None)),
+                     ("graph_features(hops)", lambda: E.graph_features(a, False)),
+                     ("graph_features(weighted)", lambda: E.graph_features(a, True)),
                      ("ssim", lambda: E.matrix_ssim(a, b)), ("matrix_mse", lambda: E.matrix_mse(a, b))):
         med, best = timeit(fn, iters=5, warmup=1)
         out.append(dict(kernel=name, count=count, n=n, ms=med * 1e3, matrices_per_s=count / med))
