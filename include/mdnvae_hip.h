@@ -120,6 +120,13 @@ int mdnvae_decoder_bwd(const float* z, const float* wt, const float* wn, int B, 
                        float* grad_z, float* layer_in, float* layer_dpre, float* grad_times_act, const float* nodes,
                        float* node_grad, void* stream);
 
+/* The decoder's second stage on its own: out [B,N*N] = act(sum_r g_r g_r^T) from node vectors
+ * nodes [B,R,MDNVAE_DEC_NP], and the gradient of the node vectors from grad_out
+ * (torch.bmm(merged.unsqueeze(2), merged.unsqueeze(1)), function_fc_new/ResNet.py:180-183, is R = 1). */
+int mdnvae_outer_sum_fwd(const float* nodes, int B, int R, int N, int epi_act, float* out, void* stream);
+int mdnvae_outer_sum_bwd(const float* grad_out, const float* nodes, int B, int R, int N, int epi_act, float* grad_nodes,
+                         void* stream);
+
 /* out_a[e] = sum_b a[b,e], out_c[e] = sum_b c[b,e] in a fixed order (bias / diagonal-weight gradients). */
 size_t mdnvae_colsum2_workspace_floats(int B, int D);
 int mdnvae_colsum2(const float* a, const float* c, int B, int D, float* workspace, float* out_a, float* out_c,
@@ -135,6 +142,8 @@ int mdnvae_mul(const float* a, const float* b, float* y, long n, void* stream);
  * rocBLAS calls made by the host; these kernels do the rest of F.linear + activation. */
 /* y[r,c] = act(y[r,c] + bias[c]) in place (bias may be NULL). */
 int mdnvae_bias_act(float* y, const float* bias, long rows, int cols, int act, void* stream);
+/* y = act(a + b): the residual joins of function_fc_new/ResNet.py:101-107,150-153 */
+int mdnvae_add_act(const float* a, const float* b, float* y, long n, int act, void* stream);
 /* grad_pre = grad_y * act'(.) expressed through the activation output y. */
 int mdnvae_act_bwd(const float* y, const float* grad_y, float* grad_pre, long n, int act, void* stream);
 /* out[e] = sum_b a[b,e], fixed summation order (bias gradients). */

@@ -12,7 +12,7 @@ from .fid import calculate_fid, FeatureStats, feature_stats, fid_from_stats, sqr
 from .trainer import Trainer, FlatBuffers, allreduce_sum  # noqa: F401
 from .modules import (ConvVAE, GCNVAE, MDNGateVAE, cVAE, GraphCNN, Linear, GCNLayer, ChannelGCN, MultiChannelGCNDecoder,  # noqa: F401
                       DiagonalIntercept, loss_function_poisson_rate, loss_function_poisson_log, loss_function_mse,
-                      loss_function_mse_terms)
+                      loss_function_mse_terms, ResNetVAE, ResidualBlock, BranchMLP, BranchGCN, MultiBranchDecoder)
 
 __all__ = ["reparameterize", "vae_loss", "vae_loss_terms", "vae_loss_and_grads", "ops", "ConvVAE", "GCNVAE", "MDNGateVAE", "cVAE",
            "GraphCNN", "Linear", "loss_function_poisson_rate", "loss_function_poisson_log", "loss_function_mse",

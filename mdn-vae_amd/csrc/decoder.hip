@@ -730,6 +730,31 @@ int mdnvae_decoder_bwd(const float* z, const float* wt, const float* wn, int B, 
     return 0;
 }
 
+int mdnvae_outer_sum_fwd(const float* nodes, int B, int R, int N, int epi_act, float* out, void* stream) {
+    MV_REQUIRE(B >= 0 && R >= 1 && R <= MAXR && N >= 1 && N <= NP - 1, E_SHAPE,
+               "mdnvae_outer_sum_fwd: unsupported shape (B=%d, R=%d, N=%d)", B, R, N);
+    if (B == 0) return 0;
+    MV_REQUIRE(nodes && out, E_ARG, "mdnvae_outer_sum_fwd: null pointer");
+    DecArgs a{B, N, 0, R, 0, 0, epi_act, 0, 0, 0, 0};
+    hipLaunchKernelGGL(outer_epilogue_kernel, dim3(wave_grid(B)), dim3(256), 0, (hipStream_t)stream, a, nodes, nullptr,
+                       nullptr, (unsigned)(0x100000000ull / (unsigned)N) + 1u, out);
+    MV_LAUNCH_CHECK("outer_epilogue_kernel");
+    return 0;
+}
+
+int mdnvae_outer_sum_bwd(const float* grad_out, const float* nodes, int B, int R, int N, int epi_act, float* grad_nodes,
+                         void* stream) {
+    MV_REQUIRE(B >= 0 && R >= 1 && R <= MAXR && N >= 1 && N <= NP - 1, E_SHAPE,
+               "mdnvae_outer_sum_bwd: unsupported shape (B=%d, R=%d, N=%d)", B, R, N);
+    if (B == 0) return 0;
+    MV_REQUIRE(grad_out && nodes && grad_nodes, E_ARG, "mdnvae_outer_sum_bwd: null pointer");
+    DecArgs a{B, N, 0, R, 0, 0, epi_act, 0, 0, 0, 0};
+    hipLaunchKernelGGL(outer_grad_kernel<false>, dim3(wave_grid(B)), dim3(256), 0, (hipStream_t)stream, a, grad_out, nodes,
+                       nullptr, nullptr, nullptr, nullptr, grad_nodes);
+    MV_LAUNCH_CHECK("outer_grad_kernel");
+    return 0;
+}
+
 size_t mdnvae_colsum2_workspace_floats(int B, int D) {
     const int rows = 64;
     return (size_t)((B + rows - 1) / rows) * 2 * D;

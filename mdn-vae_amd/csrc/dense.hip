@@ -41,6 +41,12 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ 
         gout[i] = gin[i] * dslope(act, y[i]);
 }
 
+// y[i] = act(a[i] + b[i])   (residual joins: function_fc_new/ResNet.py:101-107,150-153)
+__global__ __launch_bounds__(256) void add_act_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                      float* __restrict__ y, long n, int act) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) y[i] = dact(act, a[i] + b[i]);
+}
+
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ a, int B, int D,
                                                              int rows_per_block, float* __restrict__ part) {
     const int e = blockIdx.x * 256 + threadIdx.x;
@@ -88,6 +94,16 @@ int mdnvae_act_bwd(const float* y, const float* grad_y, float* grad_pre, long n,
     MV_REQUIRE(y && grad_y && grad_pre, E_ARG, "mdnvae_act_bwd: null pointer");
     hipLaunchKernelGGL(act_bwd_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, y, grad_y, grad_pre, n, act);
     MV_LAUNCH_CHECK("act_bwd_kernel");
+    return 0;
+}
+
+int mdnvae_add_act(const float* a, const float* b, float* y, long n, int act, void* stream) {
+    MV_REQUIRE(n >= 0, E_ARG, "mdnvae_add_act: negative size");
+    MV_REQUIRE(act >= 0 && act <= MDNVAE_ACT_RELU, E_ARG, "mdnvae_add_act: unknown activation %d", act);
+    if (n == 0) return 0;
+    MV_REQUIRE(a && b && y, E_ARG, "mdnvae_add_act: null pointer");
+    hipLaunchKernelGGL(add_act_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, a, b, y, n, act);
+    MV_LAUNCH_CHECK("add_act_kernel");
     return 0;
 }
 

@@ -180,3 +180,30 @@ def graph_fid(real, generated, weighted_paths=False, group=None):
     """calculate_fid_graph of function/VAE_CNN_NN.py:381-396 on the five graph features."""
     from . import fid
     return fid.calculate_fid(graph_features(real, weighted_paths), graph_features(generated, weighted_paths), group=group)
+
+
+@torch.no_grad()
+def extract_latent(model, data, batch_size=256, extra=()):
+    """Posterior means [n, L] and log-variances of `data`, batch by batch in eval mode -- the loop of
+    tools/extract.py:29-45 (encode only: no reconstruction is kept)."""
+    was_training = model.training
+    model.eval()
+    try:
+        mus, lvs = [], []
+        for lo in range(0, data.shape[0], batch_size):
+            mu, logvar = model.encode(data[lo:lo + batch_size].contiguous(), *extra)
+            mus.append(mu)
+            lvs.append(logvar)
+    finally:
+        model.train(was_training)
+    return torch.cat(mus), torch.cat(lvs)
+
+
+def save_latent(mu, prefix):
+    """Writes `<prefix>.npy` and `<prefix>-un.mat` ({'mu': [n, L]}) as tools/extract.py:47-51 does."""
+    import numpy as np
+    import scipy.io
+    arr = mu.detach().cpu().numpy()
+    np.save(prefix + ".npy", arr)
+    scipy.io.savemat(prefix + "-un.mat", mdict={"mu": arr})
+    return prefix + ".npy", prefix + "-un.mat"

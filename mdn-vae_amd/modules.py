@@ -378,6 +378,105 @@ class MDNGateVAE(GCNVAE):
 
 
 # ---------------------------------------------------------------------------------------
+# multi-branch ResNet-MLP decoder family (function_fc_new/ResNet.py)
+# ---------------------------------------------------------------------------------------
+class ResidualBlock(nn.Module):
+    """function_fc_new/ResNet.py:83-106: relu(fc2(relu(fc1 x)) + shortcut(x))."""
+
+    def __init__(self, in_dim, out_dim):
+        super().__init__()
+        self.fc1 = Linear(in_dim, out_dim)
+        self.fc2 = Linear(out_dim, out_dim)
+        self.shortcut = Linear(in_dim, out_dim) if in_dim != out_dim else None
+
+    def forward(self, x):
+        out = self.fc2(self.fc1(x, act="relu"))
+        identity = x if self.shortcut is None else self.shortcut(x)
+        return ops.add_act(out, identity, "relu")
+
+
+class BranchMLP(nn.Module):
+    """function_fc_new/ResNet.py:109-129."""
+
+    def __init__(self, in_dim=68 * 68, out_dim=68, decode_dimen_number=10, hidden_dim=256):
+        super().__init__()
+        self.init_fc = Linear(in_dim, hidden_dim)
+        self.resblocks = nn.Sequential(*[ResidualBlock(hidden_dim, hidden_dim) for _ in range(decode_dimen_number)])
+        self.final_fc = Linear(hidden_dim, out_dim)
+
+    def forward(self, x):
+        return self.final_fc(self.resblocks(self.init_fc(x, act="relu")))
+
+
+class BranchGCN(nn.Module):
+    """function_fc_new/ResNet.py:133-149: masked layers with identity joins."""
+
+    def __init__(self, in_dim=68 * 68, n_nodes=68, num_gcn=10):
+        super().__init__()
+        self.init_fc = Linear(in_dim, n_nodes)
+        self.gcn_layers = nn.ModuleList([GraphCNN(n_nodes, n_nodes) for _ in range(num_gcn)])
+
+    def forward(self, x):
+        h = self.init_fc(x, act="relu")
+        for gcn in self.gcn_layers:
+            h = ops.add_act(gcn(h), h, "relu")
+        return h
+
+
+class MultiBranchDecoder(nn.Module):
+    """function_fc_new/ResNet.py:152-186: three branches summed, outer product, dense 4624^2 layer."""
+
+    def __init__(self, decode_dimen_number_mlp1, hidden_dim_mlp1, decode_dimen_number_mlp2, hidden_dim_mlp2,
+                 decode_dimen_number_gcn, n_nodes=68):
+        super().__init__()
+        D = n_nodes * n_nodes
+        self.n_nodes = n_nodes
+        self.branch_mlp1 = BranchMLP(D, n_nodes, decode_dimen_number_mlp1, hidden_dim_mlp1)
+        self.branch_gcn = BranchGCN(D, n_nodes, decode_dimen_number_gcn)
+        self.branch_mlp2 = BranchMLP(D, n_nodes, decode_dimen_number_mlp2, hidden_dim_mlp2)
+        self.final_fc = Linear(D, D)
+
+    def forward(self, x):
+        merged = ops.add_act(ops.add_act(self.branch_mlp1(x), self.branch_gcn(x)), self.branch_mlp2(x))
+        return self.final_fc(ops.outer_sum(merged.unsqueeze(1)))
+
+
+class ResNetVAE(nn.Module):
+    """`VAE` of function_fc_new/ResNet.py:189-238 (FNN towers, latent 256, multi-branch decoder)."""
+
+    def __init__(self, latent_dim=256, decode_dimen_number_mlp1=8, hidden_dim_mlp1=512, decode_dimen_number_mlp2=8,
+                 hidden_dim_mlp2=256, decode_dimen_number_gcn=10, n_nodes=68):
+        super().__init__()
+        D = n_nodes * n_nodes
+        self.n_nodes = n_nodes
+        self.fc11 = Linear(D, 1024)
+        self.fc12 = Linear(D, 1024)
+        self.fc111 = Linear(1024, 128)
+        self.fc222 = Linear(1024, 128)
+        self.fc21 = Linear(128, latent_dim)
+        self.fc22 = Linear(128, latent_dim)
+        self.fc_init_decode = Linear(latent_dim, D)
+        self.multi_branch_decoder = MultiBranchDecoder(decode_dimen_number_mlp1, hidden_dim_mlp1,
+                                                       decode_dimen_number_mlp2, hidden_dim_mlp2,
+                                                       decode_dimen_number_gcn, n_nodes)
+
+    def encode(self, x):
+        h11 = self.fc111(self.fc11(x, act="relu"), act="relu")
+        h12 = self.fc222(self.fc12(x, act="relu"), act="relu")
+        return self.fc21(h11), self.fc22(h12)
+
+    def reparameterize(self, mu, logvar, eps=None):
+        return ops.reparameterize(mu, logvar, eps)
+
+    def decode(self, z):
+        return self.multi_branch_decoder(self.fc_init_decode(z))
+
+    def forward(self, x, eps=None):
+        mu, logvar = self.encode(x.reshape(-1, self.n_nodes * self.n_nodes))
+        return self.decode(self.reparameterize(mu, logvar, eps)), mu, logvar
+
+
+# ---------------------------------------------------------------------------------------
 # conditional VAE (function_FC_SC/SC-FC.py)
 # ---------------------------------------------------------------------------------------
 class cVAE(nn.Module):

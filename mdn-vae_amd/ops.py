@@ -155,6 +155,66 @@ def linear_act(x, weight, bias=None, act=None):
     return _LinearAct.apply(x, weight, bias, ACTS[act])
 
 
+class _AddAct(torch.autograd.Function):
+    """act(a + b) with one kernel each way (residual joins)."""
+
+    @staticmethod
+    def forward(ctx, a, b, act):
+        a, b = _c(a), _c(b)
+        if a.shape != b.shape:
+            raise RuntimeError(f"add_act: shapes {tuple(a.shape)} and {tuple(b.shape)} differ")
+        y = torch.empty_like(a)
+        call("mdnvae_add_act", ptr(a, "a"), ptr(b, "b"), ptr(y), a.numel(), act, stream())
+        ctx.save_for_backward(y)
+        ctx.act = act
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (y,) = ctx.saved_tensors
+        gy = _c(gy)
+        if ctx.act == 0:
+            return gy, gy, None
+        g = torch.empty_like(gy)
+        call("mdnvae_act_bwd", ptr(y), ptr(gy), ptr(g), gy.numel(), ctx.act, stream())
+        return g, g, None
+
+
+def add_act(a, b, act=None):
+    return _AddAct.apply(a, b, ACTS[act])
+
+
+class _OuterSum(torch.autograd.Function):
+    """out [B,N*N] = act(sum_r g_r g_r^T) of node vectors g [B,R,N] (the decoder's outer-product
+    stage on its own)."""
+
+    @staticmethod
+    def forward(ctx, g, epi_act):
+        if g.dim() != 3:
+            raise RuntimeError(f"outer_sum: node vectors must be [B,R,N], got {tuple(g.shape)}")
+        B, R, N = g.shape
+        nodes = torch.zeros(B, R, DEC_NP, dtype=torch.float32, device=g.device)
+        nodes[:, :, :N].copy_(g)
+        out = torch.empty(B, N * N, dtype=torch.float32, device=g.device)
+        call("mdnvae_outer_sum_fwd", ptr(nodes, "nodes"), B, R, N, epi_act, ptr(out), stream())
+        ctx.save_for_backward(nodes)
+        ctx.meta = (B, R, N, epi_act)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        (nodes,) = ctx.saved_tensors
+        B, R, N, epi_act = ctx.meta
+        gout = _c(gout)
+        gn = torch.empty_like(nodes)
+        call("mdnvae_outer_sum_bwd", ptr(gout), ptr(nodes), B, R, N, epi_act, ptr(gn), stream())
+        return gn[:, :, :N].contiguous(), None
+
+
+def outer_sum(g, epi_act=None):
+    return _OuterSum.apply(g, ACTS[epi_act] if not isinstance(epi_act, int) else epi_act)
+
+
 class _Exp(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):

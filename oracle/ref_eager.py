@@ -444,3 +444,40 @@ def graph_features(matrix, weighted_paths=True):
     else:
         path = float(np.mean(lengths)) if lengths else 0.0
     return np.array([deg.mean(), deg.std(), clust.mean(), clust.std(), path])
+
+
+# ---- multi-branch ResNet-MLP VAE (function_fc_new/ResNet.py:83-238) -----------------------------
+def _lin(p, name, x):
+    return F.linear(x, p[name + ".weight"], p[name + ".bias"])
+
+
+def _branch_mlp(p, pre, x, n_blocks):
+    h = F.relu(_lin(p, pre + ".init_fc", x))                                   # :124-129
+    for i in range(n_blocks):
+        b = f"{pre}.resblocks.{i}"
+        out = _lin(p, b + ".fc2", F.relu(_lin(p, b + ".fc1", h)))               # :96-106
+        ident = _lin(p, b + ".shortcut", h) if (b + ".shortcut.weight") in p else h
+        h = F.relu(out + ident)
+    return _lin(p, pre + ".final_fc", h)
+
+
+def _branch_gcn(p, pre, x, n_layers, mask=None):
+    h = F.relu(_lin(p, pre + ".init_fc", x))                                   # :141-149
+    for i in range(n_layers):
+        w = p[f"{pre}.gcn_layers.{i}.weight"]
+        if mask is not None:
+            w = w * mask
+        h = F.relu(F.linear(h, w, p[f"{pre}.gcn_layers.{i}.bias"]) + h)
+    return h
+
+
+def resnet_vae_forward(p, x, eps, n_mlp1=8, n_mlp2=8, n_gcn=10, mask=None, n_nodes=68):
+    """function_fc_new/ResNet.py:208-238; returns (recon, mu, logvar, z)."""
+    mu, logvar = fnn_encode(p, x)
+    z = reparameterize(mu, logvar, eps)
+    h = _lin(p, "fc_init_decode", z)
+    d = "multi_branch_decoder"
+    merged = (_branch_mlp(p, d + ".branch_mlp1", h, n_mlp1) + _branch_gcn(p, d + ".branch_gcn", h, n_gcn, mask)
+              + _branch_mlp(p, d + ".branch_mlp2", h, n_mlp2))                  # :174-180
+    outer = (merged.unsqueeze(2) * merged.unsqueeze(1)).reshape(-1, n_nodes * n_nodes)
+    return _lin(p, d + ".final_fc", outer), mu, logvar, z

@@ -355,6 +355,28 @@ def make_fid():
     save("fid", **out)
 
 
+def make_resnet_fc():
+    """function_fc_new/ResNet.py VAE with the constructor arguments of its main() (:250-257)."""
+    x, _ = fc_inputs()
+    ns = load_defs("function_fc_new/ResNet.py", extra=dict(utils=None, loadmat=None))
+    torch.manual_seed(11111)
+    model = ns["VAE"](latent_dim=256, decode_dimen_number_mlp1=8, hidden_dim_mlp1=512, decode_dimen_number_mlp2=8,
+                      hidden_dim_mlp2=256, decode_dimen_number_gcn=10)
+    shapes, bounds = refill(model)
+    xt = torch.from_numpy(x[:B])
+    eps = draw_eps(EPS_SEED, (B, 256))
+    recon, mu, logvar = run_with_eps(model, (xt,), EPS_SEED)
+    loss = ns["loss_function"](recon, xt, mu, logvar)
+    model.zero_grad()
+    loss.backward()
+    z = mu + eps * torch.exp(0.5 * logvar)
+    arrays = dict(x=x[:B], eps=eps.numpy(), mu=mu.detach().numpy(), logvar=logvar.detach().numpy(),
+                  z=z.detach().numpy(), recon=recon.detach().numpy(), loss=np.float64(loss.item()))
+    arrays.update(meta_arrays(shapes, bounds))
+    arrays.update(grads_of(model))
+    save("resnet_fc", **arrays)
+
+
 def make_graphs():
     """Graph features of validation/FID.py (edge 'distance' attached) and of function/VAE_CNN_NN.py
     (no 'distance' attribute: hop counts) on the SBM graphs of validation/FID.py (its own seeds, stored
@@ -431,7 +453,7 @@ def make_prep():
 
 ALL = dict(cnn_nn_sc=make_cnn_nn_sc, cnn_gcn_sc=make_cnn_gcn_sc, cnn_gcn_fc=make_cnn_gcn_fc,
            cnn_nn_fc=make_cnn_nn_fc, mm_gate=make_mm_gate, fnn_gcn_fc=make_fnn_gcn_fc, cvae=make_cvae, ec87=make_ec87,
-           losses=make_losses, fid=make_fid, prep=make_prep, graphs=make_graphs)
+           losses=make_losses, fid=make_fid, prep=make_prep, graphs=make_graphs, resnet_fc=make_resnet_fc)
 
 if __name__ == "__main__":
     torch.set_num_threads(8)

@@ -177,3 +177,18 @@ def test_graph_features_against_networkx_outputs_of_the_reference():
     bits = np.unpackbits(fix["sbm_real_bits"], axis=1)[:, :10000].reshape(-1, 100, 100).astype(np.float64)
     for i in range(0, 50, 10):
         np.testing.assert_allclose(R.graph_features(bits[i], True), fix["sbm_real_features"][i], rtol=2e-5, atol=1e-7)
+
+
+def test_resnet_mlp_vae():
+    """function_fc_new/ResNet.py with the constructor arguments of its main()."""
+    fix = load_fixture("resnet_fc")
+    p = _leaf(fixture_params(fix))
+    x, eps = torch.from_numpy(fix["x"]), torch.from_numpy(fix["eps"])
+    recon, mu, logvar, z = R.resnet_vae_forward(p, x, eps)
+    loss = R.vae_loss(recon, x, mu, logvar, "mse")
+    loss.backward()
+    _close(mu.detach(), fix["mu"], OUT_RTOL, "mu")
+    _close(logvar.detach(), fix["logvar"], OUT_RTOL, "logvar")
+    _close(recon.detach(), fix["recon"], OUT_RTOL, "recon")
+    assert abs(loss.item() - float(fix["loss"])) <= LOSS_RTOL * abs(float(fix["loss"]))
+    _check_grads(fix, p)
