@@ -44,13 +44,17 @@ MODELS = {
 }
 
 
-def build(model_name, n_nodes, device):
+def build(model_name, n_nodes, device, symmetric=True):
+    """`symmetric`: the synthetic connectomes are symmetric like the prepared data of the scripts,
+    so the FNN-encoder models run their first layers on the packed triangle (same sums, half the
+    GEMM work; the symmetry is verified on the device every step and checked after the run)."""
     kw, mode, kind = MODELS[model_name]
     torch.manual_seed(11111)
     if model_name == "mm_gate":
-        model = M.GCNVAE(R=5, n_nodes=n_nodes, k=32, n_layers=3, latent_dim=68)
+        model = M.GCNVAE(R=5, n_nodes=n_nodes, k=32, n_layers=3, latent_dim=68, symmetric_input=symmetric)
     elif model_name == "mdn_gate":
-        model = M.MDNGateVAE(R=5, n_nodes=n_nodes, k=32, n_layers=3, latent_dim=68, n_traits=4)
+        model = M.MDNGateVAE(R=5, n_nodes=n_nodes, k=32, n_layers=3, latent_dim=68, n_traits=4,
+                             symmetric_input=symmetric)
     else:
         model = M.ConvVAE(n_nodes=n_nodes, latent_dim=68, **kw)
     return model.to(device), mode, kind
@@ -173,6 +177,8 @@ ABI_TAGS = {
     "mdnvae_decoder_fwd": ("chain_fwd_mfma_kernel+outer_epilogue_kernel", lambda a: _decoder_work(a, 0)),
     "mdnvae_decoder_bwd": ("outer_grad_kernel+chain_bwd_mfma_kernel", lambda a: _decoder_work(a, 1)),
     "mdnvae_adam_step": ("adam_kernel", lambda a: 28.0 * a[4]),
+    # args: (x, B, N, out, asym, stream): read N*N, write the triangle, per matrix
+    "mdnvae_tri_pack": ("tri_pack_kernel", lambda a: 4.0 * a[1] * (a[2] * a[2] + a[2] * (a[2] + 1) // 2)),
 }
 HBM_TAGS = {v[0] for v in ABI_TAGS.values()}
 
@@ -251,11 +257,11 @@ def kernel_table(clock, elapsed):
 
 
 def run_workload(model_name, batch, nodes, steps, warmup, pool_batches, device, rank, world, use_clock,
-                 overlap=True):
+                 overlap=True, symmetric=True):
     """Warm up, then time exactly `steps` steps between barrier + synchronize pairs; returns
     (elapsed seconds: max over ranks, final loss, kernel clock, wall time of the instrumented pass
     or None, workload description)."""
-    model, mode, kind = build(model_name, nodes, device)
+    model, mode, kind = build(model_name, nodes, device, symmetric)
     gen = M.data.synthetic_sc if kind == "sc" else M.data.synthetic_fc
     # each rank owns its shard of the synthetic subjects (seed differs per rank)
     pool = gen(batch * pool_batches, nodes, seed=1234 + rank, device=device)
@@ -306,8 +312,12 @@ def run_workload(model_name, batch, nodes, steps, warmup, pool_batches, device, 
         clock.records.clear()
         clocked, _ = timed(steps, warmup + steps + 1)
         restore()
+    if hasattr(model, "check_inputs"):
+        model.check_inputs()                     # raises if a batch broke the symmetric-input promise
     what = (f"synthetic {nodes}x{nodes} {kind.upper()} connectomes, {model_name} VAE ({mode} + KL), fwd+bwd+Adam, "
             "data-parallel over subjects")
+    if getattr(model, "symmetric_input", False):
+        what += "; first layers on the packed upper triangle (inputs verified symmetric on the device)"
     return elapsed, float(loss.item()), clock, clocked, what
 
 
@@ -325,6 +335,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-clock", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="all-reduce every gradient after backward")
+    ap.add_argument("--full-first-layer", action="store_true",
+                    help="FNN-encoder models: run the first layers on all N*N entries instead of the packed triangle")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL).  gloo on device tensors "
                                                       "hung in this image when two ranks shared one GPU, so the "
                                                       "multi-rank path is rehearsed on the CPU by tests/test_trainer_cpu.py")
@@ -349,7 +361,8 @@ def main():
     batch = args.batch or default_batch(args.model)
     elapsed, final_loss, clock, clocked, what = run_workload(args.model, batch, args.nodes, args.steps, args.warmup,
                                                              args.pool, device, rank, world,
-                                                             not args.no_kernel_clock, not args.no_overlap)
+                                                             not args.no_kernel_clock, not args.no_overlap,
+                                                             not args.full_first_layer)
     if rank == 0:
         line = {
             "metric": "train samples/sec (fwd+bwd, 87x87 connectome)" if args.nodes == 87 else

@@ -150,6 +150,21 @@ int mdnvae_act_bwd(const float* y, const float* grad_y, float* grad_pre, long n,
 size_t mdnvae_colsum_workspace_floats(int B, int D);
 int mdnvae_colsum(const float* a, int B, int D, float* workspace, float* out, void* stream);
 
+/* ---- first dense layer on symmetric connectomes --------------------------------------------
+ * `self.fc11(x.view(-1, N*N))` (function/MM_Gate.py:157-165; function_FC_SC/SC-FC.py:95-104) sums
+ * w[h,i,j] x[b,i,j] over all N*N entries.  For a symmetric x[b] the same number is the product of
+ * the N(N+1)/2 upper-triangle entries with w[h,i,j] + w[h,j,i], at half the GEMM work, and the
+ * weight gradients of (i,j) and (j,i) are one value.  t(i,j) = i*N - i(i-1)/2 + (j-i), i <= j.
+ * N <= 192. */
+/* out [B,T] = upper triangle of x [B,N,N]; *asym is OR-ed with 1 when some x[b,i,j] != x[b,j,i]
+ * (a NaN counts as different), so that a caller can refuse input the shortcut does not hold for. */
+int mdnvae_tri_pack(const float* x, long B, int N, float* out, int* asym, void* stream);
+/* out [H,T]: out[h,t(i,j)] = w[h,i,j] + w[h,j,i] for i < j, w[h,i,i] on the diagonal. */
+int mdnvae_tri_fold(const float* w, long H, int N, float* out, void* stream);
+/* grad_w [H,N*N]: grad_w[h,i*N+j] = g[t(min(i,j),max(i,j))*stride_t + h*stride_h], g being the
+ * weight gradient of the folded layer stored as [H,T] (stride_t = 1) or [T,H] (stride_h = 1). */
+int mdnvae_tri_unfold(const float* g, long H, int N, long stride_t, long stride_h, float* grad_w, void* stream);
+
 /* ---- conv / ResNet encoder ---------------------------------------------------------------
  * The ATen conv2d / instance_norm / relu / max_pool2d calls (and their autograd) of the encoder
  * stack, function/VAE_CNN_NN.py:83-98 (ResidualBlock), :110-137 (ec, max_pool), :155-159 (encode).

@@ -665,6 +665,9 @@ __global__ __launch_bounds__(WG_NT, 2) void conv_wgrad_kernel(ConvGeom g, const 
 // B operand's address (three row offsets + three column offsets per K step).  A plane whose size is
 // not a multiple of 4 floats starts at a 4-byte phase that differs per channel; the phase is added to
 // the lane's base address.
+#ifndef WGRAD_FLAT_LDS
+#define WGRAD_FLAT_LDS (80 * 1024)
+#endif
 template <int DUMMY>
 __global__ __launch_bounds__(WG_NT, 2) void conv_wgrad_flat_kernel(int B, int Cin, int Cout, int H, int W,
                                                                    const float* __restrict__ x,
@@ -1183,7 +1186,7 @@ int mdnvae_conv2d_wgrad(const float* x, const float* in_stats, int relu_in, cons
         for (int k = 1; k <= H && k * W <= 128; ++k) {
             const int gs = (k * W + 3 + 3) & ~3, ss = ((k + 2) * W + 3 + 3) & ~3;
             const size_t need = ((size_t)2 * 64 * gs + (size_t)2 * 64 * ss) * 4;
-            if (need <= 80 * 1024) { nr = k; GS = gs; SS = ss; lds = need; }
+            if (need <= WGRAD_FLAT_LDS) { nr = k; GS = gs; SS = ss; lds = need; }
         }
         if (nr > 0) {
             static bool once_flat = false;

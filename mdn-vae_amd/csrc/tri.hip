@@ -1,0 +1,148 @@
+// First dense layer on symmetric connectomes.  x.view(-1, N*N) @ W^T (function/MM_Gate.py:157-165,
+// function_FC_SC/SC-FC.py:95-104) sums w[h,i,j] x[b,i,j] over all N*N entries; when x[b] is
+// symmetric the (i,j) and (j,i) terms share their input, so the product over the N(N+1)/2 entries
+// of the upper triangle with the folded weight w[h,i,j] + w[h,j,i] is the same number with half the
+// matrix-core work, and the weight gradient of (i,j) and (j,i) is one value written twice.
+// These kernels do the packing, folding and unfolding around the library GEMMs; the packing
+// kernel also verifies the symmetry it relies on.
+//   t(i,j) = i*N - i(i-1)/2 + (j - i), 0 <= i <= j < N   (row-major walk of the upper triangle)
+#include "common.h"
+#include "../../include/mdnvae_hip.h"
+
+namespace mdnvae {
+
+typedef float tri_v4 __attribute__((ext_vector_type(4)));
+typedef tri_v4 tri_v4u __attribute__((aligned(4)));
+
+__device__ __forceinline__ int tri_index(int i, int j, int N) { return i * N - ((i * (i - 1)) >> 1) + (j - i); }
+
+// One workgroup per matrix (a sample of x, or the weights of one output unit).  The matrix is
+// staged in LDS so that the transposed element comes from LDS (stride N dwords, N odd or even both
+// spread over the banks well enough for a pass that is bound by the global traffic).
+//   FOLD = false: out[t] = m[i][j], *asym |= (m[i][j] != m[j][i])
+//   FOLD = true : out[t] = m[i][j] + m[j][i] (i < j), m[i][i]
+template <bool FOLD>
+__global__ __launch_bounds__(256) void tri_pack_kernel(const float* __restrict__ src, int N, int T,
+                                                       float* __restrict__ out, int* __restrict__ asym) {
+    extern __shared__ float sm[];
+    const int P = N * N;
+    const float* m = src + (long)blockIdx.x * P;
+    float* o = out + (long)blockIdx.x * T;
+    const int P4 = P >> 2;
+    for (int q = threadIdx.x; q < P4; q += 256) {
+        const tri_v4 v = __builtin_nontemporal_load(reinterpret_cast<const tri_v4u*>(m) + q);
+        sm[4 * q] = v.x; sm[4 * q + 1] = v.y; sm[4 * q + 2] = v.z; sm[4 * q + 3] = v.w;
+    }
+    for (int p = (P4 << 2) + threadIdx.x; p < P; p += 256) sm[p] = m[p];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    bool differs = false;
+    for (int i = wid; i < N; i += 4) {
+        const int t0 = tri_index(i, i, N);
+        for (int j = i + lane; j < N; j += 64) {
+            const float a = sm[i * N + j], b = sm[j * N + i];
+            if (FOLD) o[t0 + (j - i)] = (j == i) ? a : a + b;
+            else { o[t0 + (j - i)] = a; differs |= !(a == b); }
+        }
+    }
+    if (!FOLD && differs) atomicOr(asym, 1);
+}
+
+// gw[h][i*N+j] = g[t(min(i,j), max(i,j)) * stride_t + h * stride_h]: a 64 x 64 tile of (p, h) goes
+// through LDS so that both the reads (contiguous along whichever of t / h has stride 1) and the
+// writes (contiguous along p) move whole cache lines.
+constexpr int UF_T = 64;
+__global__ __launch_bounds__(256) void tri_unfold_kernel(const float* __restrict__ g, int H, int N, long stride_t,
+                                                         long stride_h, float* __restrict__ gw) {
+    __shared__ float tile[UF_T][UF_T + 1];          // [p][h]
+    const int P = N * N;
+    const int p0 = blockIdx.x * UF_T, h0 = blockIdx.y * UF_T;
+    const int a = threadIdx.x & 63, b4 = threadIdx.x >> 6;
+    if (stride_h == 1) {                            // g is [T][H]: lanes along h
+        for (int r = b4; r < UF_T; r += 4) {
+            const int p = p0 + r, h = h0 + a;
+            if (p < P && h < H) {
+                const int i = p / N, j = p - i * N;
+                const int t = i <= j ? tri_index(i, j, N) : tri_index(j, i, N);
+                tile[r][a] = g[(long)t * stride_t + h];
+            }
+        }
+    } else {                                        // g is [H][T]: lanes along p
+        const int p = p0 + a;
+        int t = 0;
+        if (p < P) {
+            const int i = p / N, j = p - i * N;
+            t = i <= j ? tri_index(i, j, N) : tri_index(j, i, N);
+        }
+        for (int r = b4; r < UF_T; r += 4) {
+            const int h = h0 + r;
+            if (p < P && h < H) tile[a][r] = g[(long)t * stride_t + (long)h * stride_h];
+        }
+    }
+    __syncthreads();
+    for (int r = b4; r < UF_T; r += 4) {
+        const int h = h0 + r, p = p0 + a;
+        if (h < H && p < P) gw[(long)h * P + p] = tile[a][r];
+    }
+}
+
+}  // namespace mdnvae
+using namespace mdnvae;
+
+extern "C" {
+
+static int tri_launch(bool fold, const float* src, long rows, int N, float* out, int* asym, void* stream,
+                      const char* who) {
+    MV_REQUIRE(rows >= 0 && N >= 1, E_ARG, "%s: bad shape", who);
+    MV_REQUIRE(N <= 192, E_SHAPE, "%s: N = %d exceeds the LDS-resident matrix limit (192)", who, N);
+    MV_REQUIRE(rows <= 0x7fffffffL, E_SHAPE, "%s: too many matrices for one launch", who);
+    if (rows == 0) return 0;
+    MV_REQUIRE(src && out && (fold || asym), E_ARG, "%s: null pointer", who);
+    const int T = N * (N + 1) / 2;
+    const size_t lds = sizeof(float) * (size_t)N * N;
+    if (fold) {
+        if (lds > 64 * 1024) {
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tri_pack_kernel<true>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            MV_REQUIRE(e == hipSuccess, (int)e, "%s: cannot raise the LDS limit: %s", who, hipGetErrorString(e));
+        }
+        hipLaunchKernelGGL(tri_pack_kernel<true>, dim3((unsigned)rows), dim3(256), lds, (hipStream_t)stream, src, N, T,
+                           out, asym);
+    } else {
+        if (lds > 64 * 1024) {
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tri_pack_kernel<false>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            MV_REQUIRE(e == hipSuccess, (int)e, "%s: cannot raise the LDS limit: %s", who, hipGetErrorString(e));
+        }
+        hipLaunchKernelGGL(tri_pack_kernel<false>, dim3((unsigned)rows), dim3(256), lds, (hipStream_t)stream, src, N, T,
+                           out, asym);
+    }
+    MV_LAUNCH_CHECK("tri_pack_kernel");
+    return 0;
+}
+
+int mdnvae_tri_pack(const float* x, long B, int N, float* out, int* asym, void* stream) {
+    return tri_launch(false, x, B, N, out, asym, stream, "mdnvae_tri_pack");
+}
+
+int mdnvae_tri_fold(const float* w, long H, int N, float* out, void* stream) {
+    return tri_launch(true, w, H, N, out, nullptr, stream, "mdnvae_tri_fold");
+}
+
+int mdnvae_tri_unfold(const float* g, long H, int N, long stride_t, long stride_h, float* grad_w, void* stream) {
+    MV_REQUIRE(H >= 0 && N >= 1, E_ARG, "mdnvae_tri_unfold: bad shape");
+    if (H == 0) return 0;
+    MV_REQUIRE(g && grad_w, E_ARG, "mdnvae_tri_unfold: null pointer");
+    MV_REQUIRE(stride_t >= 1 && stride_h >= 1 && (stride_t == 1 || stride_h == 1), E_ARG,
+               "mdnvae_tri_unfold: one of the two strides must be 1");
+    const long P = (long)N * N;
+    MV_REQUIRE(P <= 0x7fffffffL && H <= 0x7fffffffL, E_SHAPE, "mdnvae_tri_unfold: shape too large");
+    const dim3 grid((unsigned)((P + UF_T - 1) / UF_T), (unsigned)((H + UF_T - 1) / UF_T));
+    MV_REQUIRE(grid.y <= 65535, E_SHAPE, "mdnvae_tri_unfold: too many output units for one launch");
+    hipLaunchKernelGGL(tri_unfold_kernel, grid, dim3(256), 0, (hipStream_t)stream, g, (int)H, N, stride_t, stride_h,
+                       grad_w);
+    MV_LAUNCH_CHECK("tri_unfold_kernel");
+    return 0;
+}
+
+}  // extern "C"

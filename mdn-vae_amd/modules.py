@@ -320,9 +320,11 @@ class MultiChannelGCNDecoder(nn.Module):
 class GCNVAE(nn.Module):
     """`VAE` of function/MM_Gate.py:143-177."""
 
-    def __init__(self, R=5, n_nodes=68, k=32, n_layers=3, latent_dim=68):
+    def __init__(self, R=5, n_nodes=68, k=32, n_layers=3, latent_dim=68, symmetric_input=False):
         super().__init__()
         self.n_nodes = n_nodes
+        self.symmetric_input = symmetric_input
+        self.register_buffer("_asym", torch.zeros(1, dtype=torch.int32), persistent=False)
         D = n_nodes * n_nodes
         self.fc11 = Linear(D, 1024)
         self.fc12 = Linear(D, 1024)
@@ -333,9 +335,27 @@ class GCNVAE(nn.Module):
         self.decoder = MultiChannelGCNDecoder(R=R, n_nodes=n_nodes, k=k, n_layers=n_layers, latent_dim=latent_dim)
 
     def encode(self, x):
-        h11 = self.fc111(self.fc11(x, act="relu"), act="relu")
-        h12 = self.fc222(self.fc12(x, act="relu"), act="relu")
+        """`symmetric_input`: the batch is promised to hold symmetric matrices (what the data
+        preparation produces), so both first layers run on the packed upper triangle with folded
+        weights, half the GEMM work for the same sums.  The promise is checked on the device with
+        every batch; `check_inputs()` reports a violation."""
+        if self.symmetric_input:
+            xt = ops.tri_pack(x, self.n_nodes, self._asym)
+            a11 = ops.sym_linear_act(xt, self.fc11.weight, self.fc11.bias, "relu", self.n_nodes)
+            a12 = ops.sym_linear_act(xt, self.fc12.weight, self.fc12.bias, "relu", self.n_nodes)
+        else:
+            a11, a12 = self.fc11(x, act="relu"), self.fc12(x, act="relu")
+        h11 = self.fc111(a11, act="relu")
+        h12 = self.fc222(a12, act="relu")
         return self.fc21(h11), self.fc22(h12)
+
+    def check_inputs(self):
+        """Raises if a batch seen since the last call was not symmetric although the model was
+        built with symmetric_input=True (its outputs for that batch are then wrong).  Reads one
+        integer from the device, so call it where the host synchronises anyway."""
+        if self.symmetric_input and int(self._asym.item()) != 0:
+            self._asym.zero_()
+            raise ValueError("symmetric_input=True, but a batch held a matrix with x[i,j] != x[j,i] (or a NaN)")
 
     def reparameterize(self, mu, logvar, eps=None):
         return ops.reparameterize(mu, logvar, eps)
@@ -356,8 +376,9 @@ class MDNGateVAE(GCNVAE):
     matrices of the GCN decoder are the component means, a linear gate on the subject's traits
     gives the mixture weights, and each component has one learned log-scale."""
 
-    def __init__(self, R=5, n_nodes=68, k=32, n_layers=3, latent_dim=68, n_traits=4):
-        super().__init__(R=R, n_nodes=n_nodes, k=k, n_layers=n_layers, latent_dim=latent_dim)
+    def __init__(self, R=5, n_nodes=68, k=32, n_layers=3, latent_dim=68, n_traits=4, symmetric_input=False):
+        super().__init__(R=R, n_nodes=n_nodes, k=k, n_layers=n_layers, latent_dim=latent_dim,
+                         symmetric_input=symmetric_input)
         self.gate = Linear(n_traits, R)
         self.log_sigma = nn.Parameter(torch.zeros(R))
 

@@ -155,6 +155,56 @@ def linear_act(x, weight, bias=None, act=None):
     return _LinearAct.apply(x, weight, bias, ACTS[act])
 
 
+def tri_pack(x, n_nodes, asym):
+    """Upper triangles [B, N(N+1)/2] of a batch of symmetric matrices x [B, N*N]; `asym` (int32[1]
+    on the device) is OR-ed with 1 if a matrix is not symmetric.  The result carries no gradient:
+    the symmetric first layer is for network inputs."""
+    x = _c(x.detach()).reshape(-1, n_nodes * n_nodes)
+    out = torch.empty(x.shape[0], n_nodes * (n_nodes + 1) // 2, dtype=torch.float32, device=x.device)
+    call("mdnvae_tri_pack", ptr(x, "x"), x.shape[0], n_nodes, ptr(out), asym.data_ptr(), stream())
+    return out
+
+
+class _SymLinearAct(torch.autograd.Function):
+    """act(x @ W^T + b) for symmetric x given as packed upper triangles: the weight is folded onto
+    the triangle (w_ij + w_ji), the two GEMMs run at half the inner / outer dimension, and the
+    folded weight gradient is written back to both (i,j) and (j,i)."""
+
+    @staticmethod
+    def forward(ctx, xt, weight, bias, act, n_nodes):
+        weight = _c(weight)
+        H, T = weight.shape[0], xt.shape[1]
+        wt = torch.empty(H, T, dtype=torch.float32, device=xt.device)
+        call("mdnvae_tri_fold", ptr(weight, "weight"), H, n_nodes, ptr(wt), stream())
+        y = _library_gemm(xt, wt.t())
+        call("mdnvae_bias_act", ptr(y), ptr(bias, "bias"), y.shape[0], y.shape[1], act, stream())
+        ctx.save_for_backward(xt, y)
+        ctx.act, ctx.n_nodes, ctx.has_bias = act, n_nodes, bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        xt, y = ctx.saved_tensors
+        gy = _c(gy)
+        if ctx.act != 0:
+            gpre = torch.empty_like(gy)
+            call("mdnvae_act_bwd", ptr(y), ptr(gy), ptr(gpre), gy.numel(), ctx.act, stream())
+        else:
+            gpre = gy
+        gw = None
+        if ctx.needs_input_grad[1]:
+            H, n = gpre.shape[1], ctx.n_nodes
+            gt = _library_gemm(xt.t(), gpre)                       # [T, H]
+            gw = torch.empty(H, n * n, dtype=torch.float32, device=gy.device)
+            call("mdnvae_tri_unfold", ptr(gt), H, n, H, 1, ptr(gw), stream())
+        gb = _colsum(gpre) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        return None, gw, gb, None, None
+
+
+def sym_linear_act(x_tri, weight, bias=None, act=None, n_nodes=None):
+    return _SymLinearAct.apply(x_tri, weight, bias, ACTS[act], n_nodes)
+
+
 class _AddAct(torch.autograd.Function):
     """act(a + b) with one kernel each way (residual joins)."""
 

@@ -185,7 +185,11 @@ class Trainer:
             if eps_generator is not None:
                 eps = torch.randn(x.shape[0], self._latent_dim(), device=x.device, generator=eps_generator)
             latent += self.step((x,) + tuple(more), y, eps=eps)
-        return float(latent.item()) / n
+        total = float(latent.item())
+        check = getattr(self.model, "check_inputs", None)
+        if check is not None:
+            check()
+        return total / n
 
     def _latent_dim(self):
         m = self.model

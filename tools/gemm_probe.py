@@ -1,6 +1,8 @@
 """Times the library fp32 GEMM layouts for the FNN tower shapes (which layout rocBLAS/hipBLASLt runs fastest)."""
 import torch, sys
-B, D, H = int(sys.argv[1]) if len(sys.argv) > 1 else 8192, 7569, 1024
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
+D = int(sys.argv[2]) if len(sys.argv) > 2 else 7569
+H = int(sys.argv[3]) if len(sys.argv) > 3 else 1024
 x = torch.randn(B, D, device="cuda"); w = torch.randn(H, D, device="cuda") * 0.01; wt = w.t().contiguous()
 g = torch.randn(B, H, device="cuda"); xt = x.t().contiguous()
 def timeit(fn, n=10):
