@@ -87,7 +87,7 @@ def cpu_baseline(model_name, n_nodes, seconds_budget=20.0):
     kw, mode, kind = MODELS[model_name]
     B = 32
     gen = M.data.synthetic_sc if kind == "sc" else M.data.synthetic_fc
-    x = gen(B, n_nodes, seed=1234, device="cpu")
+    x = gen(B, n_nodes, seed=1234, device="cuda").cpu()      # the data preparation itself is a device kernel
     if model_name == "mm_gate":
         ref = M.GCNVAE(R=5, n_nodes=n_nodes, k=32, n_layers=3, latent_dim=68)
         adjacency = knn_adjacency_from(x, n_nodes)
@@ -161,26 +161,40 @@ class KernelClock:
 
 def _decoder_work(args, backward):
     """Algorithmic HBM bytes of one chain-decoder call: the [B,(R,)N*N] matrix it writes (forward) or
-    reads (backward) plus the per-layer rows the backward emits."""
+    reads (backward) - or, when the caller works on the node vectors themselves, those [B,R,NP] -
+    plus the per-layer rows the backward emits."""
     B, N, L, R, NL = args[2 + backward], args[3 + backward], args[4 + backward], args[5 + backward], args[6 + backward]
     components = args[14 + backward]
+    matrix = args[15 + backward]                       # out (forward) / grad_out (backward)
     rows = R if components else 1
-    extra = R * NL * (ops.DEC_KP + ops.DEC_NP) if backward else L
-    return 4.0 * B * (rows * N * N + extra)
+    extra = R * NL * (ops.DEC_KP + ops.DEC_NP) + L if backward else L
+    return 4.0 * B * ((rows * N * N if matrix is not None else 0) + R * ops.DEC_NP + extra)
 
 
-# C-ABI entry point -> (tag = the kernel(s) it launches, work of one call)
+def _mdn_outer_work(a):
+    """(nodes, x, logits, log_sigma, B, K, N, mu, logvar, L, ...): x once, node vectors in, their
+    gradient out, the latent rows in and their gradients out."""
+    B, K, N, L = a[4], a[5], a[6], a[9]
+    return 4.0 * B * (N * N + 2 * K * ops.DEC_NP + 4 * L + 4 * K)
+
+
+# C-ABI entry point -> (tag = the kernel(s) it launches, possibly depending on the arguments; work of one call)
 ABI_TAGS = {
     "mdnvae_vae_loss_fwdbwd": ("loss_stream_kernel", lambda a: 4.0 * a[3] * (3 * a[4] + 4 * a[7])),
     "mdnvae_mdn_loss_fwd": ("mdn_fwd_kernel", lambda a: 4.0 * a[4] * ((a[5] + 1) * a[6] + 2 * a[9] + 3 * a[5])),
     "mdnvae_mdn_loss_bwd": ("mdn_bwd_stream_kernel", lambda a: 4.0 * a[6] * ((2 * a[7] + 1) * a[8] + 4 * a[11] + 5 * a[7])),
-    "mdnvae_decoder_fwd": ("chain_fwd_mfma_kernel+outer_epilogue_kernel", lambda a: _decoder_work(a, 0)),
-    "mdnvae_decoder_bwd": ("outer_grad_kernel+chain_bwd_mfma_kernel", lambda a: _decoder_work(a, 1)),
+    "mdnvae_mdn_outer_fwdbwd": ("mdn_outer_kernel", _mdn_outer_work),
+    "mdnvae_decoder_fwd": (lambda a: "chain_fwd_mfma_kernel+outer_epilogue_kernel" if a[15] is not None
+                           else "chain_fwd_mfma_kernel", lambda a: _decoder_work(a, 0)),
+    "mdnvae_decoder_bwd": (lambda a: "outer_grad_kernel+chain_bwd_mfma_kernel" if a[16] is not None
+                           else "chain_bwd_mfma_kernel", lambda a: _decoder_work(a, 1)),
     "mdnvae_adam_step": ("adam_kernel", lambda a: 28.0 * a[4]),
     # args: (x, B, N, out, asym, stream): read N*N, write the triangle, per matrix
     "mdnvae_tri_pack": ("tri_pack_kernel", lambda a: 4.0 * a[1] * (a[2] * a[2] + a[2] * (a[2] + 1) // 2)),
 }
-HBM_TAGS = {v[0] for v in ABI_TAGS.values()}
+HBM_TAGS = {v[0] for v in ABI_TAGS.values() if isinstance(v[0], str)} | {
+    "chain_fwd_mfma_kernel+outer_epilogue_kernel", "chain_fwd_mfma_kernel", "outer_grad_kernel+chain_bwd_mfma_kernel",
+    "chain_bwd_mfma_kernel"}
 
 
 def install_clock(clock):
@@ -210,6 +224,8 @@ def install_clock(clock):
     def call(fname, *args):
         if fname in ABI_TAGS:
             tag, work = ABI_TAGS[fname]
+            if callable(tag):
+                tag = tag(args)
             return clock.bracket(tag, work(args), lambda: orig_call(fname, *args))
         return orig_call(fname, *args)
 

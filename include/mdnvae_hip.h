@@ -101,7 +101,9 @@ int mdnvae_decoder_unpack_gcn_grad(const float* dwt, const int* adj, int N, int 
  * xlat [B,N] = sum of the first xlat_channels node vectors (the reference returns h1+h2+h3+h4).
  * components = 1: out is [B,R,N*N] with out[b,r] = g_r g_r^T, the per-channel matrices that the
  * trait-gated mixture head uses as component means (no epilogue; build-defined, no reference code).
- * nodes [B,R,MDNVAE_DEC_NP] (required): the final node vectors g_r; the backward takes them back. */
+ * nodes [B,R,MDNVAE_DEC_NP] (required): the final node vectors g_r; the backward takes them back.
+ * out = NULL (no intercept / exp / dropout): only the node vectors are produced, for a caller that
+ * consumes them directly (mdnvae_mdn_outer_fwdbwd). */
 int mdnvae_decoder_fwd(const float* z, const float* wt, int B, int N, int L, int R, int NL, int acts,
                        int epi_act, const float* icpt_w, const float* icpt_b, int do_exp, const float* drop,
                        int xlat_channels, int components, float* out, float* xlat, float* nodes, void* stream);
@@ -113,7 +115,9 @@ size_t mdnvae_decoder_bwd_rows_floats(int B, int R, int NL);
  * from which the packed weight gradient of layer (r,l) is layer_in^T . layer_dpre (a library GEMM);
  * with an intercept, grad_times_act [B,N*N] = (grad_out [*out if do_exp]) * act(sum), whose column
  * sums are the intercept-weight gradient.  grad_out is [B,R,N*N] in component mode.  nodes
- * [B,R,MDNVAE_DEC_NP] are the forward's node vectors, node_grad a workspace of the same size. */
+ * [B,R,MDNVAE_DEC_NP] are the forward's node vectors, node_grad a workspace of the same size.
+ * grad_out = NULL (no intercept / exp / dropout): node_grad is an input, the gradient of the node
+ * vectors (columns >= N zero), and the walk starts from it. */
 int mdnvae_decoder_bwd(const float* z, const float* wt, const float* wn, int B, int N, int L, int R, int NL,
                        int acts, int epi_act, const float* icpt_w, const float* icpt_b, int do_exp,
                        const float* drop, int xlat_channels, int components, const float* grad_out, const float* grad_xlat,
@@ -241,6 +245,16 @@ int mdnvae_mdn_loss_fwd(const float* comp_mean, const float* x, const float* gat
 /* grad_comp [B,K,D], grad_logits [B,K], grad_log_sigma_rows [B,K] (sum over b = gradient of log_sigma),
  * grad_mu/grad_logvar [B,L] (KL part; both or neither); grad_loss = device {g_nll, g_kl} or NULL;
  * workspace of mdnvae_mdn_workspace_bytes(B) bytes; B*K*D < 2^32. */
+/* The same likelihood for rank-one component means m_bk = g_bk g_bk^T given by their node vectors
+ * nodes [B,K,MDNVAE_DEC_NP] (the GCN decoder's channels; N*N = D), forward and backward in one pass
+ * over x: the component matrices and their gradients are never written to memory.  Upstream
+ * gradient 1.  grad_nodes [B,K,MDNVAE_DEC_NP] (columns >= N zero), grad_logits / resp /
+ * grad_log_sigma_rows [B,K], grad_mu / grad_logvar [B,L] (both or neither), loss_out[3] as above;
+ * workspace of mdnvae_mdn_workspace_bytes(B) bytes.  K <= 8, N <= MDNVAE_DEC_NP-1. */
+int mdnvae_mdn_outer_fwdbwd(const float* nodes, const float* x, const float* gate_logits, const float* log_sigma,
+                            int B, int K, int N, const float* mu, const float* logvar, int L, float* grad_nodes,
+                            float* grad_logits, float* grad_log_sigma_rows, float* grad_mu, float* grad_logvar,
+                            float* resp, void* workspace, float* loss_out, void* stream);
 int mdnvae_mdn_loss_bwd(const float* comp_mean, const float* x, const float* gate_logits, const float* log_sigma,
                         const float* resp, const float* sumsq, int B, int K, int D, const float* mu,
                         const float* logvar, int L, const float* grad_loss, float* grad_comp, float* grad_logits,

@@ -662,7 +662,9 @@ int mdnvae_decoder_fwd(const float* z, const float* wt, int B, int N, int L, int
                        int components, float* out, float* xlat, float* nodes, void* stream) {
     if (int rc = check_dec("mdnvae_decoder_fwd", B, N, L, R, NL)) return rc;
     if (B == 0) return 0;
-    MV_REQUIRE(z && wt && out, E_ARG, "mdnvae_decoder_fwd: null pointer");
+    MV_REQUIRE(z && wt, E_ARG, "mdnvae_decoder_fwd: null pointer");
+    MV_REQUIRE(out || (!icpt_w && !do_exp && !drop), E_ARG,
+               "mdnvae_decoder_fwd: node vectors alone (out = NULL) take no intercept, exp or dropout");
     MV_REQUIRE((icpt_w == nullptr) == (icpt_b == nullptr), E_ARG, "mdnvae_decoder_fwd: intercept needs weight and bias");
     MV_REQUIRE(xlat_channels >= 0 && xlat_channels <= R, E_ARG, "mdnvae_decoder_fwd: xlat_channels %d", xlat_channels);
     MV_REQUIRE(!components || (!icpt_w && !do_exp && epi_act == 0), E_ARG,
@@ -682,6 +684,7 @@ int mdnvae_decoder_fwd(const float* z, const float* wt, int B, int N, int L, int
     hipLaunchKernelGGL(chain_fwd_mfma_kernel, dim3(ntiles < 2048 ? ntiles : 2048), dim3(CH_NT), fwd_lds,
                        (hipStream_t)stream, a, z, wt, drop, nodes, xlat_channels ? xlat : nullptr);
     MV_LAUNCH_CHECK("chain_fwd_mfma_kernel");
+    if (!out) return 0;                               // the caller consumes the node vectors itself
     hipLaunchKernelGGL(outer_epilogue_kernel, dim3(wave_grid(components ? (long)B * R : B)), dim3(256), 0,
                        (hipStream_t)stream, a, nodes, icpt_w, icpt_b, (unsigned)(0x100000000ull / (unsigned)N) + 1u, out);
     MV_LAUNCH_CHECK("outer_epilogue_kernel");
@@ -697,7 +700,9 @@ int mdnvae_decoder_bwd(const float* z, const float* wt, const float* wn, int B, 
                        float* node_grad, void* stream) {
     if (int rc = check_dec("mdnvae_decoder_bwd", B, N, L, R, NL)) return rc;
     if (B == 0) return 0;
-    MV_REQUIRE(z && wt && wn && grad_out && grad_z && layer_in && layer_dpre, E_ARG, "mdnvae_decoder_bwd: null pointer");
+    MV_REQUIRE(z && wt && wn && grad_z && layer_in && layer_dpre, E_ARG, "mdnvae_decoder_bwd: null pointer");
+    MV_REQUIRE(grad_out || (!icpt_w && !do_exp && !drop), E_ARG,
+               "mdnvae_decoder_bwd: a node-vector gradient (grad_out = NULL) takes no intercept, exp or dropout");
     MV_REQUIRE((icpt_w == nullptr) == (icpt_b == nullptr), E_ARG, "mdnvae_decoder_bwd: intercept needs weight and bias");
     MV_REQUIRE(!icpt_w || grad_times_act, E_ARG, "mdnvae_decoder_bwd: intercept gradient needs grad_times_act");
     MV_REQUIRE(!components || (!icpt_w && !do_exp && epi_act == 0), E_ARG,
@@ -715,7 +720,9 @@ int mdnvae_decoder_bwd(const float* z, const float* wt, const float* wn, int B, 
         attr_set = true;
     }
     hipStream_t st = (hipStream_t)stream;
-    if (components) {
+    if (!grad_out) {
+        // node_grad already holds the gradient of the node vectors
+    } else if (components) {
         hipLaunchKernelGGL(outer_grad_kernel<true>, dim3(wave_grid((long)B * R)), dim3(256), 0, st, a, grad_out, nodes,
                            icpt_w, icpt_b, drop, grad_times_act, node_grad);
     } else {

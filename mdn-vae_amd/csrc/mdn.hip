@@ -261,6 +261,124 @@ __global__ __launch_bounds__(MDN_NT) void mdn_bwd_stream_kernel(const float* __r
     }
 }
 
+// Rank-one components: m_bk = g_bk g_bk^T from the node vectors of the GCN decoder.  One wave per
+// sample reads x[b] once, MO_ROWS rows in flight, lane c owning columns c and c+64; for every
+// component the residual r_ij = g_i g_j - x_ij is formed in registers and feeds, in the same sweep,
+//   ss_k  = sum_ij r_ij^2                      (the exponent of the likelihood),
+//   v_k[c] = sum_i r_ic g_i                    (column sums, per lane),
+//   u_k[i] = sum_j r_ij g_j                    (row sums, DPP wave reduction, total in lane 63),
+// so that after the log-sum-exp over the K components the gradient of the node vectors is
+// coef_bk (u_k + v_k) with coef_bk = resp_bk / sigma_k^2: the [B,K,N*N] component matrices, their
+// gradient and the passes over them do not exist.  The same wave does the sample's KL part.
+constexpr int MO_ROWS = 8;
+constexpr int MO_NP = MDNVAE_DEC_NP;
+template <int K>
+__global__ __launch_bounds__(MDN_NT) void mdn_outer_kernel(const float* __restrict__ nodes, const float* __restrict__ x,
+                                                           const float* __restrict__ logits,
+                                                           const float* __restrict__ log_sigma, int B, int N,
+                                                           const float* __restrict__ mu, const float* __restrict__ logvar,
+                                                           int L, float* __restrict__ gnodes, float* __restrict__ glogits,
+                                                           float* __restrict__ glsig_rows, float* __restrict__ gmu,
+                                                           float* __restrict__ glogvar, float* __restrict__ resp,
+                                                           double* __restrict__ per_sample) {
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * (MDN_NT / 64) + (threadIdx.x >> 6);
+    const int nwaves = gridDim.x * (MDN_NT / 64);
+    const int D = N * N;
+    const bool c0 = lane < N, c1 = lane + 64 < N;
+    for (int b = wave; b < B; b += nwaves) {
+        const float* X = x + (long)b * D;
+        const float* gv = nodes + (long)b * K * MO_NP;
+        float g0[K], g1[K], v0[K], v1[K], u0[K], u1[K], ss[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            g0[k] = c0 ? gv[k * MO_NP + lane] : 0.0f;
+            g1[k] = c1 ? gv[k * MO_NP + lane + 64] : 0.0f;
+            v0[k] = v1[k] = u0[k] = u1[k] = ss[k] = 0.0f;
+        }
+        for (int i0 = 0; i0 < N; i0 += MO_ROWS) {
+            float a0[MO_ROWS], a1[MO_ROWS];
+#pragma unroll
+            for (int q = 0; q < MO_ROWS; ++q) {
+                const bool live_row = i0 + q < N;
+                a0[q] = (live_row && c0) ? __builtin_nontemporal_load(X + (i0 + q) * N + lane) : 0.0f;
+                a1[q] = (live_row && c1) ? __builtin_nontemporal_load(X + (i0 + q) * N + lane + 64) : 0.0f;
+            }
+#pragma unroll
+            for (int q = 0; q < MO_ROWS; ++q) {
+                const int i = i0 + q;                               // uniform over the wave
+                if (i < N) {
+#pragma unroll
+                    for (int k = 0; k < K; ++k) {
+                        const float gi = __int_as_float(__builtin_amdgcn_readlane(
+                            __float_as_int(i < 64 ? g0[k] : g1[k]), i & 63));
+                        // dead lanes hold g = 0 and x = 0, so their residual is 0 without a select
+                        const float r0 = gi * g0[k] - a0[q], r1 = gi * g1[k] - a1[q];
+                        ss[k] += r0 * r0 + r1 * r1;
+                        v0[k] += r0 * gi;
+                        v1[k] += r1 * gi;
+                        const float p = wave_sum_dpp(r0 * g0[k] + r1 * g1[k]);
+                        const float tot = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p), 63));
+                        if (i < 64) u0[k] = (lane == i) ? tot : u0[k];
+                        else u1[k] = (lane == i - 64) ? tot : u1[k];
+                    }
+                }
+            }
+        }
+        float ssk = 0.0f;                                           // lane k < K owns component k
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const float v = wave_sum_all(ss[k]);
+            if (lane == k) ssk = v;
+        }
+        float kl = 0.0f;
+        for (int i = lane; i < L; i += 64) {
+            const long j = (long)b * L + i;
+            const float m = mu[j], lv = logvar[j];
+            const float e = expf(lv);
+            kl += -0.5f * (1.0f + lv - m * m - e);
+            if (gmu) {
+                gmu[j] = m;
+                glogvar[j] = 0.5f * (e - 1.0f);
+            }
+        }
+        kl = wave_sum_all(kl);
+        float a = -INFINITY, gl = -INFINITY, is2 = 0.0f, pi = 0.0f;
+        if (lane < K) gl = logits[(long)b * K + lane];
+        const float gmax = wave_max_all(gl);
+        const float gsum = wave_sum_all(lane < K ? expf(gl - gmax) : 0.0f);
+        if (lane < K) {
+            const float ls = log_sigma[lane];
+            const float logpi = gl - gmax - logf(gsum);
+            is2 = expf(-2.0f * ls);
+            pi = expf(logpi);
+            a = logpi - 0.5f * ssk * is2 - (float)D * (ls + 0.5f * LOG_2PI);
+        }
+        const float amax = wave_max_all(a);
+        const float asum = wave_sum_all(lane < K ? expf(a - amax) : 0.0f);
+        const float lse = amax + logf(asum);
+        float coef = 0.0f;
+        if (lane < K) {
+            const float r = expf(a - lse);
+            coef = r * is2;
+            resp[(long)b * K + lane] = r;
+            glogits[(long)b * K + lane] = pi - r;
+            glsig_rows[(long)b * K + lane] = r * ((float)D - ssk * is2);
+        }
+        if (lane == 0) {
+            per_sample[2 * b] = -(double)lse;
+            per_sample[2 * b + 1] = (double)kl;
+        }
+        float* dst = gnodes + (long)b * K * MO_NP;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const float ck = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(coef), k));
+            dst[k * MO_NP + lane] = c0 ? ck * (u0[k] + v0[k]) : 0.0f;
+            if (lane + 64 < MO_NP) dst[k * MO_NP + lane + 64] = c1 ? ck * (u1[k] + v1[k]) : 0.0f;
+        }
+    }
+}
+
 }  // namespace mdnvae
 using namespace mdnvae;
 
@@ -279,6 +397,11 @@ using namespace mdnvae;
 #ifndef MDN_MAX_BLOCKS_N
 #define MDN_MAX_BLOCKS_N 1024
 #endif
+// one wave per sample, every wave resident at once where the batch allows it
+static unsigned mdn_outer_grid(int B) {
+    const int blocks = (B + MDN_NT / 64 - 1) / (MDN_NT / 64);
+    return (unsigned)(blocks < 2048 ? blocks : 2048);
+}
 static unsigned mdn_grid(int B) {
     const int blocks = (B + MDN_NT / 64 - 1) / (MDN_NT / 64);
     return (unsigned)(blocks < MDN_MAX_BLOCKS_N ? blocks : MDN_MAX_BLOCKS_N);
@@ -307,6 +430,35 @@ int mdnvae_mdn_loss_fwd(const float* comp_mean, const float* x, const float* gat
         MV_MDN_DISPATCH(K, CALL)
 #undef CALL
         MV_LAUNCH_CHECK("mdn_fwd_kernel");
+    }
+    hipLaunchKernelGGL(mdn_finalize_kernel, dim3(1), dim3(256), 0, st, (const double*)workspace, B, loss_out);
+    MV_LAUNCH_CHECK("mdn_finalize_kernel");
+    return 0;
+}
+
+int mdnvae_mdn_outer_fwdbwd(const float* nodes, const float* x, const float* gate_logits, const float* log_sigma,
+                            int B, int K, int N, const float* mu, const float* logvar, int L, float* grad_nodes,
+                            float* grad_logits, float* grad_log_sigma_rows, float* grad_mu, float* grad_logvar,
+                            float* resp, void* workspace, float* loss_out, void* stream) {
+    MV_REQUIRE(B >= 0 && L >= 0, E_ARG, "mdnvae_mdn_outer_fwdbwd: bad size");
+    MV_REQUIRE(N >= 1 && N <= MO_NP - 1, E_SHAPE, "mdnvae_mdn_outer_fwdbwd: N = %d outside 1..%d", N, MO_NP - 1);
+    MV_REQUIRE(K >= 1 && K <= MDN_MAXK, E_SHAPE, "mdnvae_mdn_outer_fwdbwd: %d components (1..%d supported)", K,
+               MDN_MAXK);
+    MV_REQUIRE(workspace && loss_out, E_ARG, "mdnvae_mdn_outer_fwdbwd: workspace/loss_out is null");
+    hipStream_t st = (hipStream_t)stream;
+    if (B > 0) {
+        MV_REQUIRE(nodes && x && gate_logits && log_sigma && grad_nodes && grad_logits && grad_log_sigma_rows && resp,
+                   E_ARG, "mdnvae_mdn_outer_fwdbwd: null pointer");
+        MV_REQUIRE(L == 0 || (mu && logvar), E_ARG, "mdnvae_mdn_outer_fwdbwd: mu/logvar is null");
+        MV_REQUIRE((grad_mu == nullptr) == (grad_logvar == nullptr), E_ARG,
+                   "mdnvae_mdn_outer_fwdbwd: grad_mu and grad_logvar come together");
+#define CALL(KK)                                                                                                     \
+    hipLaunchKernelGGL((mdn_outer_kernel<KK>), dim3(mdn_outer_grid(B)), dim3(MDN_NT), 0, st, nodes, x, gate_logits,  \
+                       log_sigma, B, N, mu, logvar, L, grad_nodes, grad_logits, grad_log_sigma_rows, grad_mu,        \
+                       grad_logvar, resp, (double*)workspace)
+        MV_MDN_DISPATCH(K, CALL)
+#undef CALL
+        MV_LAUNCH_CHECK("mdn_outer_kernel");
     }
     hipLaunchKernelGGL(mdn_finalize_kernel, dim3(1), dim3(256), 0, st, (const double*)workspace, B, loss_out);
     MV_LAUNCH_CHECK("mdn_finalize_kernel");

@@ -303,6 +303,17 @@ class MultiChannelGCNDecoder(nn.Module):
         out, _ = ops.chain_decoder(z, self._comp_spec, self.chain_params())
         return out
 
+    def node_vectors(self, z, adjacency):
+        """The channels' node vectors g_r [B,R,NP] alone (columns >= n_nodes are padding): what the
+        mixture likelihood needs when it forms g_r g_r^T on the fly."""
+        self._adjacency(adjacency, z.device)
+        if getattr(self, "_node_spec", None) is None or self._node_spec_src is not self._spec:
+            sp = self._spec
+            self._node_spec = ops.ChainSpec(sp.N, sp.L, sp.R, sp.layers, epi_act=None, xlat_channels=0, nodes_only=True)
+            self._node_spec_src = sp
+        out, _ = ops.chain_decoder(z, self._node_spec, self.chain_params())
+        return out
+
     def chain_params(self):
         params = []
         for r in range(self.R):
@@ -382,15 +393,23 @@ class MDNGateVAE(GCNVAE):
         self.gate = Linear(n_traits, R)
         self.log_sigma = nn.Parameter(torch.zeros(R))
 
-    def forward(self, x, adjacency, traits, eps=None):
+    def forward(self, x, adjacency, traits, eps=None, nodes_only=False):
+        """(component means [B,R,N*N], gate logits, mu, logvar); with nodes_only the first entry is
+        the node vectors [B,R,NP] whose outer products the component means are, for
+        `loss_from_nodes` / the trainer's fused step, which never write the matrices out."""
         x = x.reshape(-1, self.n_nodes * self.n_nodes)
         mu, logvar = self.encode(x)
         z = self.reparameterize(mu, logvar, eps)
-        comp = self.decoder.components(z, adjacency)
+        comp = self.decoder.node_vectors(z, adjacency) if nodes_only else self.decoder.components(z, adjacency)
         return comp, self.gate(traits), mu, logvar
 
     def loss(self, comp, gate_logits, x, mu, logvar):
         return ops.mdn_loss(comp, x, gate_logits, self.log_sigma, mu, logvar)
+
+    def loss_from_nodes(self, nodes, gate_logits, x, mu, logvar):
+        """`loss` of the component means g_r g_r^T without materialising them."""
+        x = x.reshape(-1, self.n_nodes * self.n_nodes)
+        return ops.mdn_outer_loss_terms(nodes, x, gate_logits, self.log_sigma, mu, logvar, self.n_nodes)[0]
 
     def expected(self, comp, gate_logits):
         """Mixture mean sum_k pi_k m_k [B, N*N] (a library batched GEMM over the K components)."""

@@ -347,7 +347,7 @@ class ChainSpec:
     layers[l] = dict(kind='linear'|'gcn', act=..., mask=Tensor|None, adj=IntTensor|None)."""
 
     def __init__(self, n_nodes, latent_dim, channels, layers, epi_act=None, xlat_channels=0, do_exp=False,
-                 components=False):
+                 components=False, nodes_only=False):
         self.N, self.L, self.R = int(n_nodes), int(latent_dim), int(channels)
         self.layers = layers
         self.NL = len(layers)
@@ -355,6 +355,7 @@ class ChainSpec:
         self.xlat_channels = int(xlat_channels)
         self.do_exp = bool(do_exp)
         self.components = bool(components)
+        self.nodes_only = bool(nodes_only)      # the decoder returns its node vectors [B,R,NP], no matrices
         self.acts = 0
         for l, ly in enumerate(layers):
             a = ACTS[ly.get("act")]
@@ -395,7 +396,12 @@ class _ChainDecoder(torch.autograd.Function):
         dev = z.device
         wt, wn = _pack_panels(spec, params, dev)
         D = spec.N * spec.N
-        out = torch.empty((B, spec.R, D) if spec.components else (B, D), dtype=torch.float32, device=dev)
+        if spec.nodes_only:
+            if icpt_w is not None or drop is not None or spec.do_exp:
+                raise RuntimeError("decoder: node vectors alone take no intercept, exp or dropout")
+            out = None
+        else:
+            out = torch.empty((B, spec.R, D) if spec.components else (B, D), dtype=torch.float32, device=dev)
         xlat = torch.empty(B, spec.N, dtype=torch.float32, device=dev) if spec.xlat_channels else None
         nodes = torch.empty(B, spec.R, DEC_NP, dtype=torch.float32, device=dev)
         call("mdnvae_decoder_fwd", ptr(z, "z"), ptr(wt), B, spec.N, spec.L, spec.R, spec.NL, spec.acts, spec.epi_act,
@@ -407,7 +413,7 @@ class _ChainDecoder(torch.autograd.Function):
         if xlat is None:
             xlat = torch.zeros(B, 0, dtype=torch.float32, device=dev)
             ctx.mark_non_differentiable(xlat)
-        return out, xlat
+        return (nodes if spec.nodes_only else out), xlat
 
     @staticmethod
     def backward(ctx, gout, gxlat):
@@ -425,7 +431,10 @@ class _ChainDecoder(torch.autograd.Function):
         dp = torch.empty(RL, B, DEC_NP, dtype=torch.float32, device=dev)
         gz = torch.empty_like(z)
         ga = torch.empty_like(gout) if icpt_w is not None else None
-        node_grad = torch.empty_like(nodes)
+        if spec.nodes_only:                      # gout is the gradient of the node vectors themselves
+            node_grad, gout = gout, None
+        else:
+            node_grad = torch.empty_like(nodes)
         call("mdnvae_decoder_bwd", ptr(z), ptr(wt), ptr(wn), B, spec.N, spec.L, spec.R, spec.NL, spec.acts,
              spec.epi_act, ptr(icpt_w), ptr(icpt_b), int(spec.do_exp), ptr(drop), spec.xlat_channels,
              int(spec.components), ptr(gout),
@@ -702,6 +711,57 @@ def mdn_loss_terms(comp_mean, x, gate_logits, log_sigma, mu, logvar):
 
 def mdn_loss(comp_mean, x, gate_logits, log_sigma, mu, logvar):
     return mdn_loss_terms(comp_mean, x, gate_logits, log_sigma, mu, logvar)[0]
+
+
+def _mdn_outer_call(nodes, x, logits, log_sigma, mu, logvar, n_nodes):
+    nodes, x, logits, log_sigma, mu, logvar = (_c(t) for t in (nodes, x, logits, log_sigma, mu, logvar))
+    if nodes.dim() != 3 or nodes.shape[2] != DEC_NP:
+        raise RuntimeError(f"mdn outer loss: nodes {tuple(nodes.shape)} must be [B,K,{DEC_NP}]")
+    B, K, _ = nodes.shape
+    if x.shape != (B, n_nodes * n_nodes) or logits.shape != (B, K) or log_sigma.shape != (K,):
+        raise RuntimeError("mdn outer loss: x must be [B,N*N], gate_logits [B,K], log_sigma [K]")
+    dev = nodes.device
+    out = torch.empty(3, dtype=torch.float32, device=dev)
+    resp = torch.empty(B, K, dtype=torch.float32, device=dev)
+    gnodes = torch.empty_like(nodes)
+    glogits = torch.empty_like(logits)
+    gls_rows = torch.empty_like(logits)
+    gmu, glv = torch.empty_like(mu), torch.empty_like(mu)
+    ws = torch.empty(_lib.load().mdnvae_mdn_workspace_bytes(B), dtype=torch.uint8, device=dev)
+    call("mdnvae_mdn_outer_fwdbwd", ptr(nodes, "nodes"), ptr(x, "x"), ptr(logits, "gate_logits"),
+         ptr(log_sigma, "log_sigma"), B, K, n_nodes, ptr(mu, "mu"), ptr(logvar, "logvar"), mu.shape[1], ptr(gnodes),
+         ptr(glogits), ptr(gls_rows), ptr(gmu), ptr(glv), ptr(resp), ws.data_ptr(), ptr(out), stream())
+    gls = _colsum(gls_rows) if B > 0 else torch.zeros_like(log_sigma)
+    return out, gnodes, glogits, gls, gmu, glv, resp
+
+
+def mdn_outer_loss_and_grads(nodes, x, gate_logits, log_sigma, mu, logvar, n_nodes):
+    """The mixture likelihood + KL for component means g_k g_k^T given by their node vectors
+    nodes [B,K,NP] (chain decoder with nodes_only), and the gradients of the total (upstream 1),
+    from one pass over x: (terms[3], g_nodes, g_logits, g_log_sigma, g_mu, g_logvar)."""
+    with torch.no_grad():
+        return _mdn_outer_call(nodes, x, gate_logits, log_sigma, mu, logvar, n_nodes)[:6]
+
+
+class _MdnOuterLoss(torch.autograd.Function):
+    """Differentiable form of the above: the pass runs in forward, backward scales what it saved."""
+
+    @staticmethod
+    def forward(ctx, nodes, x, logits, log_sigma, mu, logvar, n_nodes):
+        out, gnodes, glogits, gls, gmu, glv, _ = _mdn_outer_call(nodes, x, logits, log_sigma, mu, logvar, n_nodes)
+        ctx.save_for_backward(gnodes, glogits, gls, gmu, glv)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        gnodes, glogits, gls, gmu, glv = ctx.saved_tensors
+        g_nll, g_kl = gout[0] + gout[1], gout[0] + gout[2]
+        return gnodes * g_nll, None, glogits * g_nll, gls * g_nll, gmu * g_kl, glv * g_kl, None
+
+
+def mdn_outer_loss_terms(nodes, x, gate_logits, log_sigma, mu, logvar, n_nodes):
+    out = _MdnOuterLoss.apply(nodes, x, gate_logits, log_sigma, mu, logvar, n_nodes)
+    return out[0], out[1], out[2]
 
 
 def softmax_rows(logits):

@@ -113,6 +113,16 @@ class Trainer:
         loss_mode "mdn" trains a model whose forward returns (component means, gate logits, mu,
         logvar) and whose .loss() is the trait-gated mixture likelihood + KL."""
         self.buf.zero_grad()
+        if self.loss_mode == "mdn" and self.fused_loss:
+            # rank-one component means: likelihood, KL and all their gradients from one pass over
+            # the target, straight from the decoder's node vectors
+            m = self.model
+            nodes, gate_logits, mu, logvar = m(*inputs, eps=eps, nodes_only=True)
+            terms, g_nodes, g_logits, g_ls, g_mu, g_lv = ops.mdn_outer_loss_and_grads(
+                nodes.detach(), target.reshape(target.shape[0], -1), gate_logits.detach(), m.log_sigma.detach(),
+                mu.detach(), logvar.detach(), m.n_nodes)
+            torch.autograd.backward([nodes, gate_logits, mu, logvar, m.log_sigma], [g_nodes, g_logits, g_mu, g_lv, g_ls])
+            return terms[0]
         out = self.model(*inputs, eps=eps)
         if self.loss_mode == "mdn":
             comp, gate_logits, mu, logvar = out

@@ -92,3 +92,84 @@ def test_mdn_gate_vae_end_to_end_against_oracle():
     mean = model.expected(comp, logits)
     want_mean = (torch.softmax(logit_c, dim=1).unsqueeze(2) * comp_c).sum(dim=1)
     assert _rel(mean, want_mean) <= 1e-5
+
+
+def _outer_oracle(nodes, x, logits, log_sigma, mu, lv, n):
+    """float64 restatement of the rank-one mixture: component k is g_k g_k^T."""
+    g = nodes[:, :, :n]
+    comp = (g.unsqueeze(3) * g.unsqueeze(2)).reshape(g.shape[0], g.shape[1], n * n)
+    return R.mdn_nll(comp, log_sigma, logits, x) + R.kl_term(mu, lv)
+
+
+@pytest.mark.parametrize("B,K,n,L", [(6, 5, 87, 68), (5, 5, 68, 68), (3, 1, 5, 2), (4, 8, 95, 7), (2, 3, 64, 4), (0, 5, 9, 3)])
+def test_rank_one_mixture_from_node_vectors_against_oracle(B, K, n, L):
+    """One-pass likelihood + gradients from node vectors against the float64 oracle, for a
+    general (not symmetric) target; the padding columns of the node gradient are zero."""
+    torch.manual_seed(100 * B + n)
+    NP = 96
+    nodes = torch.zeros(B, K, NP)
+    nodes[:, :, :n] = torch.rand(B, K, n) * 0.8 + 0.1
+    x = torch.rand(B, n * n)
+    logits = torch.randn(B, K)
+    ls = torch.randn(K) * 0.2 + 1.5            # broad components: responsibilities stay mixed
+    mu, lv = torch.randn(B, L) * 0.3, torch.randn(B, L) * 0.2
+    terms, g_nodes, g_logits, g_ls, g_mu, g_lv = M.ops.mdn_outer_loss_and_grads(
+        nodes.to(DEV), x.to(DEV), logits.to(DEV), ls.to(DEV), mu.to(DEV), lv.to(DEV), n)
+    if B == 0:
+        assert terms.tolist() == [0.0, 0.0, 0.0]
+        return
+    leaves = [t.double().requires_grad_(True) for t in (nodes, logits, ls, mu, lv)]
+    want = _outer_oracle(leaves[0], x.double(), leaves[1], leaves[2], leaves[3], leaves[4], n)
+    want.backward()
+    assert abs(terms[0].item() - want.item()) <= 1e-5 * abs(want.item())
+    assert abs((terms[1] + terms[2]).item() - terms[0].item()) <= 1e-5 * abs(terms[0].item())
+    for got, leaf, name in zip((g_nodes, g_logits, g_ls, g_mu, g_lv), leaves, ("nodes", "logits", "log_sigma", "mu", "logvar")):
+        assert _rel(got, leaf.grad) <= 1e-4, name
+    assert float(g_nodes[:, :, n:].abs().max()) == 0.0
+
+
+def test_rank_one_mixture_matches_the_materialised_path_and_scales_with_upstream():
+    torch.manual_seed(3)
+    B, K, n, L = 7, 5, 68, 68
+    nodes = torch.zeros(B, K, 96)
+    nodes[:, :, :n] = torch.rand(B, K, n)
+    x = torch.rand(B, n * n)
+    logits, ls = torch.randn(B, K), torch.full((K,), 1.2)
+    mu, lv = torch.randn(B, L) * 0.1, torch.randn(B, L) * 0.1
+    nd = nodes.to(DEV).requires_grad_(True)
+    lg = logits.to(DEV).requires_grad_(True)
+    t = M.ops.mdn_outer_loss_terms(nd, x.to(DEV), lg, ls.to(DEV), mu.to(DEV), lv.to(DEV), n)
+    (2.0 * t[1] + 0.5 * t[2]).backward()
+    g = nd.detach()[:, :, :n]
+    comp = (g.unsqueeze(3) * g.unsqueeze(2)).reshape(B, K, n * n).contiguous().requires_grad_(True)
+    lg2 = logits.to(DEV).requires_grad_(True)
+    t2 = M.ops.mdn_loss_terms(comp, x.to(DEV), lg2, ls.to(DEV), mu.to(DEV), lv.to(DEV))
+    (2.0 * t2[1] + 0.5 * t2[2]).backward()
+    for a, b in zip(t, t2):
+        assert abs(a.item() - b.item()) <= 2e-6 * abs(b.item())
+    assert _rel(lg.grad, lg2.grad) <= 1e-5
+    # chain rule through the outer product by hand: dg = (G + G^T) g
+    G = comp.grad.reshape(B, K, n, n)
+    want = torch.einsum("bkij,bkj->bki", G + G.transpose(2, 3), g)
+    assert _rel(nd.grad[:, :, :n], want) <= 1e-5
+
+
+def test_mdn_trainer_fused_and_materialised_steps_agree():
+    """Trainer(loss_mode='mdn'): the fused step (node vectors -> one-pass likelihood) and the step
+    through the materialised component matrices give the same loss and the same gradients."""
+    fix = load_fixture("mm_gate")
+    params = fixture_params(fix)
+    x = torch.from_numpy(fix["x"]).to(DEV)
+    eps = torch.from_numpy(fix["eps"]).to(DEV)
+    traits = torch.randn(x.shape[0], 4, generator=torch.Generator().manual_seed(1)).to(DEV)
+    adjacency = [list(map(int, r)) for r in fix["adjacency"]]
+    got = {}
+    for fused in (False, True):
+        torch.manual_seed(5)
+        model = M.MDNGateVAE(R=5, n_nodes=68, k=32, n_layers=3, latent_dim=68, n_traits=4)
+        model.load_state_dict(params, strict=False)
+        trainer = M.Trainer(model.to(DEV), "mdn", fused_loss=fused)
+        loss = trainer.forward_backward((x, adjacency, traits), x, eps=eps)
+        got[fused] = (loss.item(), trainer.buf.flat_g.clone())
+    assert abs(got[True][0] - got[False][0]) <= 1e-5 * abs(got[False][0])
+    assert _rel(got[True][1], got[False][1]) <= 1e-4
