@@ -94,6 +94,16 @@ int mdnvae_decoder_unpack_linear_grad(const float* dwt, const float* mask, int n
 int mdnvae_decoder_unpack_gcn_grad(const float* dwt, const int* adj, int N, int kn, float* dw, float* db,
                                    void* stream);
 
+/* The same for all count = R*NL layers of a decoder in one launch each way.  HOST arrays of length
+ * count, layer (r,l) at r*NL+l: kind (0 = Linear, 1 = GCN layer), device pointers w / bias (or NULL) /
+ * aux (Linear: mask or NULL; GCN: adjacency), n_out and k (the weight is [n_out,k]).  wt / wn / dwt
+ * are the whole panels; dw / db (or NULL) the per-layer gradient buffers.  count <= 32. */
+int mdnvae_decoder_pack_layers(int count, const int* kind, const void* const* w, const void* const* bias,
+                               const void* const* aux, const int* n_out, const int* k, float* wt, float* wn,
+                               void* stream);
+int mdnvae_decoder_unpack_layer_grads(int count, const int* kind, const float* dwt, const void* const* aux,
+                                      const int* n_out, const int* k, void* const* dw, void* const* db, void* stream);
+
 /* acts: activation code of layer l in bits [2l, 2l+1]; epi_act: activation applied to the sum of
  * outer products; icpt_w/icpt_b [N*N] (both or neither): out = out*icpt_w + icpt_b (the GraphCNN
  * intercept with identity mask, function/VAE-CNN-GCN.py:150,184,219-220); do_exp: out = exp(out);

@@ -112,6 +112,72 @@ __global__ void unpack_gcn_grad_kernel(const float* __restrict__ dwt, const int*
     if (db && idx < N) db[idx] = dwt[(KP - 1) * NP + idx];
 }
 
+// Every layer of a decoder in one launch: the per-layer pointers travel by value in the kernel
+// arguments, blockIdx.y picks the layer.  kind 0 = Linear (aux = mask or NULL), 1 = GCN layer
+// (aux = adjacency).
+constexpr int MAX_LAYERS = 32;
+struct PackTable {
+    const float* w[MAX_LAYERS];
+    const float* bias[MAX_LAYERS];
+    const void* aux[MAX_LAYERS];
+    int n_out[MAX_LAYERS], k[MAX_LAYERS], kind[MAX_LAYERS];
+};
+__global__ __launch_bounds__(256) void pack_layers_kernel(PackTable t, float* __restrict__ wt, float* __restrict__ wn) {
+    const int ly = blockIdx.y;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= KP * NP) return;
+    const float* __restrict__ w = t.w[ly];
+    const float* __restrict__ bias = t.bias[ly];
+    const int n_out = t.n_out[ly], K = t.k[ly];
+    const int k = idx / NP, n = idx - k * NP;
+    float v = 0.0f;
+    if (n < n_out) {
+        if (k == KP - 1) {
+            v = bias ? bias[n] : 0.0f;
+        } else if (t.kind[ly] == 0) {
+            if (k < K) {
+                v = w[n * K + k];
+                const float* mask = static_cast<const float*>(t.aux[ly]);
+                if (mask) v *= mask[n * K + k];
+            }
+        } else if (k < n_out) {
+            const int* adj = static_cast<const int*>(t.aux[ly]);
+            for (int j = 0; j < K; ++j)
+                if (adj[n * K + j] == k) v += w[n * K + j];
+        }
+    }
+    const long base = (long)ly * KP * NP;
+    wt[base + k * NP + n] = v;
+    wn[base + n * KP + k] = (k == KP - 1) ? 0.0f : v;
+}
+
+struct UnpackTable {
+    float* dw[MAX_LAYERS];
+    float* db[MAX_LAYERS];
+    const void* aux[MAX_LAYERS];
+    int n_out[MAX_LAYERS], k[MAX_LAYERS], kind[MAX_LAYERS];
+};
+__global__ __launch_bounds__(256) void unpack_layers_kernel(UnpackTable t, const float* __restrict__ dwt_all) {
+    const int ly = blockIdx.y;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const float* __restrict__ dwt = dwt_all + (long)ly * KP * NP;
+    const int n_out = t.n_out[ly], K = t.k[ly];
+    float* __restrict__ dw = t.dw[ly];
+    float* __restrict__ db = t.db[ly];
+    if (idx < n_out * K) {
+        const int n = idx / K, k = idx - n * K;
+        if (t.kind[ly] == 0) {
+            float v = dwt[k * NP + n];
+            const float* mask = static_cast<const float*>(t.aux[ly]);
+            if (mask) v *= mask[idx];
+            dw[idx] = v;
+        } else {
+            dw[idx] = dwt[static_cast<const int*>(t.aux[ly])[idx] * NP + n];
+        }
+    }
+    if (db && idx < n_out) db[idx] = dwt[(KP - 1) * NP + idx];
+}
+
 // ---------------------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------------------
@@ -654,6 +720,63 @@ int mdnvae_decoder_unpack_gcn_grad(const float* dwt, const int* adj, int N, int 
     hipLaunchKernelGGL(unpack_gcn_grad_kernel, dim3((N * kn + 255) / 256), dim3(256), 0, (hipStream_t)stream, dwt, adj,
                        N, kn, dw, db);
     MV_LAUNCH_CHECK("unpack_gcn_grad_kernel");
+    return 0;
+}
+
+static int check_layer_tables(const char* who, int count, const int* kind, const int* n_out, const int* k) {
+    MV_REQUIRE(count >= 1 && count <= MAX_LAYERS, E_SHAPE, "%s: %d layers (1..%d supported)", who, count, MAX_LAYERS);
+    MV_REQUIRE(kind && n_out && k, E_ARG, "%s: null table", who);
+    for (int i = 0; i < count; ++i) {
+        MV_REQUIRE(kind[i] == 0 || kind[i] == 1, E_ARG, "%s: layer %d has kind %d (0 = linear, 1 = gcn)", who, i, kind[i]);
+        if (kind[i] == 0)
+            MV_REQUIRE(n_out[i] >= 1 && n_out[i] <= NP - 1 && k[i] >= 1 && k[i] <= KP - 1, E_SHAPE,
+                       "%s: layer %d weight [%d,%d] outside the %dx%d panel", who, i, n_out[i], k[i], NP - 1, KP - 1);
+        else
+            MV_REQUIRE(n_out[i] >= 2 && n_out[i] <= NP - 1 && k[i] >= 1 && k[i] <= n_out[i], E_SHAPE,
+                       "%s: layer %d N=%d k=%d unsupported", who, i, n_out[i], k[i]);
+    }
+    return 0;
+}
+
+int mdnvae_decoder_pack_layers(int count, const int* kind, const void* const* w, const void* const* bias,
+                               const void* const* aux, const int* n_out, const int* k, float* wt, float* wn,
+                               void* stream) {
+    if (int rc = check_layer_tables("mdnvae_decoder_pack_layers", count, kind, n_out, k)) return rc;
+    MV_REQUIRE(w && bias && aux && wt && wn, E_ARG, "mdnvae_decoder_pack_layers: null pointer");
+    PackTable t{};
+    for (int i = 0; i < count; ++i) {
+        MV_REQUIRE(w[i] && (kind[i] == 0 || aux[i]), E_ARG, "mdnvae_decoder_pack_layers: layer %d lacks a weight or adjacency", i);
+        t.w[i] = static_cast<const float*>(w[i]);
+        t.bias[i] = static_cast<const float*>(bias[i]);
+        t.aux[i] = aux[i];
+        t.n_out[i] = n_out[i];
+        t.k[i] = k[i];
+        t.kind[i] = kind[i];
+    }
+    hipLaunchKernelGGL(pack_layers_kernel, dim3((KP * NP + 255) / 256, count), dim3(256), 0, (hipStream_t)stream, t, wt, wn);
+    MV_LAUNCH_CHECK("pack_layers_kernel");
+    return 0;
+}
+
+int mdnvae_decoder_unpack_layer_grads(int count, const int* kind, const float* dwt, const void* const* aux,
+                                      const int* n_out, const int* k, void* const* dw, void* const* db, void* stream) {
+    if (int rc = check_layer_tables("mdnvae_decoder_unpack_layer_grads", count, kind, n_out, k)) return rc;
+    MV_REQUIRE(dwt && aux && dw && db, E_ARG, "mdnvae_decoder_unpack_layer_grads: null pointer");
+    UnpackTable t{};
+    int most = 0;
+    for (int i = 0; i < count; ++i) {
+        MV_REQUIRE(dw[i] && (kind[i] == 0 || aux[i]), E_ARG,
+                   "mdnvae_decoder_unpack_layer_grads: layer %d lacks a gradient buffer or adjacency", i);
+        t.dw[i] = static_cast<float*>(dw[i]);
+        t.db[i] = static_cast<float*>(db[i]);
+        t.aux[i] = aux[i];
+        t.n_out[i] = n_out[i];
+        t.k[i] = k[i];
+        t.kind[i] = kind[i];
+        most = n_out[i] * k[i] > most ? n_out[i] * k[i] : most;
+    }
+    hipLaunchKernelGGL(unpack_layers_kernel, dim3((most + 255) / 256, count), dim3(256), 0, (hipStream_t)stream, t, dwt);
+    MV_LAUNCH_CHECK("unpack_layers_kernel");
     return 0;
 }
 

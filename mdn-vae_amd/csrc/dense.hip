@@ -47,23 +47,44 @@ __global__ __launch_bounds__(256) void add_act_kernel(const float* __restrict__ 
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) y[i] = dact(act, a[i] + b[i]);
 }
 
+// Column sums in a fixed order.  A workgroup is 4 row groups x 64 columns: row group g adds rows
+// g, g+4, g+8, ... of its slab (eight independent loads in flight), the four partial rows meet in
+// LDS.  colsum_partial writes one row of partial sums per slab of `rows_per_block` rows; the same
+// kernel shape then folds the partial rows into the result.
+constexpr int CS_COLS = 64, CS_GROUPS = 4, CS_UNROLL = 8;
+__device__ __forceinline__ float colsum_slab(const float* __restrict__ a, int r0, int r1, int D, int c, int g,
+                                             float (*sm)[CS_COLS]) {
+    float s = 0.f;
+    if (c < D) {
+        int r = r0 + g;
+        for (; r + (CS_UNROLL - 1) * CS_GROUPS < r1; r += CS_UNROLL * CS_GROUPS) {
+            float v[CS_UNROLL];
+#pragma unroll
+            for (int u = 0; u < CS_UNROLL; ++u) v[u] = a[(long)(r + u * CS_GROUPS) * D + c];
+#pragma unroll
+            for (int u = 0; u < CS_UNROLL; ++u) s += v[u];
+        }
+        for (; r < r1; r += CS_GROUPS) s += a[(long)r * D + c];
+    }
+    sm[g][threadIdx.x & (CS_COLS - 1)] = s;
+    __syncthreads();
+    const int t = threadIdx.x & (CS_COLS - 1);
+    return (sm[0][t] + sm[1][t]) + (sm[2][t] + sm[3][t]);
+}
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ a, int B, int D,
                                                              int rows_per_block, float* __restrict__ part) {
-    const int e = blockIdx.x * 256 + threadIdx.x;
+    __shared__ float sm[CS_GROUPS][CS_COLS];
+    const int c = blockIdx.x * CS_COLS + (threadIdx.x & (CS_COLS - 1)), g = threadIdx.x >> 6;
     const int b0 = blockIdx.y * rows_per_block;
-    const int b1 = min(B, b0 + rows_per_block);
-    if (e >= D) return;
-    float s = 0.f;
-    for (int b = b0; b < b1; ++b) s += a[(long)b * D + e];
-    part[(long)blockIdx.y * D + e] = s;
+    const float s = colsum_slab(a, b0, min(B, b0 + rows_per_block), D, c, g, sm);
+    if (g == 0 && c < D) part[(long)blockIdx.y * D + c] = s;
 }
 __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, int nparts, int D,
                                                            float* __restrict__ out) {
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= D) return;
-    float s = 0.f;
-    for (int p = 0; p < nparts; ++p) s += part[(long)p * D + e];
-    out[e] = s;
+    __shared__ float sm[CS_GROUPS][CS_COLS];
+    const int c = blockIdx.x * CS_COLS + (threadIdx.x & (CS_COLS - 1)), g = threadIdx.x >> 6;
+    const float s = colsum_slab(part, 0, nparts, D, c, g, sm);
+    if (g == 0 && c < D) out[c] = s;
 }
 
 }  // namespace mdnvae
@@ -112,12 +133,13 @@ size_t mdnvae_colsum_workspace_floats(int B, int D) { return (size_t)((B + 63) /
 int mdnvae_colsum(const float* a, int B, int D, float* workspace, float* out, void* stream) {
     MV_REQUIRE(B >= 1 && D >= 1, E_ARG, "mdnvae_colsum: empty input");
     MV_REQUIRE(a && workspace && out, E_ARG, "mdnvae_colsum: null pointer");
-    const int rows = 64, nparts = (B + rows - 1) / rows;
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3((D + 255) / 256, nparts), dim3(256), 0, (hipStream_t)stream, a, B, D,
-                       rows, workspace);
+    // slabs of 64 rows for small batches, longer ones once there are enough slabs to fill the chip
+    const int rows = B >= 8192 ? 256 : (B >= 2048 ? 128 : 64), nparts = (B + rows - 1) / rows;
+    const unsigned cols = (unsigned)((D + CS_COLS - 1) / CS_COLS);
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(cols, nparts), dim3(256), 0, (hipStream_t)stream, a, B, D, rows,
+                       workspace);
     MV_LAUNCH_CHECK("colsum_partial_kernel");
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((D + 255) / 256), dim3(256), 0, (hipStream_t)stream, workspace, nparts,
-                       D, out);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(cols), dim3(256), 0, (hipStream_t)stream, workspace, nparts, D, out);
     MV_LAUNCH_CHECK("colsum_final_kernel");
     return 0;
 }

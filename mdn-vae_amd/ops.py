@@ -364,26 +364,38 @@ class ChainSpec:
             self.acts |= a << (2 * l)
 
 
-def _pack_panels(spec, params, device):
-    """params: flat list [w(r=0,l=0), b(0,0), w(0,1), b(0,1), ...] -> (wt, wn) panels."""
-    n = spec.R * spec.NL * DEC_KP * DEC_NP
-    wt = torch.empty(n, dtype=torch.float32, device=device)
-    wn = torch.empty(n, dtype=torch.float32, device=device)
-    sl = DEC_KP * DEC_NP * 4
-    st = stream()
+def _layer_tables(spec, params):
+    """Host-side tables of the batched pack / unpack calls, layer (r,l) at r*NL+l."""
+    import ctypes
+    n = spec.R * spec.NL
+    kind, n_out, k = (ctypes.c_int * n)(), (ctypes.c_int * n)(), (ctypes.c_int * n)()
+    w, bias, aux = (ctypes.c_void_p * n)(), (ctypes.c_void_p * n)(), (ctypes.c_void_p * n)()
+    keep = []                                   # contiguous copies must outlive the launch
     for r in range(spec.R):
         for l, ly in enumerate(spec.layers):
-            w, b = params[2 * (r * spec.NL + l)], params[2 * (r * spec.NL + l) + 1]
-            off = (r * spec.NL + l) * sl
-            if ly["kind"] == "linear":
-                n_out, K = w.shape
-                call("mdnvae_decoder_pack_linear", ptr(_c(w), "weight"), ptr(ly.get("mask"), "mask"), ptr(b, "bias"),
-                     n_out, K, wt.data_ptr() + off, wn.data_ptr() + off, st)
-            else:
-                N, kn = w.shape
-                call("mdnvae_decoder_pack_gcn", ptr(_c(w), "weight"), ptr(ly["adj"], "adjacency", torch.int32),
-                     ptr(b, "bias"), N, kn, wt.data_ptr() + off, wn.data_ptr() + off, st)
+            i = r * spec.NL + l
+            wi, bi = _c(params[2 * i]), params[2 * i + 1]
+            keep.append(wi)
+            kind[i] = 0 if ly["kind"] == "linear" else 1
+            n_out[i], k[i] = wi.shape
+            w[i], bias[i] = ptr(wi, "weight"), ptr(bi, "bias")
+            aux[i] = ptr(ly.get("mask"), "mask") if kind[i] == 0 else ptr(ly["adj"], "adjacency", torch.int32)
+    return n, kind, n_out, k, w, bias, aux, keep
+
+
+def _pack_panels(spec, params, device):
+    """params: flat list [w(r=0,l=0), b(0,0), w(0,1), b(0,1), ...] -> (wt, wn) panels, one launch."""
+    n, kind, n_out, k, w, bias, aux, keep = _layer_tables(spec, params)
+    wt = torch.empty(n * DEC_KP * DEC_NP, dtype=torch.float32, device=device)
+    wn = torch.empty(n * DEC_KP * DEC_NP, dtype=torch.float32, device=device)
+    call("mdnvae_decoder_pack_layers", n, _addr(kind), _addr(w), _addr(bias), _addr(aux), _addr(n_out), _addr(k),
+         ptr(wt), ptr(wn), stream())
     return wt, wn
+
+
+def _addr(ctypes_array):
+    import ctypes
+    return ctypes.addressof(ctypes_array)
 
 
 class _ChainDecoder(torch.autograd.Function):
@@ -441,9 +453,11 @@ class _ChainDecoder(torch.autograd.Function):
              ptr(gxlat), ptr(gz), ptr(hin), ptr(dp), ptr(ga), ptr(nodes), ptr(node_grad), stream())
         # weight (+bias, last row) gradient of every layer: [KP x B] . [B x NP] library GEMMs
         dwt = torch.bmm(hin.transpose(1, 2), dp)
+        import ctypes
+        n = spec.R * spec.NL
+        kind, n_out, k = (ctypes.c_int * n)(), (ctypes.c_int * n)(), (ctypes.c_int * n)()
+        aux, dw, db = (ctypes.c_void_p * n)(), (ctypes.c_void_p * n)(), (ctypes.c_void_p * n)()
         grads = []
-        sl = DEC_KP * DEC_NP * 4
-        st = stream()
         for r in range(spec.R):
             for l, ly in enumerate(spec.layers):
                 idx = r * spec.NL + l
@@ -451,21 +465,20 @@ class _ChainDecoder(torch.autograd.Function):
                 gw = torch.empty(shape_w, dtype=torch.float32, device=dev)
                 has_b = ctx.param_shapes[2 * idx + 1] is not None
                 gb = torch.empty(shape_w[0], dtype=torch.float32, device=dev) if has_b else None
-                src = dwt.data_ptr() + idx * sl
-                if ly["kind"] == "linear":
-                    call("mdnvae_decoder_unpack_linear_grad", src, ptr(ly.get("mask")), shape_w[0], shape_w[1],
-                         ptr(gw), ptr(gb), st)
-                else:
-                    call("mdnvae_decoder_unpack_gcn_grad", src, ptr(ly["adj"], "adjacency", torch.int32), shape_w[0],
-                         shape_w[1], ptr(gw), ptr(gb), st)
+                kind[idx] = 0 if ly["kind"] == "linear" else 1
+                n_out[idx], k[idx] = shape_w
+                aux[idx] = ptr(ly.get("mask")) if kind[idx] == 0 else ptr(ly["adj"], "adjacency", torch.int32)
+                dw[idx], db[idx] = ptr(gw), ptr(gb)
                 grads += [gw, gb]
+        call("mdnvae_decoder_unpack_layer_grads", n, _addr(kind), ptr(dwt), _addr(aux), _addr(n_out), _addr(k), _addr(dw),
+             _addr(db), stream())
         g_iw = g_ib = None
         if icpt_w is not None:
             D = spec.N * spec.N
             ws = torch.empty(_lib.workspace_bytes_f("mdnvae_colsum2_workspace_floats", B, D), dtype=torch.float32, device=dev)
             g_ib = torch.empty(D, dtype=torch.float32, device=dev)
             g_iw = torch.empty(D, dtype=torch.float32, device=dev)
-            call("mdnvae_colsum2", ptr(gout), ptr(ga), B, D, ptr(ws), ptr(g_ib), ptr(g_iw), st)
+            call("mdnvae_colsum2", ptr(gout), ptr(ga), B, D, ptr(ws), ptr(g_ib), ptr(g_iw), stream())
         return (gz, None, g_iw, g_ib, None, *grads)
 
 
