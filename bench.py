@@ -272,6 +272,37 @@ def kernel_table(clock, elapsed):
     return kernels
 
 
+def mixture_stream_rates(batch, nodes, device, reps=5):
+    """The streaming form of the mixture likelihood (component means given as [B,K,N*N] matrices:
+    what a caller with arbitrary, not rank-one, component means runs), timed on its own at the
+    workload's shape: forward reads the matrices and x once, backward reads them and writes the
+    gradient.  The training step above does not run these kernels - it uses the rank-one form that
+    never materialises the matrices - so their HBM rates are reported from this separate pass."""
+    K, D, L = 5, nodes * nodes, 68
+    g = torch.Generator(device=device).manual_seed(5)
+    comp = torch.rand(batch, K, D, device=device, generator=g).requires_grad_(True)
+    x = torch.rand(batch, D, device=device, generator=g)
+    logits = torch.randn(batch, K, device=device, generator=g)
+    ls = torch.full((K,), 1.0, device=device)
+    mu, lv = (torch.randn(batch, L, device=device, generator=g) * 0.1 for _ in range(2))
+    clock = KernelClock()
+    restore = install_clock(clock)
+    try:
+        for i in range(reps + 1):
+            comp.grad = None
+            ops.mdn_loss(comp, x, logits, ls, mu, lv).backward()
+            if i == 0:
+                torch.cuda.synchronize()
+                clock.records.clear()
+        torch.cuda.synchronize()
+    finally:
+        restore()
+    total = sum(r["seconds"] for r in clock.summary().values())
+    table = kernel_table(clock, total)
+    return {k: {f: v[f] for f in ("bound", "achieved", "peak", "unit", "frac", "traffic", "launches", "avg_ms")}
+            for k, v in table.items()}
+
+
 def run_workload(model_name, batch, nodes, steps, warmup, pool_batches, device, rank, world, use_clock,
                  overlap=True, symmetric=True):
     """Warm up, then time exactly `steps` steps between barrier + synchronize pairs; returns
@@ -400,6 +431,11 @@ def main():
                 top = max(own, key=lambda k: kernels[k]["share_of_step"])
                 line["roofline_handwritten"] = dict(kernels[top], kernel=top)
             line["kernels"] = kernels
+        if kernels and args.model == "mdn_gate" and world == 1:
+            line["mixture_stream_kernels"] = dict(
+                mixture_stream_rates(batch, args.nodes, device),
+                note="streaming likelihood over materialised [B,K,N*N] component means, timed on its own; the "
+                     "training step uses the rank-one form (mdn_outer_kernel)")
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(args.model, args.nodes)
     if world == 1 and args.also and args.also != args.model:
