@@ -252,7 +252,7 @@ def install_clock(clock):
 
 
 def default_batch(model_name):
-    return 8192 if model_name in ("mm_gate", "mdn_gate") else 1024
+    return 16384 if model_name in ("mm_gate", "mdn_gate") else 1024
 
 
 def kernel_table(clock, elapsed):
@@ -374,7 +374,7 @@ def main():
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--model", default="mdn_gate", choices=list(MODELS))
-    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default 8192 for the FNN-encoder models, "
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default 16384 for the FNN-encoder models, "
                                                           "1024 for the conv-encoder models)")
     ap.add_argument("--also", default="cnn_gcn", help="second workload reported under 'also' on one GPU ('' = none)")
     ap.add_argument("--nodes", type=int, default=87)
