@@ -30,8 +30,13 @@ static_assert(NP == KP, "layer outputs are reused as the next layer's input rows
 
 constexpr int ACT_NONE = 0, ACT_SIGMOID = 1, ACT_TANH = 2;
 
+// 1 / (1 + e^-v) on the hardware exp2 and reciprocal (each within 1 ulp): the chain kernels run one
+// wave per SIMD, so the ~40 instructions of the library expf and division are not hidden
+__device__ __forceinline__ float sigmoid_fast(float v) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v));
+}
 __device__ __forceinline__ float act_apply(int a, float v) {
-    if (a == ACT_SIGMOID) return sigmoidf_(v);
+    if (a == ACT_SIGMOID) return sigmoid_fast(v);
     if (a == ACT_TANH) return tanhf(v);
     return v;
 }
@@ -205,26 +210,34 @@ constexpr int CH_LD = CH_TS + 1;     // row stride of the k-major activation buf
 // sample row of accumulator register j (column = lane & 31)
 __device__ __forceinline__ int acc_row(int j, int lane) { return (j & 3) + 8 * (j >> 2) + 4 * (lane >> 5); }
 
+// A wave owns 32 output columns of a layer, and its slice of the layer's panel lives in its
+// registers in the matrix-core operand layout: register i of lane (h = lane >> 5, c = lane & 31)
+// holds w[2i + h][n0 + c].  The next layer's slice is fetched from global memory (L2 resident: every
+// workgroup reads the same panels) while the current product runs, so LDS carries activations only
+// and a workgroup needs little of it - several tiles are resident per CU and hide each other's
+// latencies.
+constexpr int PANEL_REGS = KP / 2;
+__device__ __forceinline__ void panel_fetch(const float* __restrict__ src, int n0, int lane, float (&w)[PANEL_REGS]) {
+    const float* p = src + (lane >> 5) * NP + n0 + (lane & 31);
+#pragma unroll
+    for (int i = 0; i < PANEL_REGS; ++i) w[i] = p[2 * i * NP];
+}
+
 // acc[s][n] = sum_k in[k][s] * w[k][n0 + n] over the whole padded panel (row KP-1 of `in` is 1,
 // so the bias row of the panel is added by the product itself)
-__device__ __forceinline__ f32x16 panel_product(const float* __restrict__ in, const float* __restrict__ w, int n0,
-                                                int lane) {
+__device__ __forceinline__ f32x16 panel_product(const float* __restrict__ in, const float (&w)[PANEL_REGS], int lane) {
     f32x16 acc;
 #pragma unroll
     for (int j = 0; j < 16; ++j) acc[j] = 0.0f;
-    const int h = lane >> 5, l32 = lane & 31;
-#pragma unroll 8
-    for (int k = 0; k < KP; k += 2) {
-        const float av = in[(k + h) * CH_LD + l32];
-        const float bv = w[(k + h) * NP + n0 + l32];
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+    const float* ap = in + (lane >> 5) * CH_LD + (lane & 31);
+#pragma unroll
+    for (int i = 0; i < PANEL_REGS; ++i) {
+        // eight activation reads in flight at a time: hoisting all of them costs registers a second
+        // resident wave needs
+        if ((i & 7) == 0) __builtin_amdgcn_sched_barrier(0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * i * CH_LD], w[i], acc, 0, 0, 0);
     }
     return acc;
-}
-
-__device__ __forceinline__ void stage_panel(const float* __restrict__ src, float* __restrict__ wl) {
-    const float4* s4 = reinterpret_cast<const float4*>(src);
-    for (int i = threadIdx.x; i < KP * NP / 4; i += CH_NT) reinterpret_cast<float4*>(wl)[i] = s4[i];
 }
 
 // z tile -> k-major rows with the ones row at KP-1
@@ -239,54 +252,35 @@ __device__ __forceinline__ void load_latent_tile(const float* __restrict__ z, in
     }
 }
 
-// The next layer's panel is fetched into registers before the current layer's MFMA loop and written
-// to the other LDS panel buffer after it, so its global-memory latency hides under the MFMAs and a
-// layer costs one barrier.
-constexpr int PANEL_Q = KP * NP / 4 / CH_NT;     // float4 per thread per panel
-static_assert(PANEL_Q * CH_NT * 4 == KP * NP, "the panel must divide evenly over the workgroup");
-
-__device__ __forceinline__ void panel_fetch(const float* __restrict__ src, float4 (&pre)[PANEL_Q]) {
-    const float4* s4 = reinterpret_cast<const float4*>(src);
-#pragma unroll
-    for (int i = 0; i < PANEL_Q; ++i) pre[i] = s4[i * CH_NT + threadIdx.x];
-}
-__device__ __forceinline__ void panel_commit(const float4 (&pre)[PANEL_Q], float* __restrict__ wl) {
-#pragma unroll
-    for (int i = 0; i < PANEL_Q; ++i) reinterpret_cast<float4*>(wl)[i * CH_NT + threadIdx.x] = pre[i];
-}
-
-__global__ __launch_bounds__(CH_NT) void chain_fwd_mfma_kernel(DecArgs a, const float* __restrict__ z,
+__global__ __launch_bounds__(CH_NT, 2) void chain_fwd_mfma_kernel(DecArgs a, const float* __restrict__ z,
                                                                const float* __restrict__ wt,
                                                                const float* __restrict__ drop,
                                                                float* __restrict__ nodes, float* __restrict__ xlat) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* wl0 = smem;                                  // [2][KP][NP]
-    float* abuf0 = smem + 2 * KP * NP;                  // [2][KP][CH_LD]
+    float* abuf0 = smem;                                // [2][KP][CH_LD]
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int n = wave * 32 + (lane & 31);
     const int N = a.N;
     const int ntiles = (a.B + CH_TS - 1) / CH_TS;
     const int S = a.R * a.NL;                           // layer steps per tile
     if ((int)blockIdx.x >= ntiles) return;
-    float4 pre[PANEL_Q];
-    panel_fetch(wt, pre);
-    panel_commit(pre, wl0);
+    float wcur[PANEL_REGS], wnext[PANEL_REGS];
+    panel_fetch(wt, wave * 32, lane, wcur);
     int cur = 0;
     load_latent_tile(z, blockIdx.x * CH_TS, a.B, a.L, abuf0);
     __syncthreads();
-    long g = 0;                                         // layer steps done by this workgroup
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int b0 = tile * CH_TS;
         float xl[16];
 #pragma unroll
         for (int j = 0; j < 16; ++j) xl[j] = 0.0f;
         for (int r = 0; r < a.R; ++r) {
-            for (int l = 0; l < a.NL; ++l, ++g) {
+            for (int l = 0; l < a.NL; ++l) {
                 const int s = r * a.NL + l;
                 const bool last_step = s == S - 1;
                 const bool more = !last_step || tile + (int)gridDim.x < ntiles;
-                if (more) panel_fetch(wt + ((long)((s + 1) % S) * KP) * NP, pre);
-                const f32x16 acc = panel_product(abuf0 + cur * KP * CH_LD, wl0 + (g & 1) * KP * NP, wave * 32, lane);
+                if (more) panel_fetch(wt + ((long)((s + 1) % S) * KP) * NP, wave * 32, lane, wnext);
+                const f32x16 acc = panel_product(abuf0 + cur * KP * CH_LD, wcur, lane);
                 const int act = layer_act(a.acts, l);
                 float* nxt = abuf0 + (cur ^ 1) * KP * CH_LD;
                 if (l == a.NL - 1) {
@@ -310,7 +304,10 @@ __global__ __launch_bounds__(CH_NT) void chain_fwd_mfma_kernel(DecArgs a, const 
                         nxt[n * CH_LD + acc_row(j, lane)] = v;
                     }
                 }
-                if (more) panel_commit(pre, wl0 + ((g + 1) & 1) * KP * NP);
+                if (more) {
+#pragma unroll
+                    for (int i = 0; i < PANEL_REGS; ++i) wcur[i] = wnext[i];
+                }
                 __syncthreads();
                 cur ^= 1;
             }
@@ -501,7 +498,7 @@ __global__ __launch_bounds__(256) void outer_grad_kernel(DecArgs a, const float*
 // LDS), then walk the layers backwards: dpre = dh * act'(h) goes to layer_dpre and, n-major in
 // LDS, is the A operand of dh_prev = dpre . W (panel Wn[n][k]); the layer's input rows go to
 // layer_in.  The latent gradient accumulates over the channels in the MFMA accumulators.
-__global__ __launch_bounds__(CH_NT) void chain_bwd_mfma_kernel(DecArgs a, const float* __restrict__ z,
+__global__ __launch_bounds__(CH_NT, 2) void chain_bwd_mfma_kernel(DecArgs a, const float* __restrict__ z,
                                                                const float* __restrict__ wt,
                                                                const float* __restrict__ wn,
                                                                const float* __restrict__ drop,
@@ -509,8 +506,7 @@ __global__ __launch_bounds__(CH_NT) void chain_bwd_mfma_kernel(DecArgs a, const 
                                                                const float* __restrict__ gxlat, float* __restrict__ dz,
                                                                float* __restrict__ hin, float* __restrict__ dp) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* wl0 = smem;                                  // [2][KP][NP] panel double buffer
-    float* zt = wl0 + 2 * KP * NP;                      // [KP][CH_LD]
+    float* zt = smem;                                   // [KP][CH_LD]
     float* dpb = zt + KP * CH_LD;                       // [NP][CH_LD]
     float* acts = dpb + NP * CH_LD;                     // [NL][KP][CH_LD]
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -525,12 +521,10 @@ __global__ __launch_bounds__(CH_NT) void chain_bwd_mfma_kernel(DecArgs a, const 
         const int r = q / (2 * NL), i = q - r * 2 * NL;
         return i < NL ? wt + ((long)(r * NL + i) * KP) * NP : wn + ((long)(r * NL + (2 * NL - 1 - i)) * NP) * KP;
     };
-    float4 pre[PANEL_Q];
-    panel_fetch(panel_of(0), pre);
-    panel_commit(pre, wl0);
+    float wcur[PANEL_REGS], wnext[PANEL_REGS];
+    panel_fetch(panel_of(0), wave * 32, lane, wcur);
     load_latent_tile(z, blockIdx.x * CH_TS, a.B, a.L, zt);
     __syncthreads();
-    long g = 0;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int b0 = tile * CH_TS;
         const bool more_tiles = tile + (int)gridDim.x < ntiles;
@@ -539,10 +533,9 @@ __global__ __launch_bounds__(CH_NT) void chain_bwd_mfma_kernel(DecArgs a, const 
         for (int j = 0; j < 16; ++j) dzacc[j] = 0.0f;
         for (int r = 0; r < R; ++r) {
             // recompute the chain of channel r
-            for (int l = 0; l < NL; ++l, ++g) {
-                panel_fetch(panel_of(r * 2 * NL + l + 1), pre);          // a backward step always follows
-                const f32x16 acc = panel_product(l == 0 ? zt : acts + (l - 1) * KP * CH_LD, wl0 + (g & 1) * KP * NP,
-                                                 wave * 32, lane);
+            for (int l = 0; l < NL; ++l) {
+                panel_fetch(panel_of(r * 2 * NL + l + 1), wave * 32, lane, wnext);   // a backward step always follows
+                const f32x16 acc = panel_product(l == 0 ? zt : acts + (l - 1) * KP * CH_LD, wcur, lane);
                 const int act = layer_act(a.acts, l);
                 float* dst = acts + l * KP * CH_LD;
 #pragma unroll
@@ -551,7 +544,8 @@ __global__ __launch_bounds__(CH_NT) void chain_bwd_mfma_kernel(DecArgs a, const 
                     if (n == KP - 1) v = 1.0f;
                     dst[n * CH_LD + acc_row(j, lane)] = v;
                 }
-                panel_commit(pre, wl0 + ((g + 1) & 1) * KP * NP);
+#pragma unroll
+                for (int i = 0; i < PANEL_REGS; ++i) wcur[i] = wnext[i];
                 __syncthreads();
             }
             // gradient w.r.t. the final node vector (dropout already applied to dnode)
@@ -570,10 +564,10 @@ __global__ __launch_bounds__(CH_NT) void chain_bwd_mfma_kernel(DecArgs a, const 
                 }
                 dh[j] = v;
             }
-            for (int l = NL - 1; l >= 0; --l, ++g) {
+            for (int l = NL - 1; l >= 0; --l) {
                 const int q = r * 2 * NL + (2 * NL - 1 - l);
                 const bool more = q + 1 < S || more_tiles;
-                if (more) panel_fetch(panel_of((q + 1) % S), pre);
+                if (more) panel_fetch(panel_of((q + 1) % S), wave * 32, lane, wnext);
                 const int act = layer_act(a.acts, l);
                 const long row0 = ((long)(r * NL + l) * a.B + b0);
                 const float* hl = acts + l * KP * CH_LD;
@@ -592,14 +586,17 @@ __global__ __launch_bounds__(CH_NT) void chain_bwd_mfma_kernel(DecArgs a, const 
                 }
                 __syncthreads();
                 // dh_prev[s][k] = sum_n dpre[s][n] * Wn[n][k]
-                const f32x16 acc = panel_product(dpb, wl0 + (g & 1) * KP * NP, wave * 32, lane);
+                const f32x16 acc = panel_product(dpb, wcur, lane);
                 if (l == 0) {
 #pragma unroll
                     for (int j = 0; j < 16; ++j) dzacc[j] += acc[j];
                 } else {
                     dh = acc;
                 }
-                if (more) panel_commit(pre, wl0 + ((g + 1) & 1) * KP * NP);
+                if (more) {
+#pragma unroll
+                    for (int i = 0; i < PANEL_REGS; ++i) wcur[i] = wnext[i];
+                }
                 if (q == S - 1 && more_tiles) load_latent_tile(z, (tile + (int)gridDim.x) * CH_TS, a.B, a.L, zt);
                 __syncthreads();
             }
@@ -664,7 +661,7 @@ static int check_dec(const char* fn, int B, int N, int L, int R, int NL) {
 }
 
 static size_t chain_bwd_lds_bytes(int NL) {
-    return sizeof(float) * ((size_t)2 * KP * NP + (size_t)KP * CH_LD + (size_t)NP * CH_LD + (size_t)NL * KP * CH_LD);
+    return sizeof(float) * ((size_t)KP * CH_LD + (size_t)NP * CH_LD + (size_t)NL * KP * CH_LD);
 }
 
 static unsigned wave_grid(long items) {          // one wave per item, four waves per workgroup
@@ -796,7 +793,7 @@ int mdnvae_decoder_fwd(const float* z, const float* wt, int B, int N, int L, int
     MV_REQUIRE(!xlat_channels || xlat, E_ARG, "mdnvae_decoder_fwd: xlat is null");
     DecArgs a{B, N, L, R, NL, acts, epi_act, icpt_w != nullptr, do_exp, xlat_channels, components};
     const int ntiles = (B + CH_TS - 1) / CH_TS;
-    const size_t fwd_lds = sizeof(float) * ((size_t)2 * KP * NP + (size_t)2 * KP * CH_LD);
+    const size_t fwd_lds = sizeof(float) * ((size_t)2 * KP * CH_LD);
     static bool fwd_attr_set = false;
     if (!fwd_attr_set) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(chain_fwd_mfma_kernel),
