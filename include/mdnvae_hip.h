@@ -164,6 +164,15 @@ int mdnvae_act_bwd(const float* y, const float* grad_y, float* grad_pre, long n,
 size_t mdnvae_colsum_workspace_floats(int B, int D);
 int mdnvae_colsum(const float* a, int B, int D, float* workspace, float* out, void* stream);
 
+/* Weight gradient of F.linear for a small layer over a long batch: grad_w [N,M] = grad_pre^T . x with
+ * grad_pre [B,N], x [B,M] (autograd of the tower / head layers, function/MM_Gate.py:157-165,
+ * function/VAE_CNN_NN.py:160-161), split over the batch on the fp32 matrix cores and reduced in a
+ * fixed order.  N and M multiples of 4; all operands 16-byte aligned.  Meant for N*M up to a few
+ * hundred thousand, where a library GEMM has too few output tiles to fill the chip. */
+size_t mdnvae_linear_wgrad_workspace_floats(int B, int N, int M);
+int mdnvae_linear_wgrad(const float* grad_pre, const float* x, int B, int N, int M, float* workspace, float* grad_w,
+                        void* stream);
+
 /* ---- first dense layer on symmetric connectomes --------------------------------------------
  * `self.fc11(x.view(-1, N*N))` (function/MM_Gate.py:157-165; function_FC_SC/SC-FC.py:95-104) sums
  * w[h,i,j] x[b,i,j] over all N*N entries.  For a symmetric x[b] the same number is the product of

@@ -1,0 +1,176 @@
+// Weight gradient of a small dense layer over a long batch:  dW [N,M] = g^T . x  with g [B,N] the
+// gradient of the layer's pre-activations and x [B,M] its input (the autograd of F.linear in the
+// encoder towers and latent heads, function/MM_Gate.py:157-165, function/VAE_CNN_NN.py:160-161).
+// The output is small (N*M up to a few hundred thousand) and the reduction dimension is the batch,
+// so the work is split over the batch: a workgroup owns a 64 (n) x 128 (m) tile of dW for one slab
+// of samples, the slabs' partial tiles are added in slab order by a second kernel (fixed order,
+// reproducible).  Rows of x and g are staged through LDS in chunks of 32 samples, fetched into
+// registers one chunk ahead; the products run on the fp32 matrix cores with g as the A operand, so
+// the accumulator columns run along m and the partial tile is stored in whole cache lines.
+#include "common.h"
+#include "../../include/mdnvae_hip.h"
+
+namespace mdnvae {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int TS_TN = 64, TS_TM = 128, TS_KC = 32, TS_NT = 256;
+constexpr int TS_GLD = TS_TN + 4, TS_XLD = TS_TM + 4;        // LDS row strides (floats), 16-byte multiples
+constexpr int TS_GQ = TS_KC * TS_TN / 4 / TS_NT;            // float4 per thread per chunk of g (2)
+constexpr int TS_XQ = TS_KC * TS_TM / 4 / TS_NT;            // ... of x (4)
+
+__device__ __forceinline__ void ts_fetch(const float* __restrict__ g, const float* __restrict__ x, int N, int M, int b0,
+                                         int b_end, int n0, int m0, float4 (&cg)[TS_GQ], float4 (&cx)[TS_XQ]) {
+#pragma unroll
+    for (int i = 0; i < TS_GQ; ++i) {
+        const int q = i * TS_NT + threadIdx.x, r = q / (TS_TN / 4), col = (q - r * (TS_TN / 4)) * 4;
+        const int b = b0 + r, n = n0 + col;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (b < b_end && n < N) v = *reinterpret_cast<const float4*>(g + (long)b * N + n);
+        cg[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < TS_XQ; ++i) {
+        const int q = i * TS_NT + threadIdx.x, r = q / (TS_TM / 4), col = (q - r * (TS_TM / 4)) * 4;
+        const int b = b0 + r, m = m0 + col;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (b < b_end && m < M) v = *reinterpret_cast<const float4*>(x + (long)b * M + m);
+        cx[i] = v;
+    }
+}
+__device__ __forceinline__ void ts_commit(const float4 (&cg)[TS_GQ], const float4 (&cx)[TS_XQ], float* __restrict__ gs,
+                                          float* __restrict__ xs) {
+#pragma unroll
+    for (int i = 0; i < TS_GQ; ++i) {
+        const int q = i * TS_NT + threadIdx.x, r = q / (TS_TN / 4), col = (q - r * (TS_TN / 4)) * 4;
+        *reinterpret_cast<float4*>(gs + r * TS_GLD + col) = cg[i];
+    }
+#pragma unroll
+    for (int i = 0; i < TS_XQ; ++i) {
+        const int q = i * TS_NT + threadIdx.x, r = q / (TS_TM / 4), col = (q - r * (TS_TM / 4)) * 4;
+        *reinterpret_cast<float4*>(xs + r * TS_XLD + col) = cx[i];
+    }
+}
+
+// grid: (m tiles, n tiles, slabs); part[slab][n][m]
+__global__ __launch_bounds__(TS_NT) void tsgemm_partial_kernel(const float* __restrict__ g, const float* __restrict__ x,
+                                                               int B, int N, int M, int slab_rows,
+                                                               float* __restrict__ part) {
+    __shared__ __attribute__((aligned(16))) float gs[2][TS_KC * TS_GLD];
+    __shared__ __attribute__((aligned(16))) float xs[2][TS_KC * TS_XLD];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wn = (wave & 1) * 32, wm = (wave >> 1) * 64;       // this wave: 32 rows (n) x 64 columns (m)
+    const int m0 = blockIdx.x * TS_TM, n0 = blockIdx.y * TS_TN;
+    const int b_begin = blockIdx.z * slab_rows, b_end = min(B, b_begin + slab_rows);
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc0[j] = acc1[j] = 0.0f;
+    float4 cg[TS_GQ], cx[TS_XQ];
+    ts_fetch(g, x, N, M, b_begin, b_end, n0, m0, cg, cx);
+    ts_commit(cg, cx, gs[0], xs[0]);
+    __syncthreads();
+    const int h = lane >> 5, l32 = lane & 31;
+    int cur = 0;
+    for (int b0 = b_begin; b0 < b_end; b0 += TS_KC, cur ^= 1) {
+        const bool more = b0 + TS_KC < b_end;
+        if (more) ts_fetch(g, x, N, M, b0 + TS_KC, b_end, n0, m0, cg, cx);
+        const float* ga = gs[cur] + h * TS_GLD + wn + l32;
+        const float* xb = xs[cur] + h * TS_XLD + wm + l32;
+#pragma unroll
+        for (int k = 0; k < TS_KC; k += 2) {
+            const float av = ga[k * TS_GLD];
+            const float b0v = xb[k * TS_XLD], b1v = xb[k * TS_XLD + 32];
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0v, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1v, acc1, 0, 0, 0);
+        }
+        if (more) ts_commit(cg, cx, gs[cur ^ 1], xs[cur ^ 1]);
+        __syncthreads();
+    }
+    float* dst = part + (long)blockIdx.z * N * M;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int n = n0 + wn + (j & 3) + 8 * (j >> 2) + 4 * h;
+        const int m = m0 + wm + l32;
+        if (n < N) {
+            if (m < M) dst[(long)n * M + m] = acc0[j];
+            if (m + 32 < M) dst[(long)n * M + m + 32] = acc1[j];
+        }
+    }
+}
+
+// out[e] = sum_s part[s][e]: a workgroup covers 64 quads of e with four groups of lanes that each
+// add every fourth slab (four loads in flight), the four group sums meet in LDS in a fixed order
+__global__ __launch_bounds__(256) void tsgemm_reduce_kernel(const float* __restrict__ part, int slabs, long count,
+                                                            float* __restrict__ out) {
+    __shared__ float4 sm[4][64];
+    const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const long e4 = (long)blockIdx.x * 64 + col;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (e4 * 4 < count) {
+        int p = grp;
+        for (; p + 12 < slabs; p += 16) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(part + (long)(p + 4 * u) * count + e4 * 4);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+        }
+        for (; p < slabs; p += 4) {
+            const float4 v = *reinterpret_cast<const float4*>(part + (long)p * count + e4 * 4);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+    }
+    sm[grp][col] = s;
+    __syncthreads();
+    if (grp == 0 && e4 * 4 < count) {
+        float4 r = sm[0][col];
+#pragma unroll
+        for (int u = 1; u < 4; ++u) { r.x += sm[u][col].x; r.y += sm[u][col].y; r.z += sm[u][col].z; r.w += sm[u][col].w; }
+        *reinterpret_cast<float4*>(out + e4 * 4) = r;
+    }
+}
+
+// slabs: enough workgroups to fill the chip a few times over, at least 64 samples per slab
+static int ts_slabs(int B, int N, int M) {
+    const long tiles = (long)((M + TS_TM - 1) / TS_TM) * ((N + TS_TN - 1) / TS_TN);
+    long s = (1024 + tiles - 1) / tiles;
+    const long most = (B + 63) / 64;
+    if (s > most) s = most;
+    if (s > 256) s = 256;
+    return (int)(s < 1 ? 1 : s);
+}
+
+}  // namespace mdnvae
+using namespace mdnvae;
+
+extern "C" {
+
+size_t mdnvae_linear_wgrad_workspace_floats(int B, int N, int M) {
+    if (B < 1 || N < 1 || M < 1) return 0;
+    return (size_t)ts_slabs(B, N, M) * N * M;
+}
+
+int mdnvae_linear_wgrad(const float* grad_pre, const float* x, int B, int N, int M, float* workspace, float* grad_w,
+                        void* stream) {
+    MV_REQUIRE(B >= 1 && N >= 1 && M >= 1, E_ARG, "mdnvae_linear_wgrad: empty operand");
+    MV_REQUIRE((N & 3) == 0 && (M & 3) == 0, E_SHAPE,
+               "mdnvae_linear_wgrad: N = %d and M = %d must be multiples of 4 (16-byte rows)", N, M);
+    MV_REQUIRE(grad_pre && x && workspace && grad_w, E_ARG, "mdnvae_linear_wgrad: null pointer");
+    MV_REQUIRE(aligned16(grad_pre) && aligned16(x) && aligned16(workspace) && aligned16(grad_w), E_ALIGN,
+               "mdnvae_linear_wgrad: operands must be 16-byte aligned");
+    const int slabs = ts_slabs(B, N, M);
+    const int slab_rows = ((B + slabs - 1) / slabs + TS_KC - 1) / TS_KC * TS_KC;
+    const int used = (B + slab_rows - 1) / slab_rows;
+    const dim3 grid((M + TS_TM - 1) / TS_TM, (N + TS_TN - 1) / TS_TN, used);
+    MV_REQUIRE(grid.y <= 65535 && grid.z <= 65535, E_SHAPE, "mdnvae_linear_wgrad: shape too large");
+    hipLaunchKernelGGL(tsgemm_partial_kernel, grid, dim3(TS_NT), 0, (hipStream_t)stream, grad_pre, x, B, N, M, slab_rows,
+                       workspace);
+    MV_LAUNCH_CHECK("tsgemm_partial_kernel");
+    const long count = (long)N * M;
+    hipLaunchKernelGGL(tsgemm_reduce_kernel, dim3((unsigned)((count / 4 + 63) / 64)), dim3(256), 0, (hipStream_t)stream,
+                       workspace, used, count, grad_w);
+    MV_LAUNCH_CHECK("tsgemm_reduce_kernel");
+    return 0;
+}
+
+}  // extern "C"

@@ -145,3 +145,18 @@ def test_mdn_trainer_step_reduces_the_loss():
     losses = [trainer.step((x, adjacency, traits), x, eps=torch.randn(16, 68, device=DEV, generator=gen)).item()
               for _ in range(10)]
     assert all(l == l for l in losses) and losses[-1] < losses[0]
+
+
+@pytest.mark.parametrize("B,N,M", [(4096, 128, 1024), (2048, 68, 128), (1500, 4, 8), (1031, 132, 260), (33, 64, 128)])
+def test_small_layer_weight_gradient_kernel(B, N, M):
+    """grad_w = grad_pre^T . x of the split-over-the-batch kernel against float64."""
+    g = torch.Generator().manual_seed(B + N)
+    gp = torch.randn(B, N, generator=g)
+    x = torch.randn(B, M, generator=g)
+    got = ops._linear_wgrad(gp.to(DEV), x.to(DEV))
+    want = gp.double().t() @ x.double()
+    assert got.shape == (N, M)
+    assert float((got.double().cpu() - want).abs().max()) <= 1e-5 * float(want.abs().max())
+    # reproducible: fixed summation order
+    again = ops._linear_wgrad(gp.to(DEV), x.to(DEV))
+    assert torch.equal(got, again)
