@@ -272,6 +272,7 @@ __global__ __launch_bounds__(MDN_NT) void mdn_bwd_stream_kernel(const float* __r
 // gradient and the passes over them do not exist.  The same wave does the sample's KL part.
 constexpr int MO_ROWS = 8;
 constexpr int MO_NP = MDNVAE_DEC_NP;
+typedef float mo_v2 __attribute__((ext_vector_type(2)));
 template <int K>
 __global__ __launch_bounds__(MDN_NT) void mdn_outer_kernel(const float* __restrict__ nodes, const float* __restrict__ x,
                                                            const float* __restrict__ logits,
@@ -289,20 +290,24 @@ __global__ __launch_bounds__(MDN_NT) void mdn_outer_kernel(const float* __restri
     for (int b = wave; b < B; b += nwaves) {
         const float* X = x + (long)b * D;
         const float* gv = nodes + (long)b * K * MO_NP;
-        float g0[K], g1[K], v0[K], v1[K], u0[K], u1[K], ss[K];
+        // the lane's two columns (c, c+64) travel as one packed pair: the residual, the sum of
+        // squares and the column sums are packed fp32 operations
+        mo_v2 g[K], v[K], ss2[K];
+        float u0[K], u1[K];
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-            g0[k] = c0 ? gv[k * MO_NP + lane] : 0.0f;
-            g1[k] = c1 ? gv[k * MO_NP + lane + 64] : 0.0f;
-            v0[k] = v1[k] = u0[k] = u1[k] = ss[k] = 0.0f;
+            g[k].x = c0 ? gv[k * MO_NP + lane] : 0.0f;
+            g[k].y = c1 ? gv[k * MO_NP + lane + 64] : 0.0f;
+            v[k] = ss2[k] = mo_v2{0.0f, 0.0f};
+            u0[k] = u1[k] = 0.0f;
         }
         for (int i0 = 0; i0 < N; i0 += MO_ROWS) {
-            float a0[MO_ROWS], a1[MO_ROWS];
+            mo_v2 a[MO_ROWS];
 #pragma unroll
             for (int q = 0; q < MO_ROWS; ++q) {
                 const bool live_row = i0 + q < N;
-                a0[q] = (live_row && c0) ? __builtin_nontemporal_load(X + (i0 + q) * N + lane) : 0.0f;
-                a1[q] = (live_row && c1) ? __builtin_nontemporal_load(X + (i0 + q) * N + lane + 64) : 0.0f;
+                a[q].x = (live_row && c0) ? __builtin_nontemporal_load(X + (i0 + q) * N + lane) : 0.0f;
+                a[q].y = (live_row && c1) ? __builtin_nontemporal_load(X + (i0 + q) * N + lane + 64) : 0.0f;
             }
 #pragma unroll
             for (int q = 0; q < MO_ROWS; ++q) {
@@ -311,19 +316,27 @@ __global__ __launch_bounds__(MDN_NT) void mdn_outer_kernel(const float* __restri
 #pragma unroll
                     for (int k = 0; k < K; ++k) {
                         const float gi = __int_as_float(__builtin_amdgcn_readlane(
-                            __float_as_int(i < 64 ? g0[k] : g1[k]), i & 63));
+                            __float_as_int(i < 64 ? g[k].x : g[k].y), i & 63));
+                        const mo_v2 gi2{gi, gi};
                         // dead lanes hold g = 0 and x = 0, so their residual is 0 without a select
-                        const float r0 = gi * g0[k] - a0[q], r1 = gi * g1[k] - a1[q];
-                        ss[k] += r0 * r0 + r1 * r1;
-                        v0[k] += r0 * gi;
-                        v1[k] += r1 * gi;
-                        const float p = wave_sum_dpp(r0 * g0[k] + r1 * g1[k]);
+                        const mo_v2 r = gi2 * g[k] - a[q];
+                        ss2[k] += r * r;
+                        v[k] += r * gi2;
+                        const mo_v2 pg = r * g[k];
+                        const float p = wave_sum_dpp(pg.x + pg.y);
                         const float tot = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p), 63));
                         if (i < 64) u0[k] = (lane == i) ? tot : u0[k];
                         else u1[k] = (lane == i - 64) ? tot : u1[k];
                     }
                 }
             }
+        }
+        float ss[K], v0[K], v1[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            ss[k] = ss2[k].x + ss2[k].y;
+            v0[k] = v[k].x;
+            v1[k] = v[k].y;
         }
         float ssk = 0.0f;                                           // lane k < K owns component k
 #pragma unroll
