@@ -262,17 +262,24 @@ __global__ __launch_bounds__(MDN_NT) void mdn_bwd_stream_kernel(const float* __r
 }
 
 // Rank-one components: m_bk = g_bk g_bk^T from the node vectors of the GCN decoder.  One wave per
-// sample reads x[b] once, MO_ROWS rows in flight, lane c owning columns c and c+64; for every
-// component the residual r_ij = g_i g_j - x_ij is formed in registers and feeds, in the same sweep,
+// sample reads x[b] once, MO_ROWS rows in flight, lane c owning columns c and c+64 as a packed
+// pair; for every component the residual r_ij = g_i g_j - x_ij is formed in registers and feeds,
+// in the same sweep,
 //   ss_k  = sum_ij r_ij^2                      (the exponent of the likelihood),
 //   v_k[c] = sum_i r_ic g_i                    (column sums, per lane),
-//   u_k[i] = sum_j r_ij g_j                    (row sums, DPP wave reduction, total in lane 63),
+//   u_k[i] = sum_j r_ij g_j                    (row sums, across the lanes),
 // so that after the log-sum-exp over the K components the gradient of the node vectors is
 // coef_bk (u_k + v_k) with coef_bk = resp_bk / sigma_k^2: the [B,K,N*N] component matrices, their
 // gradient and the passes over them do not exist.  The same wave does the sample's KL part.
+// Row sums: the lanes' partial products of the K * MO_ROWS (component, row) pairs of a row group go
+// to the wave's LDS tile [pair][lane]; lane p then adds up row p of the tile with 16-byte reads
+// and leaves the total in the wave's u table, which the lanes read back per column at the end -
+// about a quarter of the instructions of one cross-lane reduction per pair.
 constexpr int MO_ROWS = 8;
 constexpr int MO_NP = MDNVAE_DEC_NP;
+constexpr int MO_LD = 68;                       // tile row stride: 16-byte rows, lanes 0..7 cover all banks
 typedef float mo_v2 __attribute__((ext_vector_type(2)));
+__host__ __device__ constexpr int mo_wave_floats(int K) { return K * MO_ROWS * MO_LD + K * MO_NP; }
 template <int K>
 __global__ __launch_bounds__(MDN_NT) void mdn_outer_kernel(const float* __restrict__ nodes, const float* __restrict__ x,
                                                            const float* __restrict__ logits,
@@ -282,24 +289,25 @@ __global__ __launch_bounds__(MDN_NT) void mdn_outer_kernel(const float* __restri
                                                            float* __restrict__ glsig_rows, float* __restrict__ gmu,
                                                            float* __restrict__ glogvar, float* __restrict__ resp,
                                                            double* __restrict__ per_sample) {
+    __shared__ __attribute__((aligned(16))) float lds[(MDN_NT / 64) * mo_wave_floats(K)];
     const int lane = threadIdx.x & 63;
     const int wave = blockIdx.x * (MDN_NT / 64) + (threadIdx.x >> 6);
     const int nwaves = gridDim.x * (MDN_NT / 64);
     const int D = N * N;
     const bool c0 = lane < N, c1 = lane + 64 < N;
+    float* tile = lds + (threadIdx.x >> 6) * mo_wave_floats(K);    // [K * MO_ROWS][MO_LD]
+    float* utab = tile + K * MO_ROWS * MO_LD;                       // [K][MO_NP]
     for (int b = wave; b < B; b += nwaves) {
         const float* X = x + (long)b * D;
         const float* gv = nodes + (long)b * K * MO_NP;
         // the lane's two columns (c, c+64) travel as one packed pair: the residual, the sum of
         // squares and the column sums are packed fp32 operations
         mo_v2 g[K], v[K], ss2[K];
-        float u0[K], u1[K];
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             g[k].x = c0 ? gv[k * MO_NP + lane] : 0.0f;
             g[k].y = c1 ? gv[k * MO_NP + lane + 64] : 0.0f;
             v[k] = ss2[k] = mo_v2{0.0f, 0.0f};
-            u0[k] = u1[k] = 0.0f;
         }
         for (int i0 = 0; i0 < N; i0 += MO_ROWS) {
             mo_v2 a[MO_ROWS];
@@ -323,20 +331,38 @@ __global__ __launch_bounds__(MDN_NT) void mdn_outer_kernel(const float* __restri
                         ss2[k] += r * r;
                         v[k] += r * gi2;
                         const mo_v2 pg = r * g[k];
-                        const float p = wave_sum_dpp(pg.x + pg.y);
-                        const float tot = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p), 63));
-                        if (i < 64) u0[k] = (lane == i) ? tot : u0[k];
-                        else u1[k] = (lane == i - 64) ? tot : u1[k];
+                        tile[(k * MO_ROWS + q) * MO_LD + lane] = pg.x + pg.y;
                     }
                 }
             }
+            // LDS operations of one wave execute in program order; the fence keeps the compiler
+            // from moving the reads below ahead of the writes above (and the next group's writes
+            // ahead of these reads)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (lane < K * MO_ROWS) {
+                const int k = lane / MO_ROWS, q = lane - k * MO_ROWS;
+                if (i0 + q < N) {
+                    const v4f* row = reinterpret_cast<const v4f*>(tile + lane * MO_LD);
+                    v4f acc4 = row[0];
+#pragma unroll
+                    for (int j = 1; j < 16; ++j) acc4 += row[j];
+                    utab[k * MO_NP + i0 + q] = (acc4.x + acc4.y) + (acc4.z + acc4.w);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
-        float ss[K], v0[K], v1[K];
+        float ss[K], v0[K], v1[K], u0[K], u1[K];
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             ss[k] = ss2[k].x + ss2[k].y;
             v0[k] = v[k].x;
             v1[k] = v[k].y;
+            u0[k] = c0 ? utab[k * MO_NP + lane] : 0.0f;
+            u1[k] = c1 ? utab[k * MO_NP + lane + 64] : 0.0f;
         }
         float ssk = 0.0f;                                           // lane k < K owns component k
 #pragma unroll
