@@ -166,9 +166,13 @@ def _decoder_work(args, backward):
     B, N, L, R, NL = args[2 + backward], args[3 + backward], args[4 + backward], args[5 + backward], args[6 + backward]
     components = args[14 + backward]
     matrix = args[15 + backward]                       # out (forward) / grad_out (backward)
+    if matrix is None:
+        # chain stage alone: matrix-core work, one 96x96 panel product per (sample, channel, layer)
+        # forward; recompute + dh.W backward, plus the weight-gradient operands it emits
+        return 2.0 * B * R * NL * ops.DEC_KP * ops.DEC_NP * (2 if backward else 1)
     rows = R if components else 1
     extra = R * NL * (ops.DEC_KP + ops.DEC_NP) + L if backward else L
-    return 4.0 * B * ((rows * N * N if matrix is not None else 0) + R * ops.DEC_NP + extra)
+    return 4.0 * B * (rows * N * N + R * ops.DEC_NP + extra)
 
 
 def _mdn_outer_work(a):
@@ -193,8 +197,7 @@ ABI_TAGS = {
     "mdnvae_tri_pack": ("tri_pack_kernel", lambda a: 4.0 * a[1] * (a[2] * a[2] + a[2] * (a[2] + 1) // 2)),
 }
 HBM_TAGS = {v[0] for v in ABI_TAGS.values() if isinstance(v[0], str)} | {
-    "chain_fwd_mfma_kernel+outer_epilogue_kernel", "chain_fwd_mfma_kernel", "outer_grad_kernel+chain_bwd_mfma_kernel",
-    "chain_bwd_mfma_kernel"}
+    "chain_fwd_mfma_kernel+outer_epilogue_kernel", "outer_grad_kernel+chain_bwd_mfma_kernel"}
 
 
 def install_clock(clock):
