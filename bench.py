@@ -383,6 +383,7 @@ def main():
     ap.add_argument("--nodes", type=int, default=87)
     ap.add_argument("--pool", type=int, default=2, help="resident synthetic batches per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-n68", action="store_true", help="skip the short 68 x 68 run reported under 'n68' on one GPU")
     ap.add_argument("--no-kernel-clock", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="all-reduce every gradient after backward")
     ap.add_argument("--full-first-layer", action="store_true",
@@ -441,6 +442,14 @@ def main():
                      "training step uses the rank-one form (mdn_outer_kernel)")
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(args.model, args.nodes)
+    if world == 1 and args.nodes != 68 and not args.no_n68:
+        # the reference-parity shape (68 x 68 crop) next to the 87 x 87 headline shape
+        steps68 = max(2, min(args.steps, 4))
+        el68, loss68, _, _, what68 = run_workload(args.model, batch, 68, steps68, 2, args.pool, device, rank, world, False,
+                                                  not args.no_overlap, not args.full_first_layer)
+        line["n68"] = {"workload": what68, "value": batch * steps68 / el68, "unit": "samples/s", "per_gpu_batch": batch,
+                       "steps": steps68, "warmup": 2, "ms_per_step": el68 / steps68 * 1e3,
+                       "final_loss_per_sample": loss68 / batch}
     if world == 1 and args.also and args.also != args.model:
         ab = default_batch(args.also)
         steps = max(2, min(args.steps, 4))
