@@ -193,7 +193,7 @@ ABI_TAGS = {
     "mdnvae_decoder_bwd": (lambda a: "outer_grad_kernel+chain_bwd_mfma_kernel" if a[16] is not None
                            else "chain_bwd_mfma_kernel", lambda a: _decoder_work(a, 1)),
     "mdnvae_adam_step": ("adam_kernel", lambda a: 28.0 * a[4]),
-    # args: (x, B, N, out, asym, stream): read N*N, write the triangle, per matrix
+    # args: (x, B, N, ld, out, asym, stream): read N*N, write the triangle, per matrix
     "mdnvae_tri_pack": ("tri_pack_kernel", lambda a: 4.0 * a[1] * (a[2] * a[2] + a[2] * (a[2] + 1) // 2)),
 }
 HBM_TAGS = {v[0] for v in ABI_TAGS.values() if isinstance(v[0], str)} | {

@@ -179,11 +179,13 @@ int mdnvae_linear_wgrad(const float* grad_pre, const float* x, int B, int N, int
  * the N(N+1)/2 upper-triangle entries with w[h,i,j] + w[h,j,i], at half the GEMM work, and the
  * weight gradients of (i,j) and (j,i) are one value.  t(i,j) = i*N - i(i-1)/2 + (j-i), i <= j.
  * N <= 192. */
-/* out [B,T] = upper triangle of x [B,N,N]; *asym is OR-ed with 1 when some x[b,i,j] != x[b,j,i]
- * (a NaN counts as different), so that a caller can refuse input the shortcut does not hold for. */
-int mdnvae_tri_pack(const float* x, long B, int N, float* out, int* asym, void* stream);
-/* out [H,T]: out[h,t(i,j)] = w[h,i,j] + w[h,j,i] for i < j, w[h,i,i] on the diagonal. */
-int mdnvae_tri_fold(const float* w, long H, int N, float* out, void* stream);
+/* out [B,ld] (ld >= T = N(N+1)/2, columns T..ld-1 are written as zeros: a row stride that is a
+ * multiple of 4 keeps the GEMM operands 16-byte aligned) = upper triangle of x [B,N,N]; *asym is
+ * OR-ed with 1 when some x[b,i,j] != x[b,j,i] (a NaN counts as different), so that a caller can
+ * refuse input the shortcut does not hold for. */
+int mdnvae_tri_pack(const float* x, long B, int N, int ld, float* out, int* asym, void* stream);
+/* out [H,ld]: out[h,t(i,j)] = w[h,i,j] + w[h,j,i] for i < j, w[h,i,i] on the diagonal, zeros past T. */
+int mdnvae_tri_fold(const float* w, long H, int N, int ld, float* out, void* stream);
 /* grad_w [H,N*N]: grad_w[h,i*N+j] = g[t(min(i,j),max(i,j))*stride_t + h*stride_h], g being the
  * weight gradient of the folded layer stored as [H,T] (stride_t = 1) or [T,H] (stride_h = 1). */
 int mdnvae_tri_unfold(const float* g, long H, int N, long stride_t, long stride_h, float* grad_w, void* stream);

@@ -22,12 +22,13 @@ __device__ __forceinline__ int tri_index(int i, int j, int N) { return i * N - (
 //   FOLD = false: out[t] = m[i][j], *asym |= (m[i][j] != m[j][i])
 //   FOLD = true : out[t] = m[i][j] + m[j][i] (i < j), m[i][i]
 template <bool FOLD>
-__global__ __launch_bounds__(256) void tri_pack_kernel(const float* __restrict__ src, int N, int T,
+__global__ __launch_bounds__(256) void tri_pack_kernel(const float* __restrict__ src, int N, int T, int ld,
                                                        float* __restrict__ out, int* __restrict__ asym) {
     extern __shared__ float sm[];
     const int P = N * N;
     const float* m = src + (long)blockIdx.x * P;
-    float* o = out + (long)blockIdx.x * T;
+    float* o = out + (long)blockIdx.x * ld;
+    if (threadIdx.x < ld - T) o[T + threadIdx.x] = 0.0f;           // padding columns of the row
     const int P4 = P >> 2;
     for (int q = threadIdx.x; q < P4; q += 256) {
         const tri_v4 v = __builtin_nontemporal_load(reinterpret_cast<const tri_v4u*>(m) + q);
@@ -91,7 +92,7 @@ using namespace mdnvae;
 
 extern "C" {
 
-static int tri_launch(bool fold, const float* src, long rows, int N, float* out, int* asym, void* stream,
+static int tri_launch(bool fold, const float* src, long rows, int N, int ld, float* out, int* asym, void* stream,
                       const char* who) {
     MV_REQUIRE(rows >= 0 && N >= 1, E_ARG, "%s: bad shape", who);
     MV_REQUIRE(N <= 192, E_SHAPE, "%s: N = %d exceeds the LDS-resident matrix limit (192)", who, N);
@@ -99,6 +100,7 @@ static int tri_launch(bool fold, const float* src, long rows, int N, float* out,
     if (rows == 0) return 0;
     MV_REQUIRE(src && out && (fold || asym), E_ARG, "%s: null pointer", who);
     const int T = N * (N + 1) / 2;
+    MV_REQUIRE(ld >= T && ld - T < 256, E_ARG, "%s: row stride %d for %d triangle entries", who, ld, T);
     const size_t lds = sizeof(float) * (size_t)N * N;
     if (fold) {
         if (lds > 64 * 1024) {
@@ -107,7 +109,7 @@ static int tri_launch(bool fold, const float* src, long rows, int N, float* out,
             MV_REQUIRE(e == hipSuccess, (int)e, "%s: cannot raise the LDS limit: %s", who, hipGetErrorString(e));
         }
         hipLaunchKernelGGL(tri_pack_kernel<true>, dim3((unsigned)rows), dim3(256), lds, (hipStream_t)stream, src, N, T,
-                           out, asym);
+                           ld, out, asym);
     } else {
         if (lds > 64 * 1024) {
             const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tri_pack_kernel<false>),
@@ -115,18 +117,18 @@ static int tri_launch(bool fold, const float* src, long rows, int N, float* out,
             MV_REQUIRE(e == hipSuccess, (int)e, "%s: cannot raise the LDS limit: %s", who, hipGetErrorString(e));
         }
         hipLaunchKernelGGL(tri_pack_kernel<false>, dim3((unsigned)rows), dim3(256), lds, (hipStream_t)stream, src, N, T,
-                           out, asym);
+                           ld, out, asym);
     }
     MV_LAUNCH_CHECK("tri_pack_kernel");
     return 0;
 }
 
-int mdnvae_tri_pack(const float* x, long B, int N, float* out, int* asym, void* stream) {
-    return tri_launch(false, x, B, N, out, asym, stream, "mdnvae_tri_pack");
+int mdnvae_tri_pack(const float* x, long B, int N, int ld, float* out, int* asym, void* stream) {
+    return tri_launch(false, x, B, N, ld, out, asym, stream, "mdnvae_tri_pack");
 }
 
-int mdnvae_tri_fold(const float* w, long H, int N, float* out, void* stream) {
-    return tri_launch(true, w, H, N, out, nullptr, stream, "mdnvae_tri_fold");
+int mdnvae_tri_fold(const float* w, long H, int N, int ld, float* out, void* stream) {
+    return tri_launch(true, w, H, N, ld, out, nullptr, stream, "mdnvae_tri_fold");
 }
 
 int mdnvae_tri_unfold(const float* g, long H, int N, long stride_t, long stride_h, float* grad_w, void* stream) {

@@ -178,13 +178,20 @@ def linear_act(x, weight, bias=None, act=None):
 
 
 def tri_pack(x, n_nodes, asym):
-    """Upper triangles [B, N(N+1)/2] of a batch of symmetric matrices x [B, N*N]; `asym` (int32[1]
+    """Upper triangles [B, tri_row_stride(N)] of a batch of symmetric matrices x [B, N*N]; `asym` (int32[1]
     on the device) is OR-ed with 1 if a matrix is not symmetric.  The result carries no gradient:
     the symmetric first layer is for network inputs."""
     x = _c(x.detach()).reshape(-1, n_nodes * n_nodes)
-    out = torch.empty(x.shape[0], n_nodes * (n_nodes + 1) // 2, dtype=torch.float32, device=x.device)
-    call("mdnvae_tri_pack", ptr(x, "x"), x.shape[0], n_nodes, ptr(out), asym.data_ptr(), stream())
+    ld = tri_row_stride(n_nodes)
+    out = torch.empty(x.shape[0], ld, dtype=torch.float32, device=x.device)
+    call("mdnvae_tri_pack", ptr(x, "x"), x.shape[0], n_nodes, ld, ptr(out), asym.data_ptr(), stream())
     return out
+
+
+def tri_row_stride(n_nodes):
+    """Row length of the packed triangles: N(N+1)/2 rounded up to a multiple of 64 floats (zero
+    filled), the inner-dimension granularity the library GEMM kernels run fastest at."""
+    return (n_nodes * (n_nodes + 1) // 2 + 63) // 64 * 64
 
 
 class _SymLinearAct(torch.autograd.Function):
@@ -197,7 +204,7 @@ class _SymLinearAct(torch.autograd.Function):
         weight = _c(weight)
         H, T = weight.shape[0], xt.shape[1]
         wt = torch.empty(H, T, dtype=torch.float32, device=xt.device)
-        call("mdnvae_tri_fold", ptr(weight, "weight"), H, n_nodes, ptr(wt), stream())
+        call("mdnvae_tri_fold", ptr(weight, "weight"), H, n_nodes, T, ptr(wt), stream())
         y = _library_gemm(xt, wt.t())
         call("mdnvae_bias_act", ptr(y), ptr(bias, "bias"), y.shape[0], y.shape[1], act, stream())
         ctx.save_for_backward(xt, y)

@@ -32,15 +32,18 @@ def test_pack_fold_unfold_against_numpy(n, rows):
     T = n * (n + 1) // 2
     flag = torch.zeros(1, dtype=torch.int32, device=DEV)
     packed = ops.tri_pack(torch.from_numpy(sym).to(DEV), n, flag)
-    assert packed.shape == (rows, T)
-    assert np.array_equal(packed.cpu().numpy(), sym[:, i, j])
+    ld = ops.tri_row_stride(n)
+    assert ld % 64 == 0 and 0 <= ld - T < 64 and packed.shape == (rows, ld)
+    assert np.array_equal(packed.cpu().numpy()[:, :T], sym[:, i, j])
+    assert not packed.cpu().numpy()[:, T:].any()
     assert int(flag.item()) == 0
     # fold: w_ij + w_ji off the diagonal, w_ii on it
     w = torch.from_numpy(a.reshape(rows, n * n)).to(DEV)
-    folded = torch.empty(rows, T, device=DEV)
-    _lib.call("mdnvae_tri_fold", _lib.ptr(w), rows, n, _lib.ptr(folded), _lib.stream())
+    folded = torch.full((rows, ld), float("nan"), device=DEV)
+    _lib.call("mdnvae_tri_fold", _lib.ptr(w), rows, n, ld, _lib.ptr(folded), _lib.stream())
     want = np.where(i == j, a[:, i, j], a[:, i, j] + a[:, j, i])
-    assert np.array_equal(folded.cpu().numpy(), want.astype(np.float32))
+    assert np.array_equal(folded.cpu().numpy()[:, :T], want.astype(np.float32))
+    assert not folded.cpu().numpy()[:, T:].any()
     # unfold from both storage orders
     g = rng.standard_normal((rows, T)).astype(np.float32)
     full = np.zeros((rows, n, n), np.float32)
@@ -74,7 +77,9 @@ def test_pack_flags_asymmetric_and_nan_input():
 def test_bad_arguments_are_refused():
     x = torch.zeros(4, device=DEV)
     with pytest.raises(Exception):
-        _lib.call("mdnvae_tri_pack", _lib.ptr(x), 1, 193, _lib.ptr(x), _lib.ptr(x), _lib.stream())
+        _lib.call("mdnvae_tri_pack", _lib.ptr(x), 1, 193, 193 * 97, _lib.ptr(x), _lib.ptr(x), _lib.stream())
+    with pytest.raises(Exception):
+        _lib.call("mdnvae_tri_pack", _lib.ptr(x), 1, 4, 9, _lib.ptr(x), _lib.ptr(x), _lib.stream())   # stride < 10
     with pytest.raises(Exception):
         _lib.call("mdnvae_tri_unfold", _lib.ptr(x), 1, 2, 2, 2, _lib.ptr(x), _lib.stream())
 
