@@ -307,7 +307,7 @@ def mixture_stream_rates(batch, nodes, device, reps=5):
 
 
 def run_workload(model_name, batch, nodes, steps, warmup, pool_batches, device, rank, world, use_clock,
-                 overlap=True, symmetric=True):
+                 overlap=True, symmetric=True, graph=False):
     """Warm up, then time exactly `steps` steps between barrier + synchronize pairs; returns
     (elapsed seconds: max over ranks, final loss, kernel clock, wall time of the instrumented pass
     or None, workload description)."""
@@ -326,9 +326,15 @@ def run_workload(model_name, batch, nodes, steps, warmup, pool_batches, device, 
     trainer = M.Trainer(model, mode) if overlap else M.Trainer(model, mode, overlap_floats=0)
     eps_gen = torch.Generator(device=device).manual_seed(99 + rank)
 
+    if graph:                                    # the whole step recorded once, replayed as one launch
+        x0 = pool[:batch]
+        trainer.capture((x0,) + extra_inputs, x0, torch.randn(batch, 68, device=device, generator=eps_gen))
+
     def one_step(i):
         x = pool[(i % pool_batches) * batch:(i % pool_batches + 1) * batch]
         eps = torch.randn(batch, 68, device=device, generator=eps_gen)
+        if graph:
+            return trainer.replay((x,) + extra_inputs, x, eps)
         return trainer.step((x,) + extra_inputs, x, eps=eps)
 
     for i in range(warmup):
@@ -383,6 +389,10 @@ def main():
     ap.add_argument("--nodes", type=int, default=87)
     ap.add_argument("--pool", type=int, default=2, help="resident synthetic batches per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-script-batch", action="store_true",
+                    help="skip the batch-256 runs (eager and graph replay) reported under 'script_batch' on one GPU")
+    ap.add_argument("--graph", action="store_true", help="run the main workload's steps as replays of a captured HIP graph "
+                                                          "(single GPU)")
     ap.add_argument("--no-n68", action="store_true", help="skip the short 68 x 68 run reported under 'n68' on one GPU")
     ap.add_argument("--no-kernel-clock", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="all-reduce every gradient after backward")
@@ -412,8 +422,9 @@ def main():
     batch = args.batch or default_batch(args.model)
     elapsed, final_loss, clock, clocked, what = run_workload(args.model, batch, args.nodes, args.steps, args.warmup,
                                                              args.pool, device, rank, world,
-                                                             not args.no_kernel_clock, not args.no_overlap,
-                                                             not args.full_first_layer)
+                                                             not args.no_kernel_clock and not args.graph,
+                                                             not args.no_overlap, not args.full_first_layer,
+                                                             graph=args.graph and world == 1)
     if rank == 0:
         line = {
             "metric": "train samples/sec (fwd+bwd, 87x87 connectome)" if args.nodes == 87 else
@@ -450,6 +461,16 @@ def main():
         line["n68"] = {"workload": what68, "value": batch * steps68 / el68, "unit": "samples/s", "per_gpu_batch": batch,
                        "steps": steps68, "warmup": 2, "ms_per_step": el68 / steps68 * 1e3,
                        "final_loss_per_sample": loss68 / batch}
+    if world == 1 and not args.no_script_batch and args.model in ("mm_gate", "mdn_gate"):
+        # the scripts' own batch size (function/VAE_CNN_NN.py:53): launch-bound when issued call by
+        # call, so the step is also timed as one replayed HIP graph
+        sb, ssteps = 256, 100
+        entry = {"per_gpu_batch": sb, "steps": ssteps, "warmup": 10, "unit": "samples/s"}
+        for key, use_graph in (("eager", False), ("graph", True)):
+            el, ls, _, _, _ = run_workload(args.model, sb, args.nodes, ssteps, 10, args.pool, device, rank, world, False,
+                                           not args.no_overlap, not args.full_first_layer, graph=use_graph)
+            entry[key] = {"value": sb * ssteps / el, "ms_per_step": el / ssteps * 1e3, "final_loss_per_sample": ls / sb}
+        line["script_batch"] = entry
     if world == 1 and args.also and args.also != args.model:
         ab = default_batch(args.also)
         steps = max(2, min(args.steps, 4))

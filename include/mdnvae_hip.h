@@ -252,6 +252,12 @@ int mdnvae_maxpool_bwd(const float* grad_feat, const int* argmax, long nplanes, 
  * the gradient first (1 for a SUM-reduced data-parallel gradient). */
 int mdnvae_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n, int step, float lr,
                      float beta1, float beta2, float eps, float grad_scale, void* stream);
+/* The same update with the step count on the device (*step_dev is incremented first, so it starts
+ * at 0; coef_dev: two floats of workspace): nothing in the call changes from step to step, which is
+ * what a step captured once into a HIP graph and replayed needs. */
+int mdnvae_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n, int* step_dev,
+                         float* coef_dev, float lr, float beta1, float beta2, float eps, float grad_scale,
+                         void* stream);
 
 /* ---- trait-gated Gaussian-mixture likelihood (BUILD-DEFINED: the reference has no such code) ----
  * comp_mean [B,K,D] component means, x [B,D], gate_logits [B,K] (from the traits), log_sigma [K];

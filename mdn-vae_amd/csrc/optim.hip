@@ -7,10 +7,25 @@
 
 namespace mdnvae {
 
+// The step count of a captured (graph-replayed) step lives on the device: this one-thread kernel
+// advances it and leaves {lr / (1 - b1^t), sqrt(1 - b2^t)} for the update kernel.
+__global__ void adam_advance_kernel(int* __restrict__ step, float lr, float b1, float b2, float* __restrict__ coef) {
+    const int t = *step + 1;
+    *step = t;
+    const double bc1 = 1.0 - pow((double)b1, (double)t), bc2 = 1.0 - pow((double)b2, (double)t);
+    coef[0] = (float)((double)lr / bc1);
+    coef[1] = (float)sqrt(bc2);
+}
+
+// coef (device, {step size, sqrt of the second bias correction}) overrides the two scalars when given
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, long n, float b1,
                                                    float b2, float eps, float step_size, float bc2_sqrt,
-                                                   float grad_scale) {
+                                                   float grad_scale, const float* __restrict__ coef) {
+    if (coef) {
+        step_size = coef[0];
+        bc2_sqrt = coef[1];
+    }
     const long n4 = n >> 2;
     float4* p4 = reinterpret_cast<float4*>(p);
     const float4* g4 = reinterpret_cast<const float4*>(g);
@@ -56,7 +71,29 @@ extern "C" int mdnvae_adam_step(float* param, const float* grad, float* exp_avg,
     if (grid < 1) grid = 1;
     if (grid > 4096) grid = 4096;
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
-                       exp_avg_sq, n, beta1, beta2, eps, step_size, bc2_sqrt, grad_scale);
+                       exp_avg_sq, n, beta1, beta2, eps, step_size, bc2_sqrt, grad_scale, (const float*)nullptr);
+    MV_LAUNCH_CHECK("adam_kernel");
+    return 0;
+}
+
+extern "C" int mdnvae_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n,
+                                    int* step_dev, float* coef_dev, float lr, float beta1, float beta2, float eps,
+                                    float grad_scale, void* stream) {
+    MV_REQUIRE(n >= 0, E_ARG, "mdnvae_adam_step_dev: bad size");
+    MV_REQUIRE(step_dev && coef_dev, E_ARG, "mdnvae_adam_step_dev: the step counter and coefficient pair are device memory");
+    if (n > 0) {
+        MV_REQUIRE(param && grad && exp_avg && exp_avg_sq, E_ARG, "mdnvae_adam_step_dev: null pointer");
+        MV_REQUIRE(aligned16(param) && aligned16(grad) && aligned16(exp_avg) && aligned16(exp_avg_sq), E_ALIGN,
+                   "mdnvae_adam_step_dev: buffers must be 16-byte aligned");
+    }
+    hipLaunchKernelGGL(adam_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step_dev, lr, beta1, beta2, coef_dev);
+    MV_LAUNCH_CHECK("adam_advance_kernel");
+    if (n == 0) return 0;
+    long grid = ((n >> 2) + 255) / 256;
+    if (grid < 1) grid = 1;
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
+                       exp_avg_sq, n, beta1, beta2, eps, 0.0f, 1.0f, grad_scale, (const float*)coef_dev);
     MV_LAUNCH_CHECK("adam_kernel");
     return 0;
 }

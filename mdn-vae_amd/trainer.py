@@ -155,6 +155,61 @@ class Trainer:
         self.optimizer_step()
         return loss
 
+    # ---- one step as a HIP graph ---------------------------------------------------------
+    def capture(self, inputs, target, eps):
+        """Record zero_grad -> forward -> loss -> backward -> Adam for this batch shape once into a
+        HIP graph; `replay` then runs a step as a single graph launch.  A step is a hundred or
+        more kernel launches, and at the scripts' batch sizes (function/VAE_CNN_NN.py:53, batch
+        256) the host cannot issue them as fast as the GPU finishes them; the replayed graph
+        removes that limit.  Tensor inputs, the target and eps are copied into static buffers
+        (the graph reads those addresses); other inputs (the adjacency list) are baked in.  The
+        warm-up and capture passes leave parameters, Adam state and step count untouched.
+        Single-process only: with data-parallel ranks the gradient exchange is not captured."""
+        if _distributed(self.group):
+            raise RuntimeError("Trainer.capture: graph replay is single-process; use step() with data-parallel ranks")
+        if eps is None:
+            raise ValueError("Trainer.capture: eps must be given (the graph cannot draw fresh noise itself)")
+        dev = self.buf.flat_p.device
+        self._g_inputs = tuple(t.detach().clone() if isinstance(t, torch.Tensor) else t for t in inputs)
+        self._g_target = target.detach().clone()
+        self._g_eps = eps.detach().clone()
+        self._g_step = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._g_coef = torch.zeros(2, dtype=torch.float32, device=dev)
+        keep = [t.clone() for t in (self.buf.flat_p, self.exp_avg, self.exp_avg_sq)]
+
+        def one():
+            loss = self.forward_backward(self._g_inputs, self._g_target, self._g_eps)
+            call("mdnvae_adam_step_dev", ptr(self.buf.flat_p), ptr(self.buf.flat_g), ptr(self.exp_avg),
+                 ptr(self.exp_avg_sq), self.buf.numel, self._g_step.data_ptr(), ptr(self._g_coef), float(self.lr),
+                 float(self.betas[0]), float(self.betas[1]), float(self.eps), 1.0, stream())
+            return loss
+
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(2):                      # first calls: library attributes, allocator pools
+                one()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph):
+            self._g_loss = one()
+        for dst, src in zip((self.buf.flat_p, self.exp_avg, self.exp_avg_sq), keep):
+            dst.copy_(src)
+        self._g_step.fill_(self.steps)
+        return self
+
+    def replay(self, inputs, target, eps):
+        """One captured step on new data of the captured shapes; returns the loss tensor of the
+        graph (overwritten by the next replay)."""
+        for dst, src in zip(self._g_inputs, inputs):
+            if isinstance(dst, torch.Tensor):
+                dst.copy_(src)
+        self._g_target.copy_(target)
+        self._g_eps.copy_(eps)
+        self._graph.replay()
+        self.steps += 1
+        return self._g_loss
+
     def hinge_step(self, fc, sc, eps_with=None, eps_without=None, generator=None, margin=0.01):
         """Conditional-VAE step of function_FC_SC/SC-FC.py:134-167: one forward with the FC input,
         one with the FC rows of a random half of the batch zeroed, and

@@ -160,3 +160,38 @@ def test_small_layer_weight_gradient_kernel(B, N, M):
     # reproducible: fixed summation order
     again = ops._linear_wgrad(gp.to(DEV), x.to(DEV))
     assert torch.equal(got, again)
+
+
+def test_captured_step_replays_the_eager_step():
+    """Trainer.capture / replay: three replayed steps leave the same parameters and losses as three
+    eager steps from the same start (same kernels, same order), and capture itself changes nothing."""
+    fix = load_fixture("mm_gate")
+    params = fixture_params(fix)
+    x = torch.from_numpy(fix["x"]).to(DEV)
+    adjacency = [list(map(int, r)) for r in fix["adjacency"]]
+    traits = torch.randn(x.shape[0], 4, generator=torch.Generator().manual_seed(1)).to(DEV)
+    g = torch.Generator().manual_seed(3)
+    batches = [(x * (1.0 + 0.1 * i), torch.randn(x.shape[0], 68, generator=g).to(DEV)) for i in range(3)]
+    out = {}
+    for mode in ("eager", "graph"):
+        torch.manual_seed(5)                      # the gate layer is not in the fixture: same random init both times
+        model = M.MDNGateVAE(R=5, n_nodes=68, k=32, n_layers=3, latent_dim=68, n_traits=4)
+        model.load_state_dict(params, strict=False)
+        with torch.no_grad():
+            model.log_sigma.fill_(1.0)
+        trainer = M.Trainer(model.to(DEV), "mdn")
+        start = trainer.buf.flat_p.clone()
+        losses = []
+        if mode == "graph":
+            trainer.capture((batches[0][0], adjacency, traits), batches[0][0], batches[0][1])
+            assert torch.equal(trainer.buf.flat_p, start) and trainer.steps == 0
+        for xb, eps in batches:
+            if mode == "graph":
+                losses.append(float(trainer.replay((xb, adjacency, traits), xb, eps).item()))
+            else:
+                losses.append(float(trainer.step((xb, adjacency, traits), xb, eps=eps).item()))
+        out[mode] = (losses, trainer.buf.flat_p.clone(), trainer.steps)
+    assert out["graph"][2] == out["eager"][2] == 3
+    for a, b in zip(out["graph"][0], out["eager"][0]):
+        assert abs(a - b) <= 1e-6 * abs(b)
+    assert float((out["graph"][1] - out["eager"][1]).abs().max()) <= 1e-6
