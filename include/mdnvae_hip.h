@@ -294,7 +294,9 @@ int mdnvae_mdn_loss_bwd(const float* comp_mean, const float* x, const float* gat
  * near the mean (the same on every rank); sum [d] and gram [d,d] are float64 accumulators
  * (zeroed by the caller) that add up across calls and, for data-parallel runs, across ranks. */
 size_t mdnvae_fid_gram_workspace_floats(long n, int d);
-/* sum += sum_rows (x - shift);  gram += sum_rows (x - shift)(x - shift)^T  (MFMA GEMM). */
+/* sum += sum_rows (x - shift);  gram += sum_rows (x - shift)(x - shift)^T  (MFMA GEMM).  For
+ * d > 128 only the 128 x 128 tiles of gram on or above the diagonal are maintained (the matrix is
+ * symmetric); mdnvae_fid_finalize reads the rest from their mirror image. */
 int mdnvae_fid_accumulate(const float* x, const float* shift, long n, int d, float* workspace, double* sum,
                           double* gram, void* stream);
 /* mean [d] = shift + sum/n;  cov [d,d] = (gram - sum sum^T/n)/(n-1), float64. */

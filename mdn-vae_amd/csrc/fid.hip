@@ -2,8 +2,9 @@
 //   reference: np.mean / np.cov(rowvar=False) / scipy.linalg.sqrtm / np.trace in calculate_fid,
 //   function/VAE_CNN_NN.py:310-316, 331-337 and validation/FID.py:61-81.
 // Moments: the shifted Gram matrix sum_rows (x-c)(x-c)^T is an MFMA GEMM (fp32 32x32x2 tiles,
-// K = rows) over chunks of 256 rows whose partial tiles are added in float64 in a fixed order;
-// only tiles on or above the diagonal are computed.  Covariance and mean follow in float64.
+// K = rows) over chunks of 1024 rows whose partial tiles are added in float64 in a fixed order;
+// only the 128 x 128 tiles on or above the diagonal are computed and kept.  Covariance and mean
+// follow in float64.
 // The matrix square root is a coupled Newton-Schulz iteration on symmetric PSD matrices, run by
 // the host as float64 library GEMMs; this file supplies its elementwise steps
 // (T = 1.5 I - 0.5 Z Y, symmetrise, trace).
@@ -13,54 +14,111 @@
 namespace mdnvae {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
-constexpr int GR_ROWS = 256;      // rows (K) per chunk
-constexpr int GR_KT = 64;         // rows staged per LDS tile
-constexpr int GR_LD = 65;         // LDS row stride of a [GR_KT][64] tile
+constexpr int GR_ROWS = 1024;     // rows (K) per chunk: fp32 accumulation inside, float64 across chunks
+constexpr int GR_T = 128;         // output tile edge
+constexpr int GR_KC = 16;         // rows staged per LDS buffer
+constexpr int GR_LD = GR_T + 4;   // LDS row stride (16-byte rows)
+constexpr int GR_CAP = 32;        // chunks per launch (bounds the workspace)
 
-// partial[chunk][d][d] (fp32): tile (ti,tj), ti <= tj, of sum over the chunk's rows
-__global__ __launch_bounds__(256) void gram_chunk_kernel(const float* __restrict__ x, const float* __restrict__ shift,
-                                                         long n, int d, float* __restrict__ partial) {
-    __shared__ float ta[GR_KT * GR_LD], tb[GR_KT * GR_LD];
+// partial[chunk][d][d] (fp32): 128 x 128 tile (ti,tj), ti <= tj, of sum over the chunk's rows of
+// (x-c)(x-c)^T.  Four waves as 2 x 2, each a 64 x 64 quadrant (2 x 2 MFMA tiles, two operand reads
+// per two MFMAs); rows are staged 16 at a time through double LDS buffers, fetched into registers
+// one stage ahead with the shift already subtracted.  VEC: d is a multiple of 4 and x is 16-byte
+// aligned, so a staged quad is one load.
+template <bool VEC>
+__global__ __launch_bounds__(256) void gram_tile_kernel(const float* __restrict__ x, const float* __restrict__ shift,
+                                                        long n, int d, float* __restrict__ partial) {
+    __shared__ __attribute__((aligned(16))) float ta[2][GR_KC * GR_LD], tb[2][GR_KC * GR_LD];
     const int ti = blockIdx.x, tj = blockIdx.y;
     if (ti > tj) return;
     const long r0 = (long)blockIdx.z * GR_ROWS;
     const long r1 = min(n, r0 + GR_ROWS);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, l32 = lane & 31;
-    const int wi = wave >> 1, wj = wave & 1;
-    f32x16 acc;
+    const int wi = (wave >> 1) * 64, wj = (wave & 1) * 64;
+    f32x16 acc[2][2];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) acc[j] = 0.0f;
-    for (long rr = r0; rr < r1; rr += GR_KT) {
-        __syncthreads();
-        for (int idx = tid; idx < GR_KT * 64; idx += 256) {
-            const int k = idx >> 6, c = idx & 63;
-            const long row = rr + k;
-            float va = 0.0f, vb = 0.0f;
-            if (row < r1) {
-                const int ca = ti * 64 + c, cb = tj * 64 + c;
-                if (ca < d) va = x[row * d + ca] - shift[ca];
-                if (cb < d) vb = x[row * d + cb] - shift[cb];
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[a][b][j] = 0.0f;
+    // this thread stages quads (row q / 32, column 4 (q % 32)) for q = tid, tid + 256: same column both times
+    const int scol = (tid & 31) * 4, srow = tid >> 5;
+    const int ca = ti * GR_T + scol, cb = tj * GR_T + scol;
+    float sa[4], sb[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        sa[c] = ca + c < d ? shift[ca + c] : 0.0f;
+        sb[c] = cb + c < d ? shift[cb + c] : 0.0f;
+    }
+    float4 pa[2], pb[2];
+    auto quad = [&](long row, int col, const float (&sh)[4]) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < r1) {
+            const float* p = x + row * d + col;
+            if (VEC) {
+                if (col < d) {
+                    v = *reinterpret_cast<const float4*>(p);
+                    v.x -= sh[0]; v.y -= sh[1]; v.z -= sh[2]; v.w -= sh[3];
+                }
+            } else {
+                if (col < d) v.x = p[0] - sh[0];
+                if (col + 1 < d) v.y = p[1] - sh[1];
+                if (col + 2 < d) v.z = p[2] - sh[2];
+                if (col + 3 < d) v.w = p[3] - sh[3];
             }
-            ta[k * GR_LD + c] = va;
-            tb[k * GR_LD + c] = vb;
         }
+        return v;
+    };
+    auto fetch = [&](long rr) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            pa[i] = quad(rr + srow + 8 * i, ca, sa);
+            pb[i] = quad(rr + srow + 8 * i, cb, sb);
+        }
+    };
+    auto commit = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            *reinterpret_cast<float4*>(&ta[buf][(srow + 8 * i) * GR_LD + scol]) = pa[i];
+            *reinterpret_cast<float4*>(&tb[buf][(srow + 8 * i) * GR_LD + scol]) = pb[i];
+        }
+    };
+    fetch(r0);
+    commit(0);
+    __syncthreads();
+    int cur = 0;
+    for (long rr = r0; rr < r1; rr += GR_KC, cur ^= 1) {
+        const bool more = rr + GR_KC < r1;
+        if (more) fetch(rr + GR_KC);
+        const float* ap = ta[cur] + h * GR_LD + wi + l32;
+        const float* bp = tb[cur] + h * GR_LD + wj + l32;
+#pragma unroll
+        for (int k = 0; k < GR_KC; k += 2) {
+            const float a0 = ap[k * GR_LD], a1 = ap[k * GR_LD + 32];
+            const float b0 = bp[k * GR_LD], b1 = bp[k * GR_LD + 32];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (more) commit(cur ^ 1);
         __syncthreads();
-#pragma unroll 8
-        for (int k = 0; k < GR_KT; k += 2) {
-            const float a = ta[(k + h) * GR_LD + wi * 32 + l32];
-            const float b = tb[(k + h) * GR_LD + wj * 32 + l32];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
-        }
     }
     float* dst = partial + (long)blockIdx.z * d * d;
-    const int col = tj * 64 + wj * 32 + l32;
-    if (col < d) {
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const int row = ti * 64 + wi * 32 + (j & 3) + 8 * (j >> 2) + 4 * h;
-            if (row < d) dst[(long)row * d + col] = acc[j];
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int col = tj * GR_T + wj + 32 * b + l32;
+            if (col < d) {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const int row = ti * GR_T + wi + 32 * a + (j & 3) + 8 * (j >> 2) + 4 * h;
+                    if (row < d) dst[(long)row * d + col] = acc[a][b][j];
+                }
+            }
         }
-    }
 }
 
 // Small feature dimensions (the d = 5, 10, 30 of the scripts): the Gram matrix entirely in float64,
@@ -111,17 +169,24 @@ __global__ __launch_bounds__(256) void gram_f64_reduce_kernel(const double* __re
     gram[idx] += s;
 }
 
-// gram[i][j] += sum_chunks partial (float64), mirrored below the diagonal
+// gram[i][j] += sum_chunks partial (float64) for the elements of the 128 x 128 tiles on or above the
+// diagonal; the tiles below it are not maintained (cov_finalize_kernel reads their mirror image)
 __global__ __launch_bounds__(256) void gram_reduce_kernel(const float* __restrict__ partial, int nchunks, int d,
                                                           double* __restrict__ gram) {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (long)d * d) return;
-    const int i = (int)(idx / d), j = (int)(idx % d);
-    const int ti = i >> 6, tj = j >> 6;
-    // element (i,j) was computed if its tile is on/above the diagonal; otherwise read (j,i)
-    const long src = (ti <= tj) ? idx : (long)j * d + i;
+    const int i = (int)(idx / d), j = (int)(idx - (long)i * d);
+    if (i / GR_T > j / GR_T) return;
     double s = 0.0;
-    for (int c = 0; c < nchunks; ++c) s += (double)partial[(long)c * d * d + src];
+    int c = 0;
+    for (; c + 4 <= nchunks; c += 4) {
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = partial[(long)(c + u) * d * d + idx];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) s += (double)v[u];
+    }
+    for (; c < nchunks; ++c) s += (double)partial[(long)c * d * d + idx];
     gram[idx] += s;
 }
 
@@ -157,7 +222,9 @@ __global__ __launch_bounds__(256) void cov_finalize_kernel(const double* __restr
     if (idx < d) mean[idx] = (double)shift[idx] + sum[idx] / n;
     if (idx < (long)d * d) {
         const int i = (int)(idx / d), j = (int)(idx % d);
-        cov[idx] = (gram[idx] - sum[i] * sum[j] / n) / (n - 1.0);
+        // the accumulator keeps the 128 x 128 tiles on or above the diagonal only
+        const long src = (i / GR_T <= j / GR_T) ? idx : (long)j * d + i;
+        cov[idx] = (gram[src] - sum[i] * sum[j] / n) / (n - 1.0);
     }
 }
 
@@ -226,7 +293,7 @@ size_t mdnvae_fid_gram_workspace_floats(long n, int d) {
         return gram > colsum ? gram : colsum;
     }
     const long nch = (n + GR_ROWS - 1) / GR_ROWS;
-    const long cap = nch < 64 ? nch : 64;            // chunks processed per launch
+    const long cap = nch < GR_CAP ? nch : GR_CAP;    // chunks processed per launch
     const size_t gram = (size_t)cap * d * d;
     return gram > colsum ? gram : colsum;
 }
@@ -253,14 +320,19 @@ int mdnvae_fid_accumulate(const float* x, const float* shift, long n, int d, flo
         }
         return launch_shifted_colsum(x, shift, n, d, part, sum, st);
     }
-    const int tiles = (d + 63) / 64;
-    const long rows_per_launch = 64L * GR_ROWS;
+    const int tiles = (d + GR_T - 1) / GR_T;
+    const long rows_per_launch = (long)GR_CAP * GR_ROWS;
+    const bool vec = (d & 3) == 0 && aligned16(x);
     for (long r0 = 0; r0 < n; r0 += rows_per_launch) {
         const long rows = (n - r0 < rows_per_launch) ? n - r0 : rows_per_launch;
         const int nch = (int)((rows + GR_ROWS - 1) / GR_ROWS);
-        hipLaunchKernelGGL(gram_chunk_kernel, dim3(tiles, tiles, nch), dim3(256), 0, st, x + r0 * d, shift, rows, d,
-                           workspace);
-        MV_LAUNCH_CHECK("gram_chunk_kernel");
+        if (vec)
+            hipLaunchKernelGGL(gram_tile_kernel<true>, dim3(tiles, tiles, nch), dim3(256), 0, st, x + r0 * d, shift, rows,
+                               d, workspace);
+        else
+            hipLaunchKernelGGL(gram_tile_kernel<false>, dim3(tiles, tiles, nch), dim3(256), 0, st, x + r0 * d, shift, rows,
+                               d, workspace);
+        MV_LAUNCH_CHECK("gram_tile_kernel");
         hipLaunchKernelGGL(gram_reduce_kernel, dim3(grid_for((long)d * d)), dim3(256), 0, st, workspace, nch, d, gram);
         MV_LAUNCH_CHECK("gram_reduce_kernel");
     }
