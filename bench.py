@@ -188,6 +188,9 @@ ABI_TAGS = {
     "mdnvae_mdn_loss_fwd": ("mdn_fwd_kernel", lambda a: 4.0 * a[4] * ((a[5] + 1) * a[6] + 2 * a[9] + 3 * a[5])),
     "mdnvae_mdn_loss_bwd": ("mdn_bwd_stream_kernel", lambda a: 4.0 * a[6] * ((2 * a[7] + 1) * a[8] + 4 * a[11] + 5 * a[7])),
     "mdnvae_mdn_outer_fwdbwd": ("mdn_outer_kernel", _mdn_outer_work),
+    # (mode, nodes, x, B, R, N, mu, logvar, L, ...): x once, node vectors in, their gradient out, latent rows
+    "mdnvae_outer_loss_fwdbwd": ("outer_loss_kernel",
+                                 lambda a: 4.0 * a[3] * (a[5] * a[5] + 2 * a[4] * ops.DEC_NP + 4 * a[8])),
     "mdnvae_decoder_fwd": (lambda a: "chain_fwd_mfma_kernel+outer_epilogue_kernel" if a[15] is not None
                            else "chain_fwd_mfma_kernel", lambda a: _decoder_work(a, 0)),
     "mdnvae_decoder_bwd": (lambda a: "outer_grad_kernel+chain_bwd_mfma_kernel" if a[16] is not None

@@ -64,6 +64,17 @@ int mdnvae_vae_loss_fwdbwd(int mode, const float* recon, const float* x, long B,
                            const float* logvar, long L, float* grad_recon, float* grad_mu,
                            float* grad_logvar, void* workspace, float* loss_out, void* stream);
 
+/* loss_function(recon, x, mu, logvar) and its gradients for recon[b] = sum_r g_br g_br^T (the plain
+ * sum of outer products of the multi-channel GCN decoder, function/MM_Gate.py:126-138, 179-182),
+ * straight from the node vectors nodes [B,R,MDNVAE_DEC_NP] in one pass over x: neither recon nor
+ * its gradient is written to memory.  Upstream gradient 1.  grad_nodes [B,R,MDNVAE_DEC_NP]
+ * (columns >= N zero), grad_mu / grad_logvar [B,L] (both or neither), loss_out[3] = {total, recon
+ * term, KL}; workspace of mdnvae_outer_loss_workspace_bytes(B) bytes.  R <= 8, N <= MDNVAE_DEC_NP-1. */
+size_t mdnvae_outer_loss_workspace_bytes(int B);
+int mdnvae_outer_loss_fwdbwd(int mode, const float* nodes, const float* x, int B, int R, int N, const float* mu,
+                             const float* logvar, int L, float* grad_nodes, float* grad_mu, float* grad_logvar,
+                             void* workspace, float* loss_out, void* stream);
+
 /* ---- multi-channel chain decoder ---------------------------------------------------------
  * R channels; channel r maps z [B,L] through NL small dense layers to a node vector g_r [B,N];
  * out[b, i*N+j] = f( sum_r g_r[b,i]*g_r[b,j] ).  Serves

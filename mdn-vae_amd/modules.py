@@ -331,6 +331,10 @@ class MultiChannelGCNDecoder(nn.Module):
 class GCNVAE(nn.Module):
     """`VAE` of function/MM_Gate.py:143-177."""
 
+    # forward(..., nodes_only=True) gives node vectors whose plain sum of outer products is the
+    # reconstruction: the trainer may take loss and gradients from them directly
+    rank_one_sum_decoder = True
+
     def __init__(self, R=5, n_nodes=68, k=32, n_layers=3, latent_dim=68, symmetric_input=False):
         super().__init__()
         self.n_nodes = n_nodes
@@ -374,10 +378,15 @@ class GCNVAE(nn.Module):
     def decode(self, z, adjacency):
         return self.decoder(z, adjacency)
 
-    def forward(self, x, adjacency, eps=None):
+    def forward(self, x, adjacency, eps=None, nodes_only=False):
+        """(recon, mu, logvar) as in function/MM_Gate.py:170-177; with nodes_only the first entry is
+        the decoder's node vectors [B,R,NP] (recon = sum_r g_r g_r^T), which the trainer's fused
+        step turns into loss and gradients without writing the reconstruction out."""
         x = x.reshape(-1, self.n_nodes * self.n_nodes)
         mu, logvar = self.encode(x)
         z = self.reparameterize(mu, logvar, eps)
+        if nodes_only:
+            return self.decoder.node_vectors(z, adjacency), mu, logvar
         return self.decode(z, adjacency), mu, logvar
 
 
@@ -386,6 +395,8 @@ class MDNGateVAE(GCNVAE):
     has no mixture code; this is the model its name and data/trait.pt point at.  The R channel
     matrices of the GCN decoder are the component means, a linear gate on the subject's traits
     gives the mixture weights, and each component has one learned log-scale."""
+
+    rank_one_sum_decoder = False        # its channels are mixture components, not summands
 
     def __init__(self, R=5, n_nodes=68, k=32, n_layers=3, latent_dim=68, n_traits=4, symmetric_input=False):
         super().__init__(R=R, n_nodes=n_nodes, k=k, n_layers=n_layers, latent_dim=latent_dim,

@@ -755,6 +755,26 @@ def mdn_loss(comp_mean, x, gate_logits, log_sigma, mu, logvar):
     return mdn_loss_terms(comp_mean, x, gate_logits, log_sigma, mu, logvar)[0]
 
 
+def outer_sum_loss_and_grads(nodes, x, mu, logvar, mode, n_nodes):
+    """Reconstruction loss + KL for recon = sum_r g_r g_r^T given by node vectors nodes [B,R,NP]
+    (chain decoder with nodes_only; no activation or intercept on the sum), and the gradients of
+    the total (upstream 1), from one pass over x: (terms[3], g_nodes, g_mu, g_logvar)."""
+    nodes, x, mu, logvar = (_c(t.detach()) for t in (nodes, x, mu, logvar))
+    if nodes.dim() != 3 or nodes.shape[2] != DEC_NP:
+        raise RuntimeError(f"outer-sum loss: nodes {tuple(nodes.shape)} must be [B,R,{DEC_NP}]")
+    B, R, _ = nodes.shape
+    if x.shape != (B, n_nodes * n_nodes):
+        raise RuntimeError(f"outer-sum loss: x {tuple(x.shape)} must be [{B},{n_nodes * n_nodes}]")
+    dev = nodes.device
+    out = torch.empty(3, dtype=torch.float32, device=dev)
+    gnodes = torch.empty_like(nodes)
+    gmu, glv = torch.empty_like(mu), torch.empty_like(mu)
+    ws = torch.empty(_lib.load().mdnvae_outer_loss_workspace_bytes(B), dtype=torch.uint8, device=dev)
+    call("mdnvae_outer_loss_fwdbwd", RECON_MODES[mode], ptr(nodes, "nodes"), ptr(x, "x"), B, R, n_nodes, ptr(mu, "mu"),
+         ptr(logvar, "logvar"), mu.shape[1], ptr(gnodes), ptr(gmu), ptr(glv), ws.data_ptr(), ptr(out), stream())
+    return out, gnodes, gmu, glv
+
+
 def _mdn_outer_call(nodes, x, logits, log_sigma, mu, logvar, n_nodes):
     nodes, x, logits, log_sigma, mu, logvar = (_c(t) for t in (nodes, x, logits, log_sigma, mu, logvar))
     if nodes.dim() != 3 or nodes.shape[2] != DEC_NP:

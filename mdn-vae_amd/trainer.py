@@ -123,6 +123,15 @@ class Trainer:
                 mu.detach(), logvar.detach(), m.n_nodes)
             torch.autograd.backward([nodes, gate_logits, mu, logvar, m.log_sigma], [g_nodes, g_logits, g_mu, g_lv, g_ls])
             return terms[0]
+        if self.fused_loss and self.loss_mode in ops.RECON_MODES and getattr(self.model, "rank_one_sum_decoder", False):
+            # plain sum of outer products (the k-NN GCN decoder): loss, KL and gradients from the
+            # node vectors, the reconstruction itself is never written
+            m = self.model
+            nodes, mu, logvar = m(*inputs, eps=eps, nodes_only=True)
+            terms, g_nodes, g_mu, g_lv = ops.outer_sum_loss_and_grads(
+                nodes, target.reshape(target.shape[0], -1), mu, logvar, self.loss_mode, m.n_nodes)
+            torch.autograd.backward([nodes, mu, logvar], [g_nodes, g_mu, g_lv])
+            return terms[0]
         out = self.model(*inputs, eps=eps)
         if self.loss_mode == "mdn":
             comp, gate_logits, mu, logvar = out
