@@ -238,13 +238,17 @@ class Trainer:
         return loss.detach()
 
     def train_epoch(self, data, batch_size=256, extra=(), target=None, shuffle=True, generator=None,
-                    eps_generator=None):
+                    eps_generator=None, graph=False):
         """One pass over `data` [n, D] (device resident) in batches of `batch_size`, last batch
         ragged, order reshuffled when `shuffle` (function/VAE_CNN_NN.py:53-55, 209-222).  The
         per-step losses are accumulated on the device and read back once; returns the epoch
         metric of the scripts, sum of losses / number of subjects (with data-parallel ranks: of
         this rank's shard).  `extra(idx)` may be a callable giving per-batch extra inputs (e.g.
-        traits) or a tuple of fixed extra inputs (the adjacency list)."""
+        traits) or a tuple of fixed extra inputs (the adjacency list).  `graph`: full batches run
+        as replays of one captured HIP graph (see `capture`; needs `eps_generator`, single
+        process); the ragged last batch is stepped call by call."""
+        if graph and eps_generator is None:
+            raise ValueError("train_epoch(graph=True) needs eps_generator: a captured step cannot draw its own noise")
         n = data.shape[0]
         order = torch.randperm(n, device=data.device, generator=generator) if shuffle else \
             torch.arange(n, device=data.device)
@@ -258,7 +262,13 @@ class Trainer:
             eps = None
             if eps_generator is not None:
                 eps = torch.randn(x.shape[0], self._latent_dim(), device=x.device, generator=eps_generator)
-            latent += self.step((x,) + tuple(more), y, eps=eps)
+            if graph and x.shape[0] == batch_size:
+                if getattr(self, "_graph_batch", None) != batch_size:
+                    self.capture((x,) + tuple(more), y, eps)
+                    self._graph_batch = batch_size
+                latent += self.replay((x,) + tuple(more), y, eps)
+            else:
+                latent += self.step((x,) + tuple(more), y, eps=eps)
         total = float(latent.item())
         check = getattr(self.model, "check_inputs", None)
         if check is not None:

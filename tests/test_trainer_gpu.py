@@ -195,3 +195,25 @@ def test_captured_step_replays_the_eager_step():
     for a, b in zip(out["graph"][0], out["eager"][0]):
         assert abs(a - b) <= 1e-6 * abs(b)
     assert float((out["graph"][1] - out["eager"][1]).abs().max()) <= 1e-6
+
+
+def test_graph_epoch_equals_eager_epoch():
+    """train_epoch(graph=True): full batches replayed from one captured graph, ragged tail stepped
+    eagerly - same epoch metric and parameters as the all-eager epoch."""
+    fix = load_fixture("mm_gate")
+    params = fixture_params(fix)
+    x = torch.from_numpy(fix["x"]).to(DEV)
+    data = torch.cat([x * (1.0 + 0.05 * i) for i in range(5)])[:19]          # 19 subjects: 4 batches of 4 + 3
+    adjacency = [list(map(int, r)) for r in fix["adjacency"]]
+    out = {}
+    for graph in (False, True):
+        model = M.GCNVAE(R=5, n_nodes=68, k=32, n_layers=3, latent_dim=68)
+        model.load_state_dict(params, strict=False)
+        trainer = M.Trainer(model.to(DEV), "poisson_log")
+        metric = trainer.train_epoch(data, batch_size=4, extra=(adjacency,), shuffle=True,
+                                     generator=torch.Generator(device=DEV).manual_seed(1),
+                                     eps_generator=torch.Generator(device=DEV).manual_seed(2), graph=graph)
+        out[graph] = (metric, trainer.buf.flat_p.clone(), trainer.steps)
+    assert out[True][2] == out[False][2] == 5
+    assert abs(out[True][0] - out[False][0]) <= 1e-6 * abs(out[False][0])
+    assert float((out[True][1] - out[False][1]).abs().max()) <= 1e-6
