@@ -988,8 +988,14 @@ static int launch_conv(ConvGeom g, const float* x, const float* stats, const flo
     if (g.slab_stride <= 7 * 64) {
         if (g.ntaps == 9 && plain) launch_conv_t<4, 7, 9, true>(g, lds, x, stats, wp, bias, out, st);
         else if (g.ntaps == 9) launch_conv_t<4, 7, 9, false>(g, lds, x, stats, wp, bias, out, st);
+        // the parity classes of a stride-2 data gradient have 1, 2, 2 and 4 taps
+        else if (g.ntaps == 4 && plain) launch_conv_t<4, 7, 4, true>(g, lds, x, stats, wp, bias, out, st);
+        else if (g.ntaps == 2 && plain) launch_conv_t<4, 7, 2, true>(g, lds, x, stats, wp, bias, out, st);
+        else if (g.ntaps == 1 && plain) launch_conv_t<4, 7, 1, true>(g, lds, x, stats, wp, bias, out, st);
         else if (plain) launch_conv_t<4, 7, 0, true>(g, lds, x, stats, wp, bias, out, st);
         else launch_conv_t<4, 7, 0, false>(g, lds, x, stats, wp, bias, out, st);
+    } else if (plain && g.ntaps == 9) {
+        launch_conv_t<4, 24, 9, true>(g, lds, x, stats, wp, bias, out, st);
     } else if (plain) {
         launch_conv_t<4, 24, 0, true>(g, lds, x, stats, wp, bias, out, st);
     } else {
