@@ -31,8 +31,9 @@ from mdnvae_amd import ops  # noqa: E402
 PEAK_FP32_MATRIX_TFLOPS = 157.3   # v_mfma_f32_32x32x2_f32, dense
 PEAK_HBM_GBPS = 8000.0
 # fabric-side bytes / algorithmic bytes from the rocprofv3 TCC counters (FETCH_SIZE x2 + WRITE_SIZE,
-# separate passes; profiles/r01_c_loss_pmc_traffic.md); kernels without a collected pass report null
-TRAFFIC_RATIO = {"loss_stream_kernel": 1.00, "mdn_fwd_kernel": 1.10, "mdn_bwd_stream_kernel": 1.27}
+# separate passes; profiles/r01_c_loss_pmc_traffic.md, profiles/r01_h_pmc_traffic.md); kernels without a collected pass report null
+TRAFFIC_RATIO = {"loss_stream_kernel": 1.00, "mdn_fwd_kernel": 1.10, "mdn_bwd_stream_kernel": 1.27,
+                 "mdn_outer_kernel": 1.03, "tri_pack_kernel": 1.01, "adam_kernel": 1.00}
 
 MODELS = {
     # name: (constructor kwargs, loss mode, data kind)
