@@ -51,6 +51,9 @@ def bench_conv(B):
              (192, 192, 3, 1, 1, True, 22), (192, 192, 3, 1, 1, True, 17)]
     if os.environ.get("KB_RES_ONLY"):
         geoms = geoms[3:4]
+    if os.environ.get("KB_GEOMS"):              # "cin,cout,ks,stride,pad,reflect,h;..."
+        geoms = [tuple(int(v) for v in g.split(",")) for g in os.environ["KB_GEOMS"].split(";")]
+        geoms = [(a, b, c, d, e, bool(f), h) for a, b, c, d, e, f, h in geoms]
     plain = not os.environ.get("KB_NORM")       # the encoder feeds materialised activations (no norm on load)
     out = []
     for cin, cout, ks, stride, pad, reflect, h in geoms:
