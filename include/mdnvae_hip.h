@@ -108,12 +108,14 @@ int mdnvae_decoder_unpack_gcn_grad(const float* dwt, const int* adj, int N, int 
 /* The same for all count = R*NL layers of a decoder in one launch each way.  HOST arrays of length
  * count, layer (r,l) at r*NL+l: kind (0 = Linear, 1 = GCN layer), device pointers w / bias (or NULL) /
  * aux (Linear: mask or NULL; GCN: adjacency), n_out and k (the weight is [n_out,k]).  wt / wn / dwt
- * are the whole panels; dw / db (or NULL) the per-layer gradient buffers.  count <= 32. */
+ * are the whole panels; dw / db (or NULL) the per-layer gradient buffers, overwritten or, with
+ * accumulate != 0, added to (autograd's `.grad +=`).  count <= 32. */
 int mdnvae_decoder_pack_layers(int count, const int* kind, const void* const* w, const void* const* bias,
                                const void* const* aux, const int* n_out, const int* k, float* wt, float* wn,
                                void* stream);
 int mdnvae_decoder_unpack_layer_grads(int count, const int* kind, const float* dwt, const void* const* aux,
-                                      const int* n_out, const int* k, void* const* dw, void* const* db, void* stream);
+                                      const int* n_out, const int* k, void* const* dw, void* const* db, int accumulate,
+                                      void* stream);
 
 /* acts: activation code of layer l in bits [2l, 2l+1]; epi_act: activation applied to the sum of
  * outer products; icpt_w/icpt_b [N*N] (both or neither): out = out*icpt_w + icpt_b (the GraphCNN
@@ -171,18 +173,19 @@ int mdnvae_bias_act(float* y, const float* bias, long rows, int cols, int act, v
 int mdnvae_add_act(const float* a, const float* b, float* y, long n, int act, void* stream);
 /* grad_pre = grad_y * act'(.) expressed through the activation output y. */
 int mdnvae_act_bwd(const float* y, const float* grad_y, float* grad_pre, long n, int act, void* stream);
-/* out[e] = sum_b a[b,e], fixed summation order (bias gradients). */
+/* out[e] = sum_b a[b,e], fixed summation order (bias gradients); accumulate != 0: out[e] += the sum. */
 size_t mdnvae_colsum_workspace_floats(int B, int D);
-int mdnvae_colsum(const float* a, int B, int D, float* workspace, float* out, void* stream);
+int mdnvae_colsum(const float* a, int B, int D, float* workspace, float* out, int accumulate, void* stream);
 
 /* Weight gradient of F.linear for a small layer over a long batch: grad_w [N,M] = grad_pre^T . x with
  * grad_pre [B,N], x [B,M] (autograd of the tower / head layers, function/MM_Gate.py:157-165,
  * function/VAE_CNN_NN.py:160-161), split over the batch on the fp32 matrix cores and reduced in a
  * fixed order.  N and M multiples of 4; all operands 16-byte aligned.  Meant for N*M up to a few
- * hundred thousand, where a library GEMM has too few output tiles to fill the chip. */
+ * hundred thousand, where a library GEMM has too few output tiles to fill the chip.  accumulate != 0:
+ * grad_w += the product. */
 size_t mdnvae_linear_wgrad_workspace_floats(int B, int N, int M);
 int mdnvae_linear_wgrad(const float* grad_pre, const float* x, int B, int N, int M, float* workspace, float* grad_w,
-                        void* stream);
+                        int accumulate, void* stream);
 
 /* ---- first dense layer on symmetric connectomes --------------------------------------------
  * `self.fc11(x.view(-1, N*N))` (function/MM_Gate.py:157-165; function_FC_SC/SC-FC.py:95-104) sums
@@ -198,8 +201,10 @@ int mdnvae_tri_pack(const float* x, long B, int N, int ld, float* out, int* asym
 /* out [H,ld]: out[h,t(i,j)] = w[h,i,j] + w[h,j,i] for i < j, w[h,i,i] on the diagonal, zeros past T. */
 int mdnvae_tri_fold(const float* w, long H, int N, int ld, float* out, void* stream);
 /* grad_w [H,N*N]: grad_w[h,i*N+j] = g[t(min(i,j),max(i,j))*stride_t + h*stride_h], g being the
- * weight gradient of the folded layer stored as [H,T] (stride_t = 1) or [T,H] (stride_h = 1). */
-int mdnvae_tri_unfold(const float* g, long H, int N, long stride_t, long stride_h, float* grad_w, void* stream);
+ * weight gradient of the folded layer stored as [H,T] (stride_t = 1) or [T,H] (stride_h = 1);
+ * accumulate != 0: grad_w += that. */
+int mdnvae_tri_unfold(const float* g, long H, int N, long stride_t, long stride_h, float* grad_w, int accumulate,
+                      void* stream);
 
 /* ---- conv / ResNet encoder ---------------------------------------------------------------
  * The ATen conv2d / instance_norm / relu / max_pool2d calls (and their autograd) of the encoder

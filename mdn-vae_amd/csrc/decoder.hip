@@ -162,7 +162,8 @@ struct UnpackTable {
     const void* aux[MAX_LAYERS];
     int n_out[MAX_LAYERS], k[MAX_LAYERS], kind[MAX_LAYERS];
 };
-__global__ __launch_bounds__(256) void unpack_layers_kernel(UnpackTable t, const float* __restrict__ dwt_all) {
+__global__ __launch_bounds__(256) void unpack_layers_kernel(UnpackTable t, const float* __restrict__ dwt_all,
+                                                            int accumulate) {
     const int ly = blockIdx.y;
     const int idx = blockIdx.x * 256 + threadIdx.x;
     const float* __restrict__ dwt = dwt_all + (long)ly * KP * NP;
@@ -171,16 +172,20 @@ __global__ __launch_bounds__(256) void unpack_layers_kernel(UnpackTable t, const
     float* __restrict__ db = t.db[ly];
     if (idx < n_out * K) {
         const int n = idx / K, k = idx - n * K;
+        float v;
         if (t.kind[ly] == 0) {
-            float v = dwt[k * NP + n];
+            v = dwt[k * NP + n];
             const float* mask = static_cast<const float*>(t.aux[ly]);
             if (mask) v *= mask[idx];
-            dw[idx] = v;
         } else {
-            dw[idx] = dwt[static_cast<const int*>(t.aux[ly])[idx] * NP + n];
+            v = dwt[static_cast<const int*>(t.aux[ly])[idx] * NP + n];
         }
+        dw[idx] = accumulate ? dw[idx] + v : v;
     }
-    if (db && idx < n_out) db[idx] = dwt[(KP - 1) * NP + idx];
+    if (db && idx < n_out) {
+        const float v = dwt[(KP - 1) * NP + idx];
+        db[idx] = accumulate ? db[idx] + v : v;
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -756,7 +761,8 @@ int mdnvae_decoder_pack_layers(int count, const int* kind, const void* const* w,
 }
 
 int mdnvae_decoder_unpack_layer_grads(int count, const int* kind, const float* dwt, const void* const* aux,
-                                      const int* n_out, const int* k, void* const* dw, void* const* db, void* stream) {
+                                      const int* n_out, const int* k, void* const* dw, void* const* db, int accumulate,
+                                      void* stream) {
     if (int rc = check_layer_tables("mdnvae_decoder_unpack_layer_grads", count, kind, n_out, k)) return rc;
     MV_REQUIRE(dwt && aux && dw && db, E_ARG, "mdnvae_decoder_unpack_layer_grads: null pointer");
     UnpackTable t{};
@@ -772,7 +778,8 @@ int mdnvae_decoder_unpack_layer_grads(int count, const int* kind, const float* d
         t.kind[i] = kind[i];
         most = n_out[i] * k[i] > most ? n_out[i] * k[i] : most;
     }
-    hipLaunchKernelGGL(unpack_layers_kernel, dim3((most + 255) / 256, count), dim3(256), 0, (hipStream_t)stream, t, dwt);
+    hipLaunchKernelGGL(unpack_layers_kernel, dim3((most + 255) / 256, count), dim3(256), 0, (hipStream_t)stream, t, dwt,
+                       accumulate);
     MV_LAUNCH_CHECK("unpack_layers_kernel");
     return 0;
 }

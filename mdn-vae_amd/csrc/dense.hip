@@ -80,11 +80,11 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
     if (g == 0 && c < D) part[(long)blockIdx.y * D + c] = s;
 }
 __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, int nparts, int D,
-                                                           float* __restrict__ out) {
+                                                           int accumulate, float* __restrict__ out) {
     __shared__ float sm[CS_GROUPS][CS_COLS];
     const int c = blockIdx.x * CS_COLS + (threadIdx.x & (CS_COLS - 1)), g = threadIdx.x >> 6;
     const float s = colsum_slab(part, 0, nparts, D, c, g, sm);
-    if (g == 0 && c < D) out[c] = s;
+    if (g == 0 && c < D) out[c] = accumulate ? out[c] + s : s;
 }
 
 }  // namespace mdnvae
@@ -130,7 +130,7 @@ int mdnvae_add_act(const float* a, const float* b, float* y, long n, int act, vo
 
 size_t mdnvae_colsum_workspace_floats(int B, int D) { return (size_t)((B + 63) / 64) * D; }
 
-int mdnvae_colsum(const float* a, int B, int D, float* workspace, float* out, void* stream) {
+int mdnvae_colsum(const float* a, int B, int D, float* workspace, float* out, int accumulate, void* stream) {
     MV_REQUIRE(B >= 1 && D >= 1, E_ARG, "mdnvae_colsum: empty input");
     MV_REQUIRE(a && workspace && out, E_ARG, "mdnvae_colsum: null pointer");
     // slabs of 64 rows for small batches, longer ones once there are enough slabs to fill the chip
@@ -139,7 +139,8 @@ int mdnvae_colsum(const float* a, int B, int D, float* workspace, float* out, vo
     hipLaunchKernelGGL(colsum_partial_kernel, dim3(cols, nparts), dim3(256), 0, (hipStream_t)stream, a, B, D, rows,
                        workspace);
     MV_LAUNCH_CHECK("colsum_partial_kernel");
-    hipLaunchKernelGGL(colsum_final_kernel, dim3(cols), dim3(256), 0, (hipStream_t)stream, workspace, nparts, D, out);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(cols), dim3(256), 0, (hipStream_t)stream, workspace, nparts, D, accumulate,
+                       out);
     MV_LAUNCH_CHECK("colsum_final_kernel");
     return 0;
 }

@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256) void tri_pack_kernel(const float* __restrict__
 // writes (contiguous along p) move whole cache lines.
 constexpr int UF_T = 64;
 __global__ __launch_bounds__(256) void tri_unfold_kernel(const float* __restrict__ g, int H, int N, long stride_t,
-                                                         long stride_h, float* __restrict__ gw) {
+                                                         long stride_h, int accumulate, float* __restrict__ gw) {
     __shared__ float tile[UF_T][UF_T + 1];          // [p][h]
     const int P = N * N;
     const int p0 = blockIdx.x * UF_T, h0 = blockIdx.y * UF_T;
@@ -83,7 +83,10 @@ __global__ __launch_bounds__(256) void tri_unfold_kernel(const float* __restrict
     __syncthreads();
     for (int r = b4; r < UF_T; r += 4) {
         const int h = h0 + r, p = p0 + a;
-        if (h < H && p < P) gw[(long)h * P + p] = tile[a][r];
+        if (h < H && p < P) {
+            const long o = (long)h * P + p;
+            gw[o] = accumulate ? gw[o] + tile[a][r] : tile[a][r];
+        }
     }
 }
 
@@ -131,7 +134,8 @@ int mdnvae_tri_fold(const float* w, long H, int N, int ld, float* out, void* str
     return tri_launch(true, w, H, N, ld, out, nullptr, stream, "mdnvae_tri_fold");
 }
 
-int mdnvae_tri_unfold(const float* g, long H, int N, long stride_t, long stride_h, float* grad_w, void* stream) {
+int mdnvae_tri_unfold(const float* g, long H, int N, long stride_t, long stride_h, float* grad_w, int accumulate,
+                      void* stream) {
     MV_REQUIRE(H >= 0 && N >= 1, E_ARG, "mdnvae_tri_unfold: bad shape");
     if (H == 0) return 0;
     MV_REQUIRE(g && grad_w, E_ARG, "mdnvae_tri_unfold: null pointer");
@@ -142,7 +146,7 @@ int mdnvae_tri_unfold(const float* g, long H, int N, long stride_t, long stride_
     const dim3 grid((unsigned)((P + UF_T - 1) / UF_T), (unsigned)((H + UF_T - 1) / UF_T));
     MV_REQUIRE(grid.y <= 65535, E_SHAPE, "mdnvae_tri_unfold: too many output units for one launch");
     hipLaunchKernelGGL(tri_unfold_kernel, grid, dim3(256), 0, (hipStream_t)stream, g, (int)H, N, stride_t, stride_h,
-                       grad_w);
+                       accumulate, grad_w);
     MV_LAUNCH_CHECK("tri_unfold_kernel");
     return 0;
 }

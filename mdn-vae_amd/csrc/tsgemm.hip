@@ -101,7 +101,7 @@ __global__ __launch_bounds__(TS_NT) void tsgemm_partial_kernel(const float* __re
 // out[e] = sum_s part[s][e]: a workgroup covers 64 quads of e with four groups of lanes that each
 // add every fourth slab (four loads in flight), the four group sums meet in LDS in a fixed order
 __global__ __launch_bounds__(256) void tsgemm_reduce_kernel(const float* __restrict__ part, int slabs, long count,
-                                                            float* __restrict__ out) {
+                                                            int accumulate, float* __restrict__ out) {
     __shared__ float4 sm[4][64];
     const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
     const long e4 = (long)blockIdx.x * 64 + col;
@@ -126,6 +126,10 @@ __global__ __launch_bounds__(256) void tsgemm_reduce_kernel(const float* __restr
         float4 r = sm[0][col];
 #pragma unroll
         for (int u = 1; u < 4; ++u) { r.x += sm[u][col].x; r.y += sm[u][col].y; r.z += sm[u][col].z; r.w += sm[u][col].w; }
+        if (accumulate) {
+            const float4 o = *reinterpret_cast<const float4*>(out + e4 * 4);
+            r.x += o.x; r.y += o.y; r.z += o.z; r.w += o.w;
+        }
         *reinterpret_cast<float4*>(out + e4 * 4) = r;
     }
 }
@@ -151,7 +155,7 @@ size_t mdnvae_linear_wgrad_workspace_floats(int B, int N, int M) {
 }
 
 int mdnvae_linear_wgrad(const float* grad_pre, const float* x, int B, int N, int M, float* workspace, float* grad_w,
-                        void* stream) {
+                        int accumulate, void* stream) {
     MV_REQUIRE(B >= 1 && N >= 1 && M >= 1, E_ARG, "mdnvae_linear_wgrad: empty operand");
     MV_REQUIRE((N & 3) == 0 && (M & 3) == 0, E_SHAPE,
                "mdnvae_linear_wgrad: N = %d and M = %d must be multiples of 4 (16-byte rows)", N, M);
@@ -168,7 +172,7 @@ int mdnvae_linear_wgrad(const float* grad_pre, const float* x, int B, int N, int
     MV_LAUNCH_CHECK("tsgemm_partial_kernel");
     const long count = (long)N * M;
     hipLaunchKernelGGL(tsgemm_reduce_kernel, dim3((unsigned)((count / 4 + 63) / 64)), dim3(256), 0, (hipStream_t)stream,
-                       workspace, used, count, grad_w);
+                       workspace, used, count, accumulate, grad_w);
     MV_LAUNCH_CHECK("tsgemm_reduce_kernel");
     return 0;
 }

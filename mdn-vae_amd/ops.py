@@ -106,12 +106,66 @@ def vae_loss_and_grads(recon, x, mu, logvar, mode):
 ACTS = {None: 0, "none": 0, "sigmoid": 1, "tanh": 2, "relu": 3}
 
 
-def _colsum(a):
+# ---------------------------------------------------------------------------------------
+# gradients added straight into .grad
+# ---------------------------------------------------------------------------------------
+_SINK = None
+
+
+class accumulate_into_grads:
+    """While active, an op whose parameter gradient comes out of one of this library's kernels adds
+    it straight into the parameter's existing `.grad` (what autograd's AccumulateGrad would do with
+    one more elementwise kernel per parameter - some fifty launches a step for the GCN-decoder
+    models) and hands autograd no gradient for that parameter.  `ready(param)`, if given, is called
+    after each such addition (post-accumulate hooks do not fire on this path).  Parameters whose
+    `.grad` is missing, of another dtype / shape or not contiguous take the ordinary path."""
+
+    def __init__(self, ready=None):
+        self.ready = ready
+
+    def __enter__(self):
+        global _SINK
+        self._outer, _SINK = _SINK, self
+        return self
+
+    def __exit__(self, *exc):
+        global _SINK
+        _SINK = self._outer
+        return False
+
+
+def _grad_target(param):
+    """The `.grad` tensor the active sink may add into, or None."""
+    if _SINK is None or param is None:
+        return None
+    g = getattr(param, "grad", None)
+    if g is None or not g.is_cuda or g.dtype != torch.float32 or g.shape != param.shape or not g.is_contiguous():
+        return None
+    return g
+
+
+def _grad_added(param):
+    if _SINK is not None and _SINK.ready is not None:
+        _SINK.ready(param)
+
+
+def _colsum(a, into=None):
+    """Column sums of a [B,D]; `into` [D]: add them to it instead of returning a new tensor."""
     B, D = a.shape
     ws = torch.empty(_lib.workspace_bytes_f("mdnvae_colsum_workspace_floats", B, D), dtype=torch.float32, device=a.device)
-    out = torch.empty(D, dtype=torch.float32, device=a.device)
-    call("mdnvae_colsum", ptr(a), B, D, ptr(ws), ptr(out), stream())
+    out = into if into is not None else torch.empty(D, dtype=torch.float32, device=a.device)
+    call("mdnvae_colsum", ptr(a), B, D, ptr(ws), ptr(out), int(into is not None), stream())
     return out
+
+
+def _bias_grad(gpre, bias_param):
+    """Bias gradient of a dense layer: None when it went straight into bias_param.grad."""
+    target = _grad_target(bias_param)
+    if target is not None:
+        _colsum(gpre, into=target)
+        _grad_added(bias_param)
+        return None
+    return _colsum(gpre)
 
 
 def _library_gemm(a, b):
@@ -126,14 +180,15 @@ def _small_wgrad_ok(B, n_out, n_in):
     return B >= 1024 and n_out % 4 == 0 and n_in % 4 == 0 and n_out * n_in <= (1 << 18)
 
 
-def _linear_wgrad(gpre, x):
-    """grad_w [N,M] = gpre^T . x for gpre [B,N], x [B,M] (contiguous)."""
+def _linear_wgrad(gpre, x, into=None):
+    """grad_w [N,M] = gpre^T . x for gpre [B,N], x [B,M] (contiguous); `into`: add it there instead."""
     B, N = gpre.shape
     M = x.shape[1]
     ws = torch.empty(_lib.workspace_bytes_f("mdnvae_linear_wgrad_workspace_floats", B, N, M), dtype=torch.float32,
                      device=x.device)
-    gw = torch.empty(N, M, dtype=torch.float32, device=x.device)
-    call("mdnvae_linear_wgrad", ptr(gpre, "grad_pre"), ptr(x, "x"), B, N, M, ptr(ws), ptr(gw), stream())
+    gw = into if into is not None else torch.empty(N, M, dtype=torch.float32, device=x.device)
+    call("mdnvae_linear_wgrad", ptr(gpre, "grad_pre"), ptr(x, "x"), B, N, M, ptr(ws), ptr(gw), int(into is not None),
+         stream())
     return gw
 
 
@@ -150,6 +205,7 @@ class _LinearAct(torch.autograd.Function):
         ctx.save_for_backward(x, weight, y)
         ctx.act = act
         ctx.has_bias = bias is not None
+        ctx.params = (weight, bias)              # the objects whose .grad a sink may add into
         return y
 
     @staticmethod
@@ -165,11 +221,16 @@ class _LinearAct(torch.autograd.Function):
         gw = None
         if ctx.needs_input_grad[1]:
             if _small_wgrad_ok(x.shape[0], weight.shape[0], weight.shape[1]):
-                gw = _linear_wgrad(_c(gpre), x)
+                target = _grad_target(ctx.params[0])
+                if target is not None:
+                    _linear_wgrad(_c(gpre), x, into=target)
+                    _grad_added(ctx.params[0])
+                else:
+                    gw = _linear_wgrad(_c(gpre), x)
             else:
                 # [K,B].[B,H] then a transposed view: the library runs this layout ~20% faster than gpre^T . x
                 gw = _library_gemm(x.t(), gpre).t()
-        gb = _colsum(gpre) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        gb = _bias_grad(gpre, ctx.params[1]) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         return gx, gw, gb, None
 
 
@@ -209,6 +270,7 @@ class _SymLinearAct(torch.autograd.Function):
         call("mdnvae_bias_act", ptr(y), ptr(bias, "bias"), y.shape[0], y.shape[1], act, stream())
         ctx.save_for_backward(xt, y)
         ctx.act, ctx.n_nodes, ctx.has_bias = act, n_nodes, bias is not None
+        ctx.params = (weight, bias)
         return y
 
     @staticmethod
@@ -224,9 +286,14 @@ class _SymLinearAct(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             H, n = gpre.shape[1], ctx.n_nodes
             gt = _library_gemm(xt.t(), gpre)                       # [T, H]
-            gw = torch.empty(H, n * n, dtype=torch.float32, device=gy.device)
-            call("mdnvae_tri_unfold", ptr(gt), H, n, H, 1, ptr(gw), stream())
-        gb = _colsum(gpre) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+            target = _grad_target(ctx.params[0])
+            if target is not None:
+                call("mdnvae_tri_unfold", ptr(gt), H, n, H, 1, ptr(target), 1, stream())
+                _grad_added(ctx.params[0])
+            else:
+                gw = torch.empty(H, n * n, dtype=torch.float32, device=gy.device)
+                call("mdnvae_tri_unfold", ptr(gt), H, n, H, 1, ptr(gw), 0, stream())
+        gb = _bias_grad(gpre, ctx.params[1]) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         return None, gw, gb, None, None
 
 
@@ -451,6 +518,7 @@ class _ChainDecoder(torch.autograd.Function):
         ctx.spec = spec
         ctx.save_for_backward(z, wt, wn, icpt_w, icpt_b, drop, nodes)
         ctx.param_shapes = [tuple(p.shape) if p is not None else None for p in params]
+        ctx.param_objs = params                  # the objects whose .grad a sink may add into
         if xlat is None:
             xlat = torch.zeros(B, 0, dtype=torch.float32, device=dev)
             ctx.mark_non_differentiable(xlat)
@@ -486,21 +554,32 @@ class _ChainDecoder(torch.autograd.Function):
         n = spec.R * spec.NL
         kind, n_out, k = (ctypes.c_int * n)(), (ctypes.c_int * n)(), (ctypes.c_int * n)()
         aux, dw, db = (ctypes.c_void_p * n)(), (ctypes.c_void_p * n)(), (ctypes.c_void_p * n)()
+        # with a gradient sink active and every layer parameter holding a .grad, the unpack adds into
+        # those directly and autograd gets no gradients for them
+        targets = [_grad_target(p) if p is not None else None for p in ctx.param_objs]
+        into = all(t is not None or p is None for t, p in zip(targets, ctx.param_objs))
         grads = []
         for r in range(spec.R):
             for l, ly in enumerate(spec.layers):
                 idx = r * spec.NL + l
                 shape_w = ctx.param_shapes[2 * idx]
-                gw = torch.empty(shape_w, dtype=torch.float32, device=dev)
                 has_b = ctx.param_shapes[2 * idx + 1] is not None
-                gb = torch.empty(shape_w[0], dtype=torch.float32, device=dev) if has_b else None
+                if into:
+                    gw, gb = targets[2 * idx], targets[2 * idx + 1]
+                else:
+                    gw = torch.empty(shape_w, dtype=torch.float32, device=dev)
+                    gb = torch.empty(shape_w[0], dtype=torch.float32, device=dev) if has_b else None
                 kind[idx] = 0 if ly["kind"] == "linear" else 1
                 n_out[idx], k[idx] = shape_w
                 aux[idx] = ptr(ly.get("mask")) if kind[idx] == 0 else ptr(ly["adj"], "adjacency", torch.int32)
                 dw[idx], db[idx] = ptr(gw), ptr(gb)
-                grads += [gw, gb]
+                grads += [None, None] if into else [gw, gb]
         call("mdnvae_decoder_unpack_layer_grads", n, _addr(kind), ptr(dwt), _addr(aux), _addr(n_out), _addr(k), _addr(dw),
-             _addr(db), stream())
+             _addr(db), int(into), stream())
+        if into:
+            for p in ctx.param_objs:
+                if p is not None:
+                    _grad_added(p)
         g_iw = g_ib = None
         if icpt_w is not None:
             D = spec.N * spec.N

@@ -16,7 +16,10 @@ from ._lib import call, ptr, stream
 
 
 class FlatBuffers:
-    """Re-homes a module's parameters (and their .grad) into two flat fp32 buffers."""
+    """Re-homes a module's parameters (and their .grad) into two flat fp32 buffers.  Every
+    parameter starts at a multiple of 4 floats, so each view is 16-byte aligned for the kernels
+    that write gradients into it; the few padding elements stay zero in both buffers (a zero
+    gradient leaves a zero parameter at zero under Adam)."""
 
     def __init__(self, module):
         self.params = [p for p in module.parameters() if p.requires_grad]
@@ -26,9 +29,9 @@ class FlatBuffers:
         sizes = [p.numel() for p in self.params]
         self.offsets = [0]
         for s in sizes:
-            self.offsets.append(self.offsets[-1] + s)
+            self.offsets.append(self.offsets[-1] + (s + 3) // 4 * 4)
         total = self.offsets[-1]
-        self.flat_p = torch.empty(total, dtype=torch.float32, device=dev)
+        self.flat_p = torch.zeros(total, dtype=torch.float32, device=dev)
         self.flat_g = torch.zeros(total, dtype=torch.float32, device=dev)
         for p, o in zip(self.params, self.offsets):
             n = p.numel()
@@ -71,7 +74,7 @@ class Trainer:
     ranges of the flat gradient buffer are reduced in buckets after backward."""
 
     def __init__(self, model, loss_mode, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, group=None, fused_loss=True,
-                 overlap_floats=1 << 20):
+                 overlap_floats=1 << 20, direct_grads=True):
         self.model, self.loss_mode, self.group = model, loss_mode, group
         self.lr, self.betas, self.eps = lr, betas, eps
         self.buf = FlatBuffers(model)
@@ -79,6 +82,8 @@ class Trainer:
         self.exp_avg_sq = torch.zeros_like(self.buf.flat_p)
         self.steps = 0
         self.fused_loss = fused_loss
+        self.direct_grads = direct_grads
+        self._hook_of = {}          # id(param) -> its early all-reduce hook
         self._pending = []          # async all-reduces launched from hooks during backward
         self._rest = [(0, self.buf.numel)]   # flat ranges still to be reduced after backward
         if _distributed(group) and overlap_floats:
@@ -89,7 +94,9 @@ class Trainer:
         for p, o in zip(self.buf.params, self.buf.offsets):
             if p.numel() >= min_floats:
                 early.append((o, o + p.numel()))
-                p.register_post_accumulate_grad_hook(self._make_hook(o, p.numel()))
+                hook = self._make_hook(o, p.numel())
+                p.register_post_accumulate_grad_hook(hook)
+                self._hook_of[id(p)] = hook      # the direct-gradient path calls it itself
         rest, pos = [], 0
         for lo, hi in sorted(early):
             if lo > pos:
@@ -111,7 +118,21 @@ class Trainer:
     def forward_backward(self, inputs, target, eps=None):
         """inputs: positional arguments of model.forward; returns the detached loss (0-dim).
         loss_mode "mdn" trains a model whose forward returns (component means, gate logits, mu,
-        logvar) and whose .loss() is the trait-gated mixture likelihood + KL."""
+        logvar) and whose .loss() is the trait-gated mixture likelihood + KL.
+        With `direct_grads` (default) the kernels that produce parameter gradients add them
+        straight into the flat gradient buffer (ops.accumulate_into_grads) instead of going through
+        one AccumulateGrad kernel per parameter."""
+        if not self.direct_grads:
+            return self._forward_backward(inputs, target, eps)
+        with ops.accumulate_into_grads(ready=self._grad_ready if self._hook_of else None):
+            return self._forward_backward(inputs, target, eps)
+
+    def _grad_ready(self, param):
+        hook = self._hook_of.get(id(param))
+        if hook is not None:
+            hook(param)
+
+    def _forward_backward(self, inputs, target, eps=None):
         self.buf.zero_grad()
         if self.loss_mode == "mdn" and self.fused_loss:
             # rank-one component means: likelihood, KL and all their gradients from one pass over

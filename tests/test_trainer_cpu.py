@@ -17,7 +17,9 @@ def test_flat_buffers_alias_parameters_and_grads():
     net = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.Linear(7, 3))
     before = [p.detach().clone() for p in net.parameters()]
     buf = M.FlatBuffers(net)
-    assert buf.numel == sum(p.numel() for p in net.parameters())
+    # every parameter starts at a multiple of 4 floats (16-byte aligned views), padding stays zero
+    assert buf.numel == sum((p.numel() + 3) // 4 * 4 for p in net.parameters())
+    assert all(o % 4 == 0 for o in buf.offsets)
     for p, b in zip(net.parameters(), before):
         assert torch.equal(p, b)
     net(torch.randn(4, 5)).sum().backward()

@@ -217,3 +217,40 @@ def test_graph_epoch_equals_eager_epoch():
     assert out[True][2] == out[False][2] == 5
     assert abs(out[True][0] - out[False][0]) <= 1e-6 * abs(out[False][0])
     assert float((out[True][1] - out[False][1]).abs().max()) <= 1e-6
+
+
+def test_direct_gradients_equal_autograd_accumulation():
+    """Trainer(direct_grads=True): the kernels add parameter gradients straight into the flat
+    buffer; the result is the buffer autograd's own accumulation leaves, for the FNN/GCN models
+    (fused and plain loss) and a conv-encoder model, and accumulates over two backward passes."""
+    fix = load_fixture("mm_gate")
+    params = fixture_params(fix)
+    x = torch.from_numpy(fix["x"]).to(DEV)
+    x = 0.5 * (x.reshape(-1, 68, 68) + x.reshape(-1, 68, 68).transpose(1, 2)).reshape(-1, 68 * 68).contiguous()
+    eps = torch.from_numpy(fix["eps"]).to(DEV)
+    adjacency = [list(map(int, r)) for r in fix["adjacency"]]
+    for fused in (True, False):
+        got = {}
+        for direct in (False, True):
+            model = M.GCNVAE(R=5, n_nodes=68, k=32, n_layers=3, latent_dim=68, symmetric_input=True)
+            model.load_state_dict(params, strict=False)
+            trainer = M.Trainer(model.to(DEV), "poisson_log", fused_loss=fused, direct_grads=direct)
+            trainer.forward_backward((x, adjacency), x, eps=eps)
+            got[direct] = trainer.buf.flat_g.clone()
+        scale = float(got[False].abs().max())
+        assert float((got[True] - got[False]).abs().max()) <= 1e-6 * scale, fused
+    # += semantics: a second backward without zeroing doubles the buffer
+    model = M.GCNVAE(R=5, n_nodes=68, k=32, n_layers=3, latent_dim=68, symmetric_input=True)
+    model.load_state_dict(params, strict=False)
+    model = model.to(DEV)
+    buf = M.trainer.FlatBuffers(model)
+    buf.zero_grad()
+    for _ in range(2):
+        with ops.accumulate_into_grads():
+            recon, mu, lv = model(x, adjacency, eps=eps)
+            ops.vae_loss(recon, x, mu, lv, "poisson_log").backward()
+    twice = buf.flat_g.clone()
+    buf.zero_grad()
+    recon, mu, lv = model(x, adjacency, eps=eps)
+    ops.vae_loss(recon, x, mu, lv, "poisson_log").backward()
+    assert float((twice - 2.0 * buf.flat_g).abs().max()) <= 2e-6 * float(buf.flat_g.abs().max())

@@ -52,7 +52,7 @@ def test_pack_fold_unfold_against_numpy(n, rows):
     for src, st, sh in ((torch.from_numpy(g).to(DEV), 1, T), (torch.from_numpy(g.T.copy()).to(DEV), rows, 1)):
         out = torch.full((rows, n * n), float("nan"), device=DEV)
         if rows:
-            _lib.call("mdnvae_tri_unfold", _lib.ptr(src), rows, n, st, sh, _lib.ptr(out), _lib.stream())
+            _lib.call("mdnvae_tri_unfold", _lib.ptr(src), rows, n, st, sh, _lib.ptr(out), 0, _lib.stream())
         assert np.array_equal(out.cpu().numpy(), full.reshape(rows, n * n))
 
 
@@ -81,7 +81,7 @@ def test_bad_arguments_are_refused():
     with pytest.raises(Exception):
         _lib.call("mdnvae_tri_pack", _lib.ptr(x), 1, 4, 9, _lib.ptr(x), _lib.ptr(x), _lib.stream())   # stride < 10
     with pytest.raises(Exception):
-        _lib.call("mdnvae_tri_unfold", _lib.ptr(x), 1, 2, 2, 2, _lib.ptr(x), _lib.stream())
+        _lib.call("mdnvae_tri_unfold", _lib.ptr(x), 1, 2, 2, 2, _lib.ptr(x), 0, _lib.stream())
 
 
 def test_symmetric_first_layer_matches_plain_layer_and_oracle():
