@@ -126,10 +126,13 @@ int mdnvae_decoder_unpack_layer_grads(int count, const int* kind, const float* d
  * trait-gated mixture head uses as component means (no epilogue; build-defined, no reference code).
  * nodes [B,R,MDNVAE_DEC_NP] (required): the final node vectors g_r; the backward takes them back.
  * out = NULL (no intercept / exp / dropout): only the node vectors are produced, for a caller that
- * consumes them directly (mdnvae_mdn_outer_fwdbwd). */
+ * consumes them directly (mdnvae_mdn_outer_fwdbwd).
+ * layer_in (optional) [R][NL][B][KP]: every layer's input rows (column KP-1 = 1), kept for a backward
+ * pass that then does not recompute the chain (layer_in_saved below). */
 int mdnvae_decoder_fwd(const float* z, const float* wt, int B, int N, int L, int R, int NL, int acts,
                        int epi_act, const float* icpt_w, const float* icpt_b, int do_exp, const float* drop,
-                       int xlat_channels, int components, float* out, float* xlat, float* nodes, void* stream);
+                       int xlat_channels, int components, float* out, float* xlat, float* nodes, float* layer_in,
+                       void* stream);
 
 /* floats in each of layer_in / layer_dpre for a batch of B */
 size_t mdnvae_decoder_bwd_rows_floats(int B, int R, int NL);
@@ -140,12 +143,14 @@ size_t mdnvae_decoder_bwd_rows_floats(int B, int R, int NL);
  * sums are the intercept-weight gradient.  grad_out is [B,R,N*N] in component mode.  nodes
  * [B,R,MDNVAE_DEC_NP] are the forward's node vectors, node_grad a workspace of the same size.
  * grad_out = NULL (no intercept / exp / dropout): node_grad is an input, the gradient of the node
- * vectors (columns >= N zero), and the walk starts from it. */
+ * vectors (columns >= N zero), and the walk starts from it.
+ * layer_in_saved != 0: layer_in already holds the rows written by mdnvae_decoder_fwd for the same
+ * z and weights (used when there is no dropout multiplier; otherwise the chain is recomputed). */
 int mdnvae_decoder_bwd(const float* z, const float* wt, const float* wn, int B, int N, int L, int R, int NL,
                        int acts, int epi_act, const float* icpt_w, const float* icpt_b, int do_exp,
                        const float* drop, int xlat_channels, int components, const float* grad_out, const float* grad_xlat,
                        float* grad_z, float* layer_in, float* layer_dpre, float* grad_times_act, const float* nodes,
-                       float* node_grad, void* stream);
+                       float* node_grad, int layer_in_saved, void* stream);
 
 /* The decoder's second stage on its own: out [B,N*N] = act(sum_r g_r g_r^T) from node vectors
  * nodes [B,R,MDNVAE_DEC_NP], and the gradient of the node vectors from grad_out

@@ -260,7 +260,8 @@ __device__ __forceinline__ void load_latent_tile(const float* __restrict__ z, in
 __global__ __launch_bounds__(CH_NT, 2) void chain_fwd_mfma_kernel(DecArgs a, const float* __restrict__ z,
                                                                const float* __restrict__ wt,
                                                                const float* __restrict__ drop,
-                                                               float* __restrict__ nodes, float* __restrict__ xlat) {
+                                                               float* __restrict__ nodes, float* __restrict__ xlat,
+                                                               float* __restrict__ hin) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* abuf0 = smem;                                // [2][KP][CH_LD]
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -285,6 +286,19 @@ __global__ __launch_bounds__(CH_NT, 2) void chain_fwd_mfma_kernel(DecArgs a, con
                 const bool last_step = s == S - 1;
                 const bool more = !last_step || tile + (int)gridDim.x < ntiles;
                 if (more) panel_fetch(wt + ((long)((s + 1) % S) * KP) * NP, wave * 32, lane, wnext);
+                // Every layer's input rows (with the ones column) are kept for the backward pass: they
+                // are its weight-gradient operand and, as the previous layer's output, give that
+                // layer's activation slope without recomputing the chain.  The first layer's input
+                // is the latent tile in LDS; the others are stored from the producing layer's
+                // registers below.
+                if (hin && l == 0) {
+                    const float* src = abuf0 + cur * KP * CH_LD;
+                    const long row0 = (long)s * a.B + b0;
+                    for (int i = t; i < CH_TS * KP; i += CH_NT) {
+                        const int sr = i / KP, k = i - sr * KP;
+                        if (b0 + sr < a.B) hin[(row0 + sr) * KP + k] = src[k * CH_LD + sr];
+                    }
+                }
                 const f32x16 acc = panel_product(abuf0 + cur * KP * CH_LD, wcur, lane);
                 const int act = layer_act(a.acts, l);
                 float* nxt = abuf0 + (cur ^ 1) * KP * CH_LD;
@@ -306,7 +320,9 @@ __global__ __launch_bounds__(CH_NT, 2) void chain_fwd_mfma_kernel(DecArgs a, con
                     for (int j = 0; j < 16; ++j) {
                         float v = (n < N) ? act_apply(act, acc[j]) : 0.0f;
                         if (n == KP - 1) v = 1.0f;
-                        nxt[n * CH_LD + acc_row(j, lane)] = v;
+                        const int sr = acc_row(j, lane);
+                        nxt[n * CH_LD + sr] = v;
+                        if (hin && b0 + sr < a.B) hin[((long)(s + 1) * a.B + b0 + sr) * KP + n] = v;
                     }
                 }
                 if (more) {
@@ -616,6 +632,105 @@ __global__ __launch_bounds__(CH_NT, 2) void chain_bwd_mfma_kernel(DecArgs a, con
     }
 }
 
+// Chain backward when the forward pass kept every layer's input rows (layer_in): nothing is
+// recomputed.  The activation slope of layer l comes from its output, which is the next layer's
+// saved input (the node vectors for the last layer), read from global memory one step ahead; only
+// the pre-activation gradient tile lives in LDS, as the A operand of dh_prev = dpre . W.
+__global__ __launch_bounds__(CH_NT, 2) void chain_bwd_saved_kernel(DecArgs a, const float* __restrict__ wn,
+                                                                const float* __restrict__ dnode,
+                                                                const float* __restrict__ gxlat,
+                                                                const float* __restrict__ hin,
+                                                                const float* __restrict__ nodes,
+                                                                float* __restrict__ dz, float* __restrict__ dp) {
+    __shared__ __attribute__((aligned(16))) float dpb[NP * CH_LD];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int n = wave * 32 + (lane & 31);
+    const int N = a.N, R = a.R, NL = a.NL;
+    const int ntiles = (a.B + CH_TS - 1) / CH_TS;
+    if ((int)blockIdx.x >= ntiles) return;
+    const int S = R * NL;                               // panel steps per tile: channel q / NL, layer NL-1 - q % NL
+    auto panel_of = [&](int q) {
+        const int r = q / NL, l = NL - 1 - (q - r * NL);
+        return wn + ((long)(r * NL + l) * NP) * KP;
+    };
+    // outputs of layer l of channel r for this lane's 16 (sample, column) pairs
+    auto fetch_h = [&](int b0, int r, int l, float (&h)[16]) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int s = acc_row(j, lane);
+            float v = 0.0f;
+            if (b0 + s < a.B && n < N)
+                v = (l == NL - 1) ? nodes[((long)(b0 + s) * R + r) * NP + n]
+                                  : hin[((long)(r * NL + l + 1) * a.B + b0 + s) * KP + n];
+            h[j] = v;
+        }
+    };
+    float wcur[PANEL_REGS], wnext[PANEL_REGS], hcur[16], hnext[16];
+    panel_fetch(panel_of(0), wave * 32, lane, wcur);
+    fetch_h(blockIdx.x * CH_TS, 0, NL - 1, hcur);
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int b0 = tile * CH_TS;
+        const bool more_tiles = tile + (int)gridDim.x < ntiles;
+        f32x16 dzacc;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) dzacc[j] = 0.0f;
+        for (int r = 0; r < R; ++r) {
+            f32x16 dh;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int s = acc_row(j, lane);
+                float v = 0.0f;
+                if (b0 + s < a.B && n < N) {
+                    v = dnode[((long)(b0 + s) * R + r) * NP + n];
+                    if (gxlat && r < a.xlat_r) v += gxlat[(long)(b0 + s) * N + n];
+                }
+                dh[j] = v;
+            }
+            for (int l = NL - 1; l >= 0; --l) {
+                const int q = r * NL + (NL - 1 - l);
+                const bool more = q + 1 < S || more_tiles;
+                if (more) {
+                    const int qn = (q + 1) % S, rn = qn / NL, ln = NL - 1 - (qn - rn * NL);
+                    panel_fetch(panel_of(qn), wave * 32, lane, wnext);
+                    fetch_h(q + 1 < S ? b0 : (tile + (int)gridDim.x) * CH_TS, rn, ln, hnext);
+                }
+                const int act = layer_act(a.acts, l);
+                const long row0 = ((long)(r * NL + l) * a.B + b0);
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const int s = acc_row(j, lane);
+                    const float v = (n < N) ? dh[j] * act_slope(act, hcur[j]) : 0.0f;
+                    dpb[n * CH_LD + s] = v;
+                    if (b0 + s < a.B) dp[(row0 + s) * NP + n] = v;
+                }
+                __syncthreads();
+                // dh_prev[s][k] = sum_n dpre[s][n] * Wn[n][k]
+                const f32x16 acc = panel_product(dpb, wcur, lane);
+                if (l == 0) {
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) dzacc[j] += acc[j];
+                } else {
+                    dh = acc;
+                }
+                if (more) {
+#pragma unroll
+                    for (int i = 0; i < PANEL_REGS; ++i) wcur[i] = wnext[i];
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) hcur[j] = hnext[j];
+                }
+                __syncthreads();
+            }
+        }
+        if (n < a.L) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int s = acc_row(j, lane);
+                if (b0 + s < a.B) dz[(long)(b0 + s) * a.L + n] = dzacc[j];
+            }
+        }
+    }
+}
+
 // column sums over the batch: out0[e] = sum_b a[b][e], out1[e] = sum_b c[b][e]  (fixed order)
 __global__ __launch_bounds__(256) void colsum2_partial_kernel(const float* __restrict__ a, const float* __restrict__ c,
                                                               int B, int D, int rows_per_block,
@@ -786,7 +901,7 @@ int mdnvae_decoder_unpack_layer_grads(int count, const int* kind, const float* d
 
 int mdnvae_decoder_fwd(const float* z, const float* wt, int B, int N, int L, int R, int NL, int acts, int epi_act,
                        const float* icpt_w, const float* icpt_b, int do_exp, const float* drop, int xlat_channels,
-                       int components, float* out, float* xlat, float* nodes, void* stream) {
+                       int components, float* out, float* xlat, float* nodes, float* layer_in, void* stream) {
     if (int rc = check_dec("mdnvae_decoder_fwd", B, N, L, R, NL)) return rc;
     if (B == 0) return 0;
     MV_REQUIRE(z && wt, E_ARG, "mdnvae_decoder_fwd: null pointer");
@@ -809,7 +924,7 @@ int mdnvae_decoder_fwd(const float* z, const float* wt, int B, int N, int L, int
         fwd_attr_set = true;
     }
     hipLaunchKernelGGL(chain_fwd_mfma_kernel, dim3(ntiles < 2048 ? ntiles : 2048), dim3(CH_NT), fwd_lds,
-                       (hipStream_t)stream, a, z, wt, drop, nodes, xlat_channels ? xlat : nullptr);
+                       (hipStream_t)stream, a, z, wt, drop, nodes, xlat_channels ? xlat : nullptr, layer_in);
     MV_LAUNCH_CHECK("chain_fwd_mfma_kernel");
     if (!out) return 0;                               // the caller consumes the node vectors itself
     hipLaunchKernelGGL(outer_epilogue_kernel, dim3(wave_grid(components ? (long)B * R : B)), dim3(256), 0,
@@ -824,7 +939,7 @@ int mdnvae_decoder_bwd(const float* z, const float* wt, const float* wn, int B, 
                        int epi_act, const float* icpt_w, const float* icpt_b, int do_exp, const float* drop,
                        int xlat_channels, int components, const float* grad_out, const float* grad_xlat, float* grad_z,
                        float* layer_in, float* layer_dpre, float* grad_times_act, const float* nodes,
-                       float* node_grad, void* stream) {
+                       float* node_grad, int layer_in_saved, void* stream) {
     if (int rc = check_dec("mdnvae_decoder_bwd", B, N, L, R, NL)) return rc;
     if (B == 0) return 0;
     MV_REQUIRE(z && wt && wn && grad_z && layer_in && layer_dpre, E_ARG, "mdnvae_decoder_bwd: null pointer");
@@ -858,6 +973,13 @@ int mdnvae_decoder_bwd(const float* z, const float* wt, const float* wn, int B, 
     }
     MV_LAUNCH_CHECK("outer_grad_kernel");
     const int ntiles = (B + CH_TS - 1) / CH_TS;
+    if (layer_in_saved && !drop) {
+        // the forward pass left every layer's input rows in layer_in: no recomputation
+        hipLaunchKernelGGL(chain_bwd_saved_kernel, dim3(ntiles < 4096 ? ntiles : 4096), dim3(CH_NT), 0, st, a, wn, node_grad,
+                           xlat_channels ? grad_xlat : nullptr, layer_in, nodes, grad_z, layer_dpre);
+        MV_LAUNCH_CHECK("chain_bwd_saved_kernel");
+        return 0;
+    }
     hipLaunchKernelGGL(chain_bwd_mfma_kernel, dim3(ntiles < 2048 ? ntiles : 2048), dim3(CH_NT), lds, st, a, z, wt, wn,
                        drop, node_grad, xlat_channels ? grad_xlat : nullptr, grad_z, layer_in, layer_dpre);
     MV_LAUNCH_CHECK("chain_bwd_mfma_kernel");

@@ -512,11 +512,16 @@ class _ChainDecoder(torch.autograd.Function):
             out = torch.empty((B, spec.R, D) if spec.components else (B, D), dtype=torch.float32, device=dev)
         xlat = torch.empty(B, spec.N, dtype=torch.float32, device=dev) if spec.xlat_channels else None
         nodes = torch.empty(B, spec.R, DEC_NP, dtype=torch.float32, device=dev)
+        # when a backward pass will follow (and no dropout multiplier hides the last layer's output),
+        # the forward keeps every layer's input rows so that backward does not recompute the chain
+        hin = None
+        if drop is None and any(ctx.needs_input_grad):
+            hin = torch.empty(spec.R * spec.NL, B, DEC_KP, dtype=torch.float32, device=dev)
         call("mdnvae_decoder_fwd", ptr(z, "z"), ptr(wt), B, spec.N, spec.L, spec.R, spec.NL, spec.acts, spec.epi_act,
              ptr(icpt_w, "icpt_w"), ptr(icpt_b, "icpt_b"), int(spec.do_exp), ptr(drop, "drop"), spec.xlat_channels,
-             int(spec.components), ptr(out), ptr(xlat), ptr(nodes), stream())
+             int(spec.components), ptr(out), ptr(xlat), ptr(nodes), ptr(hin), stream())
         ctx.spec = spec
-        ctx.save_for_backward(z, wt, wn, icpt_w, icpt_b, drop, nodes)
+        ctx.save_for_backward(z, wt, wn, icpt_w, icpt_b, drop, nodes, hin)
         ctx.param_shapes = [tuple(p.shape) if p is not None else None for p in params]
         ctx.param_objs = params                  # the objects whose .grad a sink may add into
         if xlat is None:
@@ -527,7 +532,7 @@ class _ChainDecoder(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gout, gxlat):
         spec = ctx.spec
-        z, wt, wn, icpt_w, icpt_b, drop, nodes = ctx.saved_tensors
+        z, wt, wn, icpt_w, icpt_b, drop, nodes, saved_hin = ctx.saved_tensors
         B = z.shape[0]
         dev = z.device
         gout = _c(gout)
@@ -536,7 +541,7 @@ class _ChainDecoder(torch.autograd.Function):
         else:
             gxlat = None
         RL = spec.R * spec.NL
-        hin = torch.empty(RL, B, DEC_KP, dtype=torch.float32, device=dev)
+        hin = saved_hin if saved_hin is not None else torch.empty(RL, B, DEC_KP, dtype=torch.float32, device=dev)
         dp = torch.empty(RL, B, DEC_NP, dtype=torch.float32, device=dev)
         gz = torch.empty_like(z)
         ga = torch.empty_like(gout) if icpt_w is not None else None
@@ -547,7 +552,8 @@ class _ChainDecoder(torch.autograd.Function):
         call("mdnvae_decoder_bwd", ptr(z), ptr(wt), ptr(wn), B, spec.N, spec.L, spec.R, spec.NL, spec.acts,
              spec.epi_act, ptr(icpt_w), ptr(icpt_b), int(spec.do_exp), ptr(drop), spec.xlat_channels,
              int(spec.components), ptr(gout),
-             ptr(gxlat), ptr(gz), ptr(hin), ptr(dp), ptr(ga), ptr(nodes), ptr(node_grad), stream())
+             ptr(gxlat), ptr(gz), ptr(hin), ptr(dp), ptr(ga), ptr(nodes), ptr(node_grad), int(saved_hin is not None),
+             stream())
         # weight (+bias, last row) gradient of every layer: [KP x B] . [B x NP] library GEMMs
         dwt = torch.bmm(hin.transpose(1, 2), dp)
         import ctypes

@@ -9,6 +9,7 @@
 int main(int argc, char** argv) {
     const int B = argc > 1 ? atoi(argv[1]) : 8192;
     const int N = argc > 2 ? atoi(argv[2]) : 87;
+    const int saved = argc > 3 ? atoi(argv[3]) : 1;          // forward keeps the layer inputs, backward does not recompute
     const int L = 68, R = 5, NL = 4, KP = MDNVAE_DEC_KP, NP = MDNVAE_DEC_NP;
     const int acts = (1 << 2) | (1 << 4) | (1 << 6);          // linear, then three sigmoid layers
     const size_t panel = (size_t)R * NL * KP * NP;
@@ -29,16 +30,16 @@ int main(int argc, char** argv) {
             int rc;
             if (which == 0)
                 rc = mdnvae_decoder_fwd(z, wt, B, N, L, R, NL, acts, 0, nullptr, nullptr, 0, nullptr, 0, 0, nullptr, nullptr,
-                                        nodes, 0);
+                                        nodes, saved ? hin : nullptr, 0);
             else
                 rc = mdnvae_decoder_bwd(z, wt, wn, B, N, L, R, NL, acts, 0, nullptr, nullptr, 0, nullptr, 0, 0, nullptr,
-                                        nullptr, gz, hin, dp, nullptr, nodes, gnodes, 0);
+                                        nullptr, gz, hin, dp, nullptr, nodes, gnodes, saved, 0);
             if (rc) { printf("rc=%d %s\n", rc, mdnvae_last_error()); return 1; }
             hipEventRecord(e1, 0); hipEventSynchronize(e1);
             float ms; hipEventElapsedTime(&ms, e0, e1);
             if (it >= 0) { sum += ms; if (ms < best) best = ms; }
         }
-        const double flop = 2.0 * B * R * NL * KP * NP * (which ? 3 : 1);
+        const double flop = 2.0 * B * R * NL * KP * NP * (which ? (saved ? 1 : 2) : 1);
         printf("chain_%s B=%d N=%d avg %.1f us best %.1f us  %.1f TFLOP/s\n", which ? "bwd" : "fwd", B, N, sum / iters * 1e3,
                best * 1e3, flop / (sum / iters) / 1e9);
     }
