@@ -268,10 +268,15 @@ __global__ __launch_bounds__(CH_NT, 2) void chain_fwd_mfma_kernel(DecArgs a, con
     const int n = wave * 32 + (lane & 31);
     const int N = a.N;
     const int ntiles = (a.B + CH_TS - 1) / CH_TS;
-    const int S = a.R * a.NL;                           // layer steps per tile
     if ((int)blockIdx.x >= ntiles) return;
+    // with few tiles (small batches) the channels are spread over gridDim.y workgroups: the chains
+    // of different channels are independent, and a tile's 20 serial layer steps become 4
+    const int rper = (a.R + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int r_begin = blockIdx.y * rper, r_end = min(a.R, r_begin + rper);
+    if (r_begin >= r_end) return;
+    const int s_begin = r_begin * a.NL, s_end = r_end * a.NL;      // this workgroup's layer steps per tile
     float wcur[PANEL_REGS], wnext[PANEL_REGS];
-    panel_fetch(wt, wave * 32, lane, wcur);
+    panel_fetch(wt + ((long)s_begin * KP) * NP, wave * 32, lane, wcur);
     int cur = 0;
     load_latent_tile(z, blockIdx.x * CH_TS, a.B, a.L, abuf0);
     __syncthreads();
@@ -280,12 +285,12 @@ __global__ __launch_bounds__(CH_NT, 2) void chain_fwd_mfma_kernel(DecArgs a, con
         float xl[16];
 #pragma unroll
         for (int j = 0; j < 16; ++j) xl[j] = 0.0f;
-        for (int r = 0; r < a.R; ++r) {
+        for (int r = r_begin; r < r_end; ++r) {
             for (int l = 0; l < a.NL; ++l) {
                 const int s = r * a.NL + l;
-                const bool last_step = s == S - 1;
+                const bool last_step = s == s_end - 1;
                 const bool more = !last_step || tile + (int)gridDim.x < ntiles;
-                if (more) panel_fetch(wt + ((long)((s + 1) % S) * KP) * NP, wave * 32, lane, wnext);
+                if (more) panel_fetch(wt + ((long)(last_step ? s_begin : s + 1) * KP) * NP, wave * 32, lane, wnext);
                 // Every layer's input rows (with the ones column) are kept for the backward pass: they
                 // are its weight-gradient operand and, as the previous layer's output, give that
                 // layer's activation slope without recomputing the chain.  The first layer's input
@@ -923,7 +928,9 @@ int mdnvae_decoder_fwd(const float* z, const float* wt, int B, int N, int L, int
         MV_REQUIRE(e == hipSuccess, (int)e, "mdnvae_decoder_fwd: cannot raise the LDS limit: %s", hipGetErrorString(e));
         fwd_attr_set = true;
     }
-    hipLaunchKernelGGL(chain_fwd_mfma_kernel, dim3(ntiles < 2048 ? ntiles : 2048), dim3(CH_NT), fwd_lds,
+    // x_latent sums channels inside one workgroup, so the channel split is for decoders without it
+    const unsigned ysplit = (ntiles <= 128 && xlat_channels == 0) ? (unsigned)R : 1u;
+    hipLaunchKernelGGL(chain_fwd_mfma_kernel, dim3(ntiles < 2048 ? ntiles : 2048, ysplit), dim3(CH_NT), fwd_lds,
                        (hipStream_t)stream, a, z, wt, drop, nodes, xlat_channels ? xlat : nullptr, layer_in);
     MV_LAUNCH_CHECK("chain_fwd_mfma_kernel");
     if (!out) return 0;                               // the caller consumes the node vectors itself
