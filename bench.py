@@ -170,7 +170,7 @@ def _decoder_work(args, backward):
     if matrix is None:
         # chain stage alone: matrix-core work, one 96x96 panel product per (sample, channel, layer)
         # forward; recompute + dh.W backward, plus the weight-gradient operands it emits
-        saved = backward and bool(args[-2])               # layer_in_saved: no recomputation
+        saved = backward and bool(args[-3])               # layer_in_saved: no recomputation
         return 2.0 * B * R * NL * ops.DEC_KP * ops.DEC_NP * (2 if backward and not saved else 1)
     rows = R if components else 1
     extra = R * NL * (ops.DEC_KP + ops.DEC_NP) + L if backward else L
@@ -196,7 +196,7 @@ ABI_TAGS = {
     "mdnvae_decoder_fwd": (lambda a: "chain_fwd_mfma_kernel+outer_epilogue_kernel" if a[15] is not None
                            else "chain_fwd_mfma_kernel", lambda a: _decoder_work(a, 0)),
     "mdnvae_decoder_bwd": (lambda a: "outer_grad_kernel+chain_bwd_mfma_kernel" if a[16] is not None
-                           else ("chain_bwd_saved_kernel" if a[-2] else "chain_bwd_mfma_kernel"),
+                           else ("chain_bwd_saved_kernel" if a[-3] else "chain_bwd_mfma_kernel"),
                            lambda a: _decoder_work(a, 1)),
     "mdnvae_adam_step": ("adam_kernel", lambda a: 28.0 * a[4]),
     # args: (x, B, N, ld, out, asym, stream): read N*N, write the triangle, per matrix

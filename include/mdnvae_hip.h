@@ -145,12 +145,14 @@ size_t mdnvae_decoder_bwd_rows_floats(int B, int R, int NL);
  * grad_out = NULL (no intercept / exp / dropout): node_grad is an input, the gradient of the node
  * vectors (columns >= N zero), and the walk starts from it.
  * layer_in_saved != 0: layer_in already holds the rows written by mdnvae_decoder_fwd for the same
- * z and weights (used when there is no dropout multiplier; otherwise the chain is recomputed). */
+ * z and weights (used when there is no dropout multiplier; otherwise the chain is recomputed).
+ * grad_z_parts (optional, [R,B,L] workspace): lets a small batch (at most 4096 samples) run one
+ * workgroup per (tile, channel) on that path; the per-channel parts are added in channel order. */
 int mdnvae_decoder_bwd(const float* z, const float* wt, const float* wn, int B, int N, int L, int R, int NL,
                        int acts, int epi_act, const float* icpt_w, const float* icpt_b, int do_exp,
                        const float* drop, int xlat_channels, int components, const float* grad_out, const float* grad_xlat,
                        float* grad_z, float* layer_in, float* layer_dpre, float* grad_times_act, const float* nodes,
-                       float* node_grad, int layer_in_saved, void* stream);
+                       float* node_grad, int layer_in_saved, float* grad_z_parts, void* stream);
 
 /* The decoder's second stage on its own: out [B,N*N] = act(sum_r g_r g_r^T) from node vectors
  * nodes [B,R,MDNVAE_DEC_NP], and the gradient of the node vectors from grad_out

@@ -653,7 +653,13 @@ __global__ __launch_bounds__(CH_NT, 2) void chain_bwd_saved_kernel(DecArgs a, co
     const int N = a.N, R = a.R, NL = a.NL;
     const int ntiles = (a.B + CH_TS - 1) / CH_TS;
     if ((int)blockIdx.x >= ntiles) return;
-    const int S = R * NL;                               // panel steps per tile: channel q / NL, layer NL-1 - q % NL
+    // with few tiles (small batches) the channels are spread over gridDim.y workgroups, each writing
+    // its own partial latent gradient (dz then points at [gridDim.y][B][L], added up afterwards)
+    const int rper = (R + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int r_begin = blockIdx.y * rper, r_end = min(R, r_begin + rper);
+    if (r_begin >= r_end) return;
+    dz += (long)blockIdx.y * a.B * a.L;
+    const int q_begin = r_begin * NL, S = r_end * NL;   // panel steps q of a tile: channel q / NL, layer NL-1 - q % NL
     auto panel_of = [&](int q) {
         const int r = q / NL, l = NL - 1 - (q - r * NL);
         return wn + ((long)(r * NL + l) * NP) * KP;
@@ -671,15 +677,15 @@ __global__ __launch_bounds__(CH_NT, 2) void chain_bwd_saved_kernel(DecArgs a, co
         }
     };
     float wcur[PANEL_REGS], wnext[PANEL_REGS], hcur[16], hnext[16];
-    panel_fetch(panel_of(0), wave * 32, lane, wcur);
-    fetch_h(blockIdx.x * CH_TS, 0, NL - 1, hcur);
+    panel_fetch(panel_of(q_begin), wave * 32, lane, wcur);
+    fetch_h(blockIdx.x * CH_TS, r_begin, NL - 1, hcur);
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int b0 = tile * CH_TS;
         const bool more_tiles = tile + (int)gridDim.x < ntiles;
         f32x16 dzacc;
 #pragma unroll
         for (int j = 0; j < 16; ++j) dzacc[j] = 0.0f;
-        for (int r = 0; r < R; ++r) {
+        for (int r = r_begin; r < r_end; ++r) {
             f32x16 dh;
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
@@ -695,7 +701,7 @@ __global__ __launch_bounds__(CH_NT, 2) void chain_bwd_saved_kernel(DecArgs a, co
                 const int q = r * NL + (NL - 1 - l);
                 const bool more = q + 1 < S || more_tiles;
                 if (more) {
-                    const int qn = (q + 1) % S, rn = qn / NL, ln = NL - 1 - (qn - rn * NL);
+                    const int qn = q + 1 < S ? q + 1 : q_begin, rn = qn / NL, ln = NL - 1 - (qn - rn * NL);
                     panel_fetch(panel_of(qn), wave * 32, lane, wnext);
                     fetch_h(q + 1 < S ? b0 : (tile + (int)gridDim.x) * CH_TS, rn, ln, hnext);
                 }
@@ -734,6 +740,16 @@ __global__ __launch_bounds__(CH_NT, 2) void chain_bwd_saved_kernel(DecArgs a, co
             }
         }
     }
+}
+
+// out[i] = sum_p part[p][i] in index order (the per-channel partial latent gradients)
+__global__ __launch_bounds__(256) void add_parts_kernel(const float* __restrict__ part, int parts, long n,
+                                                        float* __restrict__ out) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float s = part[i];
+    for (int p = 1; p < parts; ++p) s += part[(long)p * n + i];
+    out[i] = s;
 }
 
 // column sums over the batch: out0[e] = sum_b a[b][e], out1[e] = sum_b c[b][e]  (fixed order)
@@ -946,7 +962,7 @@ int mdnvae_decoder_bwd(const float* z, const float* wt, const float* wn, int B, 
                        int epi_act, const float* icpt_w, const float* icpt_b, int do_exp, const float* drop,
                        int xlat_channels, int components, const float* grad_out, const float* grad_xlat, float* grad_z,
                        float* layer_in, float* layer_dpre, float* grad_times_act, const float* nodes,
-                       float* node_grad, int layer_in_saved, void* stream) {
+                       float* node_grad, int layer_in_saved, float* grad_z_parts, void* stream) {
     if (int rc = check_dec("mdnvae_decoder_bwd", B, N, L, R, NL)) return rc;
     if (B == 0) return 0;
     MV_REQUIRE(z && wt && wn && grad_z && layer_in && layer_dpre, E_ARG, "mdnvae_decoder_bwd: null pointer");
@@ -982,9 +998,18 @@ int mdnvae_decoder_bwd(const float* z, const float* wt, const float* wn, int B, 
     const int ntiles = (B + CH_TS - 1) / CH_TS;
     if (layer_in_saved && !drop) {
         // the forward pass left every layer's input rows in layer_in: no recomputation
-        hipLaunchKernelGGL(chain_bwd_saved_kernel, dim3(ntiles < 4096 ? ntiles : 4096), dim3(CH_NT), 0, st, a, wn, node_grad,
-                           xlat_channels ? grad_xlat : nullptr, layer_in, nodes, grad_z, layer_dpre);
+        // few tiles: one workgroup per (tile, channel), partial latent gradients added in channel order
+        const bool split = grad_z_parts && ntiles <= 128 && R > 1;
+        hipLaunchKernelGGL(chain_bwd_saved_kernel, dim3(ntiles < 4096 ? ntiles : 4096, split ? R : 1), dim3(CH_NT), 0, st,
+                           a, wn, node_grad, xlat_channels ? grad_xlat : nullptr, layer_in, nodes,
+                           split ? grad_z_parts : grad_z, layer_dpre);
         MV_LAUNCH_CHECK("chain_bwd_saved_kernel");
+        if (split) {
+            const long nz = (long)B * L;
+            hipLaunchKernelGGL(add_parts_kernel, dim3((unsigned)((nz + 255) / 256)), dim3(256), 0, st, grad_z_parts, R, nz,
+                               grad_z);
+            MV_LAUNCH_CHECK("add_parts_kernel");
+        }
         return 0;
     }
     hipLaunchKernelGGL(chain_bwd_mfma_kernel, dim3(ntiles < 2048 ? ntiles : 2048), dim3(CH_NT), lds, st, a, z, wt, wn,

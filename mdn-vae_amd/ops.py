@@ -544,6 +544,9 @@ class _ChainDecoder(torch.autograd.Function):
         hin = saved_hin if saved_hin is not None else torch.empty(RL, B, DEC_KP, dtype=torch.float32, device=dev)
         dp = torch.empty(RL, B, DEC_NP, dtype=torch.float32, device=dev)
         gz = torch.empty_like(z)
+        # small batches: workspace for one partial latent gradient per channel
+        gz_parts = torch.empty(spec.R, B, spec.L, dtype=torch.float32, device=dev) \
+            if (saved_hin is not None and B <= 4096 and spec.R > 1) else None
         ga = torch.empty_like(gout) if icpt_w is not None else None
         if spec.nodes_only:                      # gout is the gradient of the node vectors themselves
             node_grad, gout = gout, None
@@ -553,7 +556,7 @@ class _ChainDecoder(torch.autograd.Function):
              spec.epi_act, ptr(icpt_w), ptr(icpt_b), int(spec.do_exp), ptr(drop), spec.xlat_channels,
              int(spec.components), ptr(gout),
              ptr(gxlat), ptr(gz), ptr(hin), ptr(dp), ptr(ga), ptr(nodes), ptr(node_grad), int(saved_hin is not None),
-             stream())
+             ptr(gz_parts), stream())
         # weight (+bias, last row) gradient of every layer: [KP x B] . [B x NP] library GEMMs
         dwt = torch.bmm(hin.transpose(1, 2), dp)
         import ctypes

@@ -33,7 +33,7 @@ int main(int argc, char** argv) {
                                         nodes, saved ? hin : nullptr, 0);
             else
                 rc = mdnvae_decoder_bwd(z, wt, wn, B, N, L, R, NL, acts, 0, nullptr, nullptr, 0, nullptr, 0, 0, nullptr,
-                                        nullptr, gz, hin, dp, nullptr, nodes, gnodes, saved, 0);
+                                        nullptr, gz, hin, dp, nullptr, nodes, gnodes, saved, nullptr, 0);
             if (rc) { printf("rc=%d %s\n", rc, mdnvae_last_error()); return 1; }
             hipEventRecord(e1, 0); hipEventSynchronize(e1);
             float ms; hipEventElapsedTime(&ms, e0, e1);
