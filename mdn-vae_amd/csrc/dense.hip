@@ -133,6 +133,13 @@ size_t mdnvae_colsum_workspace_floats(int B, int D) { return (size_t)((B + 63) /
 int mdnvae_colsum(const float* a, int B, int D, float* workspace, float* out, int accumulate, void* stream) {
     MV_REQUIRE(B >= 1 && D >= 1, E_ARG, "mdnvae_colsum: empty input");
     MV_REQUIRE(a && workspace && out, E_ARG, "mdnvae_colsum: null pointer");
+    if (B <= 512) {
+        // a short batch is one slab: the folding kernel adds its rows straight into the result
+        hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)((D + CS_COLS - 1) / CS_COLS)), dim3(256), 0,
+                           (hipStream_t)stream, a, B, D, accumulate, out);
+        MV_LAUNCH_CHECK("colsum_final_kernel");
+        return 0;
+    }
     // slabs of 64 rows for small batches, longer ones once there are enough slabs to fill the chip
     const int rows = B >= 8192 ? 256 : (B >= 2048 ? 128 : 64), nparts = (B + rows - 1) / rows;
     const unsigned cols = (unsigned)((D + CS_COLS - 1) / CS_COLS);
