@@ -35,6 +35,8 @@ PEAK_HBM_GBPS = 8000.0
 TRAFFIC_RATIO = {"loss_stream_kernel": 1.00, "mdn_fwd_kernel": 1.10, "mdn_bwd_stream_kernel": 1.27,
                  "mdn_outer_kernel": 1.03, "tri_pack_kernel": 1.01, "adam_kernel": 1.00}
 
+REHEARSE_EXCHANGE = False
+
 MODELS = {
     # name: (constructor kwargs, loss mode, data kind)
     "cnn_gcn": (dict(decoder="gcn", intercept="diag", final="none"), "poisson_log", "sc"),   # function/VAE-CNN-GCN.py
@@ -347,18 +349,18 @@ def run_workload(model_name, batch, nodes, steps, warmup, pool_batches, device, 
         one_step(i)
 
     def timed(nsteps, first):
-        if world > 1:
+        if world > 1 or REHEARSE_EXCHANGE:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         out = None
         for i in range(nsteps):
             out = one_step(first + i)
-        if world > 1:
+        if world > 1 or REHEARSE_EXCHANGE:
             dist.barrier()
         torch.cuda.synchronize()
         el = torch.tensor([time.perf_counter() - t0], device=device, dtype=torch.float64)
-        if world > 1:
+        if world > 1 or REHEARSE_EXCHANGE:
             dist.all_reduce(el, op=dist.ReduceOp.MAX)
         return float(el.item()), out
 
@@ -394,6 +396,8 @@ def main():
     ap.add_argument("--also", default="cnn_gcn", help="second workload reported under 'also' on one GPU ('' = none)")
     ap.add_argument("--nodes", type=int, default=87)
     ap.add_argument("--pool", type=int, default=2, help="resident synthetic batches per GPU")
+    ap.add_argument("--rehearse-exchange", action="store_true",
+                    help="one GPU only: run the collective calls of the data-parallel path on a one-rank RCCL group")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-script-batch", action="store_true",
                     help="skip the batch-256 runs (eager and graph replay) reported under 'script_batch' on one GPU")
@@ -418,6 +422,15 @@ def main():
         local_rank %= torch.cuda.device_count()          # rehearsal: ranks may share a GPU
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    if args.rehearse_exchange and world == 1:
+        # one GPU: a one-rank RCCL group whose collectives are identities, so that the calls of the
+        # multi-GPU path (barriers, early and bucketed gradient all-reduce, MAX of the timings) run
+        global REHEARSE_EXCHANGE
+        REHEARSE_EXCHANGE = True
+        M.trainer.MIN_RANKS_FOR_EXCHANGE = 1
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group(backend="nccl", world_size=1, rank=0, device_id=device)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
@@ -494,7 +507,7 @@ def main():
         line["also"] = also
     if rank == 0:
         print(json.dumps(line))
-    if world > 1:
+    if world > 1 or REHEARSE_EXCHANGE:
         dist.destroy_process_group()
 
 

@@ -50,10 +50,16 @@ class FlatBuffers:
                 p.grad = self.flat_g[o:o + p.numel()].view(p.shape)
 
 
+# A one-rank process group normally counts as "not distributed".  Set to 1 to send its gradients
+# through the collective calls anyway (the sums are then identities): the only way to run the
+# RCCL code path on a machine with a single GPU.
+MIN_RANKS_FOR_EXCHANGE = 2
+
+
 def allreduce_sum(flat, group=None, bucket_floats=8 << 20):
     """In-place SUM all-reduce of a flat buffer in buckets of `bucket_floats` (32 MiB): large
     enough that each xGMI ring step moves megabytes, small enough to pipeline."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not _distributed(group):
         return
     works = []
     for o in range(0, flat.numel(), bucket_floats):
@@ -63,7 +69,7 @@ def allreduce_sum(flat, group=None, bucket_floats=8 << 20):
 
 
 def _distributed(group=None):
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size(group) >= MIN_RANKS_FOR_EXCHANGE
 
 
 class Trainer:

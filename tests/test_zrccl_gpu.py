@@ -1,0 +1,56 @@
+"""The data-parallel step on the real RCCL backend with a one-rank group (one GPU is all there is):
+every collective is an identity, but the calls - communicator set-up on the device, asynchronous
+all-reduce of flat-buffer views launched from inside backward, bucketed all-reduce, waits - are the
+ones a multi-GPU run makes."""
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+
+from conftest import load_fixture, fixture_params
+import mdnvae_amd as M
+from mdnvae_amd import trainer as T
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_one_rank_rccl_step_equals_the_local_step():
+    fix = load_fixture("mm_gate")
+    params = fixture_params(fix)
+    x = torch.from_numpy(fix["x"]).to(DEV)
+    x = 0.5 * (x.reshape(-1, 68, 68) + x.reshape(-1, 68, 68).transpose(1, 2)).reshape(-1, 68 * 68).contiguous()
+    eps = torch.from_numpy(fix["eps"]).to(DEV)
+    adjacency = [list(map(int, r)) for r in fix["adjacency"]]
+
+    def run(distributed):
+        model = M.GCNVAE(R=5, n_nodes=68, k=32, n_layers=3, latent_dim=68, symmetric_input=True)
+        model.load_state_dict(params, strict=False)
+        trainer = M.Trainer(model.to(DEV), "poisson_log")
+        assert bool(trainer._hook_of) == distributed          # the big first-layer matrices reduce early
+        losses = [float(trainer.step((x, adjacency), x, eps=eps).item()) for _ in range(3)]
+        torch.cuda.synchronize()
+        return losses, trainer.buf.flat_p.clone()
+
+    local = run(False)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{_free_port()}", world_size=1, rank=0,
+                            device_id=torch.device(DEV))
+    T.MIN_RANKS_FOR_EXCHANGE = 1
+    try:
+        dist.barrier()
+        exchanged = run(True)
+        stats = M.FeatureStats(8, torch.zeros(8, device=DEV), DEV).update(torch.rand(64, 8, device=DEV)).allreduce()
+        assert stats.n == 64
+    finally:
+        T.MIN_RANKS_FOR_EXCHANGE = 2
+        dist.destroy_process_group()
+    assert exchanged[0] == local[0]
+    assert torch.equal(exchanged[1], local[1])
