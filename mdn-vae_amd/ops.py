@@ -118,10 +118,15 @@ class accumulate_into_grads:
     one more elementwise kernel per parameter - some fifty launches a step for the GCN-decoder
     models) and hands autograd no gradient for that parameter.  `ready(param)`, if given, is called
     after each such addition (post-accumulate hooks do not fire on this path).  Parameters whose
-    `.grad` is missing, of another dtype / shape or not contiguous take the ordinary path."""
+    `.grad` is missing, of another dtype / shape or not contiguous take the ordinary path.
+    `folded(param, gt, n_nodes)`, if given, takes over the weight gradient of a symmetric-input
+    layer in its folded form gt [T, H] (one value per unordered pair (i,j)): the caller then owns
+    writing it to both (i,j) and (j,i) of param.grad, after whatever it does with the half-size
+    buffer first (the data-parallel trainer all-reduces it)."""
 
-    def __init__(self, ready=None):
+    def __init__(self, ready=None, folded=None):
         self.ready = ready
+        self.folded = folded
 
     def __enter__(self):
         global _SINK
@@ -287,7 +292,9 @@ class _SymLinearAct(torch.autograd.Function):
             H, n = gpre.shape[1], ctx.n_nodes
             gt = _library_gemm(xt.t(), gpre)                       # [T, H]
             target = _grad_target(ctx.params[0])
-            if target is not None:
+            if target is not None and _SINK.folded is not None:
+                _SINK.folded(ctx.params[0], gt, n)
+            elif target is not None:
                 call("mdnvae_tri_unfold", ptr(gt), H, n, H, 1, ptr(target), 1, stream())
                 _grad_added(ctx.params[0])
             else:

@@ -19,12 +19,16 @@ class FlatBuffers:
     """Re-homes a module's parameters (and their .grad) into two flat fp32 buffers.  Every
     parameter starts at a multiple of 4 floats, so each view is 16-byte aligned for the kernels
     that write gradients into it; the few padding elements stay zero in both buffers (a zero
-    gradient leaves a zero parameter at zero under Adam)."""
+    gradient leaves a zero parameter at zero under Adam).  `front(param) -> bool` moves the
+    parameters it selects to the start of the buffers (module order otherwise), so that the rest
+    is one contiguous range."""
 
-    def __init__(self, module):
+    def __init__(self, module, front=None):
         self.params = [p for p in module.parameters() if p.requires_grad]
         if not self.params:
             raise ValueError("module has no trainable parameters")
+        if front is not None:
+            self.params = [p for p in self.params if front(p)] + [p for p in self.params if not front(p)]
         dev = self.params[0].device
         sizes = [p.numel() for p in self.params]
         self.offsets = [0]
@@ -76,14 +80,18 @@ class Trainer:
     """`overlap_floats`: with more than one rank, a parameter of at least this many elements has
     its gradient all-reduced from a post-accumulate hook, i.e. as soon as backward has produced it,
     so the transfer of the large encoder matrices runs under the rest of the backward pass (every
-    rank runs the same graph, so the hooks fire in the same order everywhere).  The remaining
-    ranges of the flat gradient buffer are reduced in buckets after backward."""
+    rank runs the same graph, so the hooks fire in the same order everywhere).  A symmetric-input
+    first layer (GCNVAE(symmetric_input=True)) hands over its weight gradient folded onto the upper
+    triangle, so half the bytes cross the links and the copy to both triangles happens after the
+    sum.  The rest of the flat gradient buffer is reduced in buckets after backward."""
 
     def __init__(self, model, loss_mode, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, group=None, fused_loss=True,
                  overlap_floats=1 << 20, direct_grads=True):
         self.model, self.loss_mode, self.group = model, loss_mode, group
         self.lr, self.betas, self.eps = lr, betas, eps
-        self.buf = FlatBuffers(model)
+        early = _distributed(group) and overlap_floats
+        # the early-reduced matrices sit together at the front: what is left is one all-reduce
+        self.buf = FlatBuffers(model, front=(lambda p: p.numel() >= overlap_floats) if early else None)
         self.exp_avg = torch.zeros_like(self.buf.flat_p)
         self.exp_avg_sq = torch.zeros_like(self.buf.flat_p)
         self.steps = 0
@@ -91,6 +99,7 @@ class Trainer:
         self.direct_grads = direct_grads
         self._hook_of = {}          # id(param) -> its early all-reduce hook
         self._pending = []          # async all-reduces launched from hooks during backward
+        self._folded = []           # (all-reduce, folded gradient [T,H], param, n_nodes) awaiting their unfold
         self._rest = [(0, self.buf.numel)]   # flat ranges still to be reduced after backward
         if _distributed(group) and overlap_floats:
             self._install_overlap_hooks(overlap_floats)
@@ -130,13 +139,25 @@ class Trainer:
         one AccumulateGrad kernel per parameter."""
         if not self.direct_grads:
             return self._forward_backward(inputs, target, eps)
-        with ops.accumulate_into_grads(ready=self._grad_ready if self._hook_of else None):
+        exchange = bool(self._hook_of)
+        with ops.accumulate_into_grads(ready=self._grad_ready if exchange else None,
+                                       folded=self._folded_grad if exchange else None):
             return self._forward_backward(inputs, target, eps)
 
     def _grad_ready(self, param):
         hook = self._hook_of.get(id(param))
         if hook is not None:
             hook(param)
+
+    def _folded_grad(self, param, gt, n_nodes):
+        """Weight gradient of a symmetric-input first layer, still folded onto the upper triangle
+        ([T, H], half the elements of the weight): that is what crosses the links.  The SUM commutes
+        with writing each value to (i,j) and (j,i), which optimizer_step does once the transfer is in."""
+        if id(param) not in self._hook_of:   # a small layer: unfold now, its range goes with the buckets
+            call("mdnvae_tri_unfold", ptr(gt), gt.shape[1], n_nodes, gt.shape[1], 1, ptr(param.grad), 1, stream())
+            return
+        work = dist.all_reduce(gt, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._folded.append((work, gt, param, n_nodes))
 
     def _forward_backward(self, inputs, target, eps=None):
         self.buf.zero_grad()
@@ -181,6 +202,10 @@ class Trainer:
         for w in self._pending:
             w.wait()
         self._pending.clear()
+        for work, gt, param, n_nodes in self._folded:
+            work.wait()
+            call("mdnvae_tri_unfold", ptr(gt), gt.shape[1], n_nodes, gt.shape[1], 1, ptr(param.grad), 1, stream())
+        self._folded.clear()
         self.steps += 1
         call("mdnvae_adam_step", ptr(self.buf.flat_p), ptr(self.buf.flat_g), ptr(self.exp_avg), ptr(self.exp_avg_sq),
              self.buf.numel, self.steps, float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps),

@@ -35,9 +35,19 @@ def test_one_rank_rccl_step_equals_the_local_step():
         model.load_state_dict(params, strict=False)
         trainer = M.Trainer(model.to(DEV), "poisson_log")
         assert bool(trainer._hook_of) == distributed          # the big first-layer matrices reduce early
-        losses = [float(trainer.step((x, adjacency), x, eps=eps).item()) for _ in range(3)]
+        losses = []
+        for _ in range(3):
+            loss = trainer.forward_backward((x, adjacency), x, eps=eps)
+            # both first-layer weight gradients travel folded (half size), unfolded after the sum
+            assert len(trainer._folded) == (2 if distributed else 0)
+            assert all(gt.shape == (M.ops.tri_row_stride(68), 1024) for _, gt, _, _ in trainer._folded)
+            trainer.optimizer_step()
+            assert not trainer._folded and not trainer._pending
+            losses.append(float(loss.item()))
         torch.cuda.synchronize()
-        return losses, trainer.buf.flat_p.clone()
+        if distributed:                                       # big matrices first, the rest is one range
+            assert trainer._rest == [(2 * 1024 * 68 * 68, trainer.buf.numel)]
+        return losses, {k: v.detach().clone() for k, v in model.named_parameters()}
 
     local = run(False)
     torch.cuda.set_device(0)
@@ -53,4 +63,5 @@ def test_one_rank_rccl_step_equals_the_local_step():
         T.MIN_RANKS_FOR_EXCHANGE = 2
         dist.destroy_process_group()
     assert exchanged[0] == local[0]
-    assert torch.equal(exchanged[1], local[1])
+    for name, value in local[1].items():
+        assert torch.equal(exchanged[1][name], value), name
