@@ -69,11 +69,14 @@ int mdnvae_vae_loss_fwdbwd(int mode, const float* recon, const float* x, long B,
  * straight from the node vectors nodes [B,R,MDNVAE_DEC_NP] in one pass over x: neither recon nor
  * its gradient is written to memory.  Upstream gradient 1.  grad_nodes [B,R,MDNVAE_DEC_NP]
  * (columns >= N zero), grad_mu / grad_logvar [B,L] (both or neither), loss_out[3] = {total, recon
- * term, KL}; workspace of mdnvae_outer_loss_workspace_bytes(B) bytes.  R <= 8, N <= MDNVAE_DEC_NP-1. */
+ * term, KL}; workspace of mdnvae_outer_loss_workspace_bytes(B) bytes.  R <= 8, N <= MDNVAE_DEC_NP-1.
+ * x_symmetric != 0: the caller vouches that every x[b] equals its transpose (e.g. mdnvae_tri_pack
+ * has checked the same buffer); the pass then needs no row sums.  On input that is not symmetric
+ * the loss is still right but grad_nodes is not. */
 size_t mdnvae_outer_loss_workspace_bytes(int B);
 int mdnvae_outer_loss_fwdbwd(int mode, const float* nodes, const float* x, int B, int R, int N, const float* mu,
                              const float* logvar, int L, float* grad_nodes, float* grad_mu, float* grad_logvar,
-                             void* workspace, float* loss_out, void* stream);
+                             int x_symmetric, void* workspace, float* loss_out, void* stream);
 
 /* ---- multi-channel chain decoder ---------------------------------------------------------
  * R channels; channel r maps z [B,L] through NL small dense layers to a node vector g_r [B,N];
@@ -300,11 +303,14 @@ int mdnvae_mdn_loss_fwd(const float* comp_mean, const float* x, const float* gat
  * over x: the component matrices and their gradients are never written to memory.  Upstream
  * gradient 1.  grad_nodes [B,K,MDNVAE_DEC_NP] (columns >= N zero), grad_logits / resp /
  * grad_log_sigma_rows [B,K], grad_mu / grad_logvar [B,L] (both or neither), loss_out[3] as above;
- * workspace of mdnvae_mdn_workspace_bytes(B) bytes.  K <= 8, N <= MDNVAE_DEC_NP-1. */
+ * workspace of mdnvae_mdn_workspace_bytes(B) bytes.  K <= 8, N <= MDNVAE_DEC_NP-1.
+ * x_symmetric != 0: the caller vouches that every x[b] equals its transpose (e.g. mdnvae_tri_pack
+ * has checked the same buffer); the pass then needs no row sums and runs at streaming speed.  On
+ * input that is not symmetric the loss is still right but grad_nodes is not. */
 int mdnvae_mdn_outer_fwdbwd(const float* nodes, const float* x, const float* gate_logits, const float* log_sigma,
                             int B, int K, int N, const float* mu, const float* logvar, int L, float* grad_nodes,
                             float* grad_logits, float* grad_log_sigma_rows, float* grad_mu, float* grad_logvar,
-                            float* resp, void* workspace, float* loss_out, void* stream);
+                            float* resp, int x_symmetric, void* workspace, float* loss_out, void* stream);
 int mdnvae_mdn_loss_bwd(const float* comp_mean, const float* x, const float* gate_logits, const float* log_sigma,
                         const float* resp, const float* sumsq, int B, int K, int D, const float* mu,
                         const float* logvar, int L, const float* grad_loss, float* grad_comp, float* grad_logits,

@@ -158,20 +158,14 @@ __global__ __launch_bounds__(LOSS_NT) void loss_stream_kernel(
 }
 
 // out[0] = recon term + KL, out[1] = recon term, out[2] = KL
-__global__ __launch_bounds__(256) void loss_finalize_kernel(const double* __restrict__ partials, int nblocks,
+__global__ __launch_bounds__(PAIR_NT) void loss_finalize_kernel(const double* __restrict__ partials, int nblocks,
                                                             float* __restrict__ out) {
-    __shared__ double red[4];
-    double a = 0.0, k = 0.0;
-    for (int i = threadIdx.x; i < nblocks; i += 256) {
-        a += partials[2 * i];
-        k += partials[2 * i + 1];
-    }
-    a = block_sum<256, double>(a, red);
-    k = block_sum<256, double>(k, red);
+    __shared__ double red[PAIR_NT / 64];
+    const PairSum t = block_pair_sum(partials, nblocks, red);
     if (threadIdx.x == 0) {
-        out[0] = (float)(a + k);
-        out[1] = (float)a;
-        out[2] = (float)k;
+        out[0] = (float)(t.a + t.k);
+        out[1] = (float)t.a;
+        out[2] = (float)t.k;
     }
 }
 
@@ -220,7 +214,7 @@ static int launch_loss(int mode, const float* recon, const float* x, float* grad
 #undef MV_LOSS_CASE
     MV_LAUNCH_CHECK("loss_stream_kernel");
     if (WANT_LOSS) {
-        hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, st, partials, grid, out);
+        hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(PAIR_NT), 0, st, partials, grid, out);
         MV_LAUNCH_CHECK("loss_finalize_kernel");
     }
     return 0;

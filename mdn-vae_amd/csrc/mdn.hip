@@ -132,20 +132,14 @@ __global__ __launch_bounds__(MDN_NT) void mdn_fwd_kernel(const float* __restrict
 }
 
 // out[0] = nll + KL, out[1] = nll, out[2] = KL (fixed summation order)
-__global__ __launch_bounds__(256) void mdn_finalize_kernel(const double* __restrict__ per_sample, int B,
+__global__ __launch_bounds__(PAIR_NT) void mdn_finalize_kernel(const double* __restrict__ per_sample, int B,
                                                            float* __restrict__ out) {
-    __shared__ double red[4];
-    double a = 0.0, k = 0.0;
-    for (int i = threadIdx.x; i < B; i += 256) {
-        a += per_sample[2 * i];
-        k += per_sample[2 * i + 1];
-    }
-    a = block_sum<256, double>(a, red);
-    k = block_sum<256, double>(k, red);
+    __shared__ double red[PAIR_NT / 64];
+    const PairSum t = block_pair_sum(per_sample, B, red);
     if (threadIdx.x == 0) {
-        out[0] = (float)(a + k);
-        out[1] = (float)a;
-        out[2] = (float)k;
+        out[0] = (float)(t.a + t.k);
+        out[1] = (float)t.a;
+        out[2] = (float)t.k;
     }
 }
 
@@ -280,7 +274,78 @@ constexpr int MO_NP = MDNVAE_DEC_NP;
 constexpr int MO_LD = 68;                       // tile row stride: 16-byte rows, lanes 0..7 cover all banks
 typedef float mo_v2 __attribute__((ext_vector_type(2)));
 __host__ __device__ constexpr int mo_wave_floats(int K) { return K * MO_ROWS * MO_LD + K * MO_NP; }
+// ---- the sweep over a symmetric x[b] ----
+// Lane l owns the adjacent columns 2l and 2l+1 (one 8-byte load per row).  Loads go through a
+// buffer descriptor of the sample's N*N floats: a lane whose columns do not exist carries an offset
+// past the end, for which the hardware returns 0, so the row loads need no branches; the row offset
+// is a scalar.  (Measured on MI355X at B = 16384, N = 87: issuing the next group's loads ahead of
+// the arithmetic, 4 or 16 rows per group, unpacked FMAs and other cache policies all land within a
+// few percent of this form or below it; the loads alone take 0.9 of the kernel's time.)
+typedef unsigned mo_u2 __attribute__((ext_vector_type(2)));
+constexpr int MO_SR = 8;                        // rows per group (even: a row's parity is its slot's)
+template <bool FULL>
+__device__ __forceinline__ void mo_sym_load(__amdgpu_buffer_rsrc_t rsrc, int off, int row_bytes, int i0, int rows,
+                                            mo_u2 (&a)[MO_SR]) {
+#pragma unroll
+    for (int q = 0; q < MO_SR; ++q) {
+        if (FULL || q < rows) a[q] = __builtin_amdgcn_raw_buffer_load_b64(rsrc, off, (i0 + q) * row_bytes, 2 /* nt */);
+        else a[q] = mo_u2{0u, 0u};
+    }
+}
+// rows i0 .. i0+rows-1 (i0 a multiple of MO_SR, so the parity of a row is known at compile time)
+// against every component; the K components of a row are independent chains, issued side by side
+template <int K, bool FULL>
+__device__ __forceinline__ void mo_sym_rows(const mo_u2 (&a)[MO_SR], bool second_ok, int i0, int rows,
+                                            const mo_v2 (&g)[K], mo_v2 (&v)[K], mo_v2 (&ss2)[K]) {
+#pragma unroll
+    for (int q = 0; q < MO_SR; ++q) {
+        if (FULL || q < rows) {
+            // the second column of the last lane of an odd N is the next row's first element
+            const mo_v2 xq{__uint_as_float(a[q].x), second_ok ? __uint_as_float(a[q].y) : 0.0f};
+            mo_v2 gi2[K], r[K];
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const float gi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int((q & 1) ? g[k].y : g[k].x),
+                                                                         (i0 + q) >> 1));
+                gi2[k] = mo_v2{gi, gi};
+            }
+#pragma unroll
+            for (int k = 0; k < K; ++k) r[k] = gi2[k] * g[k] - xq;
+#pragma unroll
+            for (int k = 0; k < K; ++k) ss2[k] += r[k] * r[k];
+#pragma unroll
+            for (int k = 0; k < K; ++k) v[k] += r[k] * gi2[k];
+        }
+    }
+}
 template <int K>
+__device__ __forceinline__ void mo_sym_sweep(const float* X, int N, int lane, const mo_v2 (&g)[K], mo_v2 (&v)[K],
+                                             mo_v2 (&ss2)[K]) {
+    // the descriptor must be provably wave-uniform: X depends on the wave's index
+    const unsigned long addr = reinterpret_cast<unsigned long>(X);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)addr);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(addr >> 32));
+    void* base = reinterpret_cast<void*>(((unsigned long)hi << 32) | lo);
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(base, 0, N * N * 4, 0x00020000);
+    const int off = 2 * lane < N ? lane * 8 : 0x7ffffff0;
+    const bool second_ok = 2 * lane + 1 < N;
+    const int row_bytes = N * 4;
+    const int groups = N / MO_SR, tail = N - groups * MO_SR;
+    mo_u2 a[MO_SR];
+    for (int gr = 0; gr < groups; ++gr) {
+        mo_sym_load<true>(rsrc, off, row_bytes, gr * MO_SR, MO_SR, a);
+        mo_sym_rows<K, true>(a, second_ok, gr * MO_SR, MO_SR, g, v, ss2);
+    }
+    if (tail) {
+        mo_sym_load<false>(rsrc, off, row_bytes, groups * MO_SR, tail, a);
+        mo_sym_rows<K, false>(a, second_ok, groups * MO_SR, tail, g, v, ss2);
+    }
+}
+
+// SYM: the caller vouches that every x[b] is symmetric.  Then r is symmetric, the row sums equal
+// the column sums the lanes already hold, and the sweep needs no LDS and no cross-lane step at all:
+// three packed operations per (row, component) on a stream of x.
+template <int K, bool SYM>
 __global__ __launch_bounds__(MDN_NT) void mdn_outer_kernel(const float* __restrict__ nodes, const float* __restrict__ x,
                                                            const float* __restrict__ logits,
                                                            const float* __restrict__ log_sigma, int B, int N,
@@ -289,12 +354,14 @@ __global__ __launch_bounds__(MDN_NT) void mdn_outer_kernel(const float* __restri
                                                            float* __restrict__ glsig_rows, float* __restrict__ gmu,
                                                            float* __restrict__ glogvar, float* __restrict__ resp,
                                                            double* __restrict__ per_sample) {
-    __shared__ __attribute__((aligned(16))) float lds[(MDN_NT / 64) * mo_wave_floats(K)];
+    __shared__ __attribute__((aligned(16))) float lds[SYM ? 4 : (MDN_NT / 64) * mo_wave_floats(K)];
     const int lane = threadIdx.x & 63;
     const int wave = blockIdx.x * (MDN_NT / 64) + (threadIdx.x >> 6);
     const int nwaves = gridDim.x * (MDN_NT / 64);
     const int D = N * N;
-    const bool c0 = lane < N, c1 = lane + 64 < N;
+    // columns of the lane's packed pair: (lane, lane + 64), or (2 lane, 2 lane + 1) in the SYM sweep
+    const int col0 = SYM ? 2 * lane : lane, col1 = SYM ? 2 * lane + 1 : lane + 64;
+    const bool c0 = col0 < N, c1 = col1 < N;
     float* tile = lds + (threadIdx.x >> 6) * mo_wave_floats(K);    // [K * MO_ROWS][MO_LD]
     float* utab = tile + K * MO_ROWS * MO_LD;                       // [K][MO_NP]
     for (int b = wave; b < B; b += nwaves) {
@@ -305,11 +372,12 @@ __global__ __launch_bounds__(MDN_NT) void mdn_outer_kernel(const float* __restri
         mo_v2 g[K], v[K], ss2[K];
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-            g[k].x = c0 ? gv[k * MO_NP + lane] : 0.0f;
-            g[k].y = c1 ? gv[k * MO_NP + lane + 64] : 0.0f;
+            g[k].x = c0 ? gv[k * MO_NP + col0] : 0.0f;
+            g[k].y = c1 ? gv[k * MO_NP + col1] : 0.0f;
             v[k] = ss2[k] = mo_v2{0.0f, 0.0f};
         }
-        for (int i0 = 0; i0 < N; i0 += MO_ROWS) {
+        if constexpr (SYM) mo_sym_sweep<K>(X, N, lane, g, v, ss2);
+        for (int i0 = 0; !SYM && i0 < N; i0 += MO_ROWS) {
             mo_v2 a[MO_ROWS];
 #pragma unroll
             for (int q = 0; q < MO_ROWS; ++q) {
@@ -361,8 +429,8 @@ __global__ __launch_bounds__(MDN_NT) void mdn_outer_kernel(const float* __restri
             ss[k] = ss2[k].x + ss2[k].y;
             v0[k] = v[k].x;
             v1[k] = v[k].y;
-            u0[k] = c0 ? utab[k * MO_NP + lane] : 0.0f;
-            u1[k] = c1 ? utab[k * MO_NP + lane + 64] : 0.0f;
+            u0[k] = SYM ? v0[k] : (c0 ? utab[k * MO_NP + lane] : 0.0f);
+            u1[k] = SYM ? v1[k] : (c1 ? utab[k * MO_NP + lane + 64] : 0.0f);
         }
         float ssk = 0.0f;                                           // lane k < K owns component k
 #pragma unroll
@@ -412,8 +480,8 @@ __global__ __launch_bounds__(MDN_NT) void mdn_outer_kernel(const float* __restri
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             const float ck = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(coef), k));
-            dst[k * MO_NP + lane] = c0 ? ck * (u0[k] + v0[k]) : 0.0f;
-            if (lane + 64 < MO_NP) dst[k * MO_NP + lane + 64] = c1 ? ck * (u1[k] + v1[k]) : 0.0f;
+            if (col0 < MO_NP) dst[k * MO_NP + col0] = c0 ? ck * (u0[k] + v0[k]) : 0.0f;
+            if (col1 < MO_NP) dst[k * MO_NP + col1] = c1 ? ck * (u1[k] + v1[k]) : 0.0f;
         }
     }
 }
@@ -436,7 +504,8 @@ using namespace mdnvae;
 #ifndef MDN_MAX_BLOCKS_N
 #define MDN_MAX_BLOCKS_N 1024
 #endif
-// one wave per sample, every wave resident at once where the batch allows it
+// one wave per sample, every wave resident at once where the batch allows it (a grid sized to the
+// kernel's measured occupancy, equal samples per wave, was tried and is no faster)
 static unsigned mdn_outer_grid(int B) {
     const int blocks = (B + MDN_NT / 64 - 1) / (MDN_NT / 64);
     return (unsigned)(blocks < 2048 ? blocks : 2048);
@@ -470,7 +539,7 @@ int mdnvae_mdn_loss_fwd(const float* comp_mean, const float* x, const float* gat
 #undef CALL
         MV_LAUNCH_CHECK("mdn_fwd_kernel");
     }
-    hipLaunchKernelGGL(mdn_finalize_kernel, dim3(1), dim3(256), 0, st, (const double*)workspace, B, loss_out);
+    hipLaunchKernelGGL(mdn_finalize_kernel, dim3(1), dim3(PAIR_NT), 0, st, (const double*)workspace, B, loss_out);
     MV_LAUNCH_CHECK("mdn_finalize_kernel");
     return 0;
 }
@@ -478,7 +547,7 @@ int mdnvae_mdn_loss_fwd(const float* comp_mean, const float* x, const float* gat
 int mdnvae_mdn_outer_fwdbwd(const float* nodes, const float* x, const float* gate_logits, const float* log_sigma,
                             int B, int K, int N, const float* mu, const float* logvar, int L, float* grad_nodes,
                             float* grad_logits, float* grad_log_sigma_rows, float* grad_mu, float* grad_logvar,
-                            float* resp, void* workspace, float* loss_out, void* stream) {
+                            float* resp, int x_symmetric, void* workspace, float* loss_out, void* stream) {
     MV_REQUIRE(B >= 0 && L >= 0, E_ARG, "mdnvae_mdn_outer_fwdbwd: bad size");
     MV_REQUIRE(N >= 1 && N <= MO_NP - 1, E_SHAPE, "mdnvae_mdn_outer_fwdbwd: N = %d outside 1..%d", N, MO_NP - 1);
     MV_REQUIRE(K >= 1 && K <= MDN_MAXK, E_SHAPE, "mdnvae_mdn_outer_fwdbwd: %d components (1..%d supported)", K,
@@ -492,14 +561,21 @@ int mdnvae_mdn_outer_fwdbwd(const float* nodes, const float* x, const float* gat
         MV_REQUIRE((grad_mu == nullptr) == (grad_logvar == nullptr), E_ARG,
                    "mdnvae_mdn_outer_fwdbwd: grad_mu and grad_logvar come together");
 #define CALL(KK)                                                                                                     \
-    hipLaunchKernelGGL((mdn_outer_kernel<KK>), dim3(mdn_outer_grid(B)), dim3(MDN_NT), 0, st, nodes, x, gate_logits,  \
-                       log_sigma, B, N, mu, logvar, L, grad_nodes, grad_logits, grad_log_sigma_rows, grad_mu,        \
-                       grad_logvar, resp, (double*)workspace)
+    if (x_symmetric)                                                                                                 \
+        hipLaunchKernelGGL((mdn_outer_kernel<KK, true>),                                                             \
+                           dim3(mdn_outer_grid(B)),                                                                  \
+                           dim3(MDN_NT), 0, st, nodes, x, gate_logits, log_sigma, B, N, mu, logvar, L, grad_nodes,   \
+                           grad_logits, grad_log_sigma_rows, grad_mu, grad_logvar, resp, (double*)workspace);        \
+    else                                                                                                             \
+        hipLaunchKernelGGL((mdn_outer_kernel<KK, false>),                                                            \
+                           dim3(mdn_outer_grid(B)),                                                                  \
+                           dim3(MDN_NT), 0, st, nodes, x, gate_logits, log_sigma, B, N, mu, logvar, L, grad_nodes,   \
+                           grad_logits, grad_log_sigma_rows, grad_mu, grad_logvar, resp, (double*)workspace)
         MV_MDN_DISPATCH(K, CALL)
 #undef CALL
         MV_LAUNCH_CHECK("mdn_outer_kernel");
     }
-    hipLaunchKernelGGL(mdn_finalize_kernel, dim3(1), dim3(256), 0, st, (const double*)workspace, B, loss_out);
+    hipLaunchKernelGGL(mdn_finalize_kernel, dim3(1), dim3(PAIR_NT), 0, st, (const double*)workspace, B, loss_out);
     MV_LAUNCH_CHECK("mdn_finalize_kernel");
     return 0;
 }

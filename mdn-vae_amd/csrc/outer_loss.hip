@@ -38,18 +38,75 @@ __device__ __forceinline__ void ol_term(float s, float x, float& value, float& s
     }
 }
 
+// ---- the sweep over a symmetric x[b] ----
+// s and the slope e are then symmetric as well, the row sums equal the column sums the lanes hold,
+// and the pass needs no LDS and no cross-lane step.  Lane l owns the adjacent columns 2l and 2l+1
+// (one 8-byte load per row) and reads through a buffer descriptor of the sample's N*N floats: a
+// lane whose columns do not exist carries an offset past the end, for which the hardware returns 0
+// without a branch; the row offset is a scalar.
+typedef unsigned ol_u2 __attribute__((ext_vector_type(2)));
+template <int MODE, int R, bool FULL>
+__device__ __forceinline__ void ol_sym_group(__amdgpu_buffer_rsrc_t rsrc, int off, int row_bytes, bool ok0, bool ok1,
+                                             int i0, int rows, const ol_v2 (&g)[R], ol_v2 (&v)[R], float& term) {
+    ol_u2 a[OL_ROWS];
+#pragma unroll
+    for (int q = 0; q < OL_ROWS; ++q)
+        if (FULL || q < rows) a[q] = __builtin_amdgcn_raw_buffer_load_b64(rsrc, off, (i0 + q) * row_bytes, 2 /* nt */);
+#pragma unroll
+    for (int q = 0; q < OL_ROWS; ++q) {
+        if (FULL || q < rows) {
+            ol_v2 gi2[R];
+            ol_v2 s{0.0f, 0.0f};
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                // i0 is a multiple of OL_ROWS (even): the row's parity is q's
+                const float gi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int((q & 1) ? g[r].y : g[r].x),
+                                                                         (i0 + q) >> 1));
+                gi2[r] = ol_v2{gi, gi};
+                s += gi2[r] * g[r];
+            }
+            float t0, e0, t1, e1;
+            ol_term<MODE>(s.x, __uint_as_float(a[q].x), t0, e0);
+            ol_term<MODE>(s.y, __uint_as_float(a[q].y), t1, e1);     // (an odd N: the pair's second column of
+            const ol_v2 e{ok0 ? e0 : 0.0f, ok1 ? e1 : 0.0f};         //  the last lane is discarded here)
+            term += (ok0 ? t0 : 0.0f) + (ok1 ? t1 : 0.0f);
+#pragma unroll
+            for (int r = 0; r < R; ++r) v[r] += e * gi2[r];
+        }
+    }
+}
 template <int MODE, int R>
+__device__ __forceinline__ void ol_sym_sweep(const float* X, int N, int lane, const ol_v2 (&g)[R], ol_v2 (&v)[R],
+                                             float& term) {
+    // the descriptor must be provably wave-uniform: X depends on the wave's index
+    const unsigned long addr = reinterpret_cast<unsigned long>(X);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)addr);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(addr >> 32));
+    void* base = reinterpret_cast<void*>(((unsigned long)hi << 32) | lo);
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(base, 0, N * N * 4, 0x00020000);
+    const bool ok0 = 2 * lane < N, ok1 = 2 * lane + 1 < N;
+    const int off = ok0 ? lane * 8 : 0x7ffffff0;
+    const int groups = N / OL_ROWS, tail = N - groups * OL_ROWS;
+    for (int gr = 0; gr < groups; ++gr)
+        ol_sym_group<MODE, R, true>(rsrc, off, N * 4, ok0, ok1, gr * OL_ROWS, OL_ROWS, g, v, term);
+    if (tail) ol_sym_group<MODE, R, false>(rsrc, off, N * 4, ok0, ok1, groups * OL_ROWS, tail, g, v, term);
+}
+
+// SYM: the caller vouches that every x[b] is symmetric (see ol_sym_sweep).
+template <int MODE, int R, bool SYM>
 __global__ __launch_bounds__(OL_NT) void outer_loss_kernel(const float* __restrict__ nodes, const float* __restrict__ x,
                                                            int B, int N, const float* __restrict__ mu,
                                                            const float* __restrict__ logvar, int L,
                                                            float* __restrict__ gnodes, float* __restrict__ gmu,
                                                            float* __restrict__ glogvar, double* __restrict__ per_sample) {
-    __shared__ __attribute__((aligned(16))) float lds[(OL_NT / 64) * ol_wave_floats(R)];
+    __shared__ __attribute__((aligned(16))) float lds[SYM ? 4 : (OL_NT / 64) * ol_wave_floats(R)];
     const int lane = threadIdx.x & 63;
     const int wave = blockIdx.x * (OL_NT / 64) + (threadIdx.x >> 6);
     const int nwaves = gridDim.x * (OL_NT / 64);
     const int D = N * N;
-    const bool c0 = lane < N, c1 = lane + 64 < N;
+    // columns of the lane's packed pair: (lane, lane + 64), or (2 lane, 2 lane + 1) in the SYM sweep
+    const int col0 = SYM ? 2 * lane : lane, col1 = SYM ? 2 * lane + 1 : lane + 64;
+    const bool c0 = col0 < N, c1 = col1 < N;
     float* tile = lds + (threadIdx.x >> 6) * ol_wave_floats(R);    // [R * OL_ROWS][OL_LD]
     float* utab = tile + R * OL_ROWS * OL_LD;                       // [R][OL_NP]
     for (int b = wave; b < B; b += nwaves) {
@@ -58,12 +115,13 @@ __global__ __launch_bounds__(OL_NT) void outer_loss_kernel(const float* __restri
         ol_v2 g[R], v[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            g[r].x = c0 ? gv[r * OL_NP + lane] : 0.0f;
-            g[r].y = c1 ? gv[r * OL_NP + lane + 64] : 0.0f;
+            g[r].x = c0 ? gv[r * OL_NP + col0] : 0.0f;
+            g[r].y = c1 ? gv[r * OL_NP + col1] : 0.0f;
             v[r] = ol_v2{0.0f, 0.0f};
         }
         float term = 0.0f;
-        for (int i0 = 0; i0 < N; i0 += OL_ROWS) {
+        if constexpr (SYM) ol_sym_sweep<MODE, R>(X, N, lane, g, v, term);
+        for (int i0 = 0; !SYM && i0 < N; i0 += OL_ROWS) {
             ol_v2 a[OL_ROWS];
 #pragma unroll
             for (int q = 0; q < OL_ROWS; ++q) {
@@ -136,46 +194,40 @@ __global__ __launch_bounds__(OL_NT) void outer_loss_kernel(const float* __restri
         float* dst = gnodes + (long)b * R * OL_NP;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            const float u0 = c0 ? utab[r * OL_NP + lane] : 0.0f;
-            const float u1 = c1 ? utab[r * OL_NP + lane + 64] : 0.0f;
-            dst[r * OL_NP + lane] = c0 ? u0 + v[r].x : 0.0f;
-            if (lane + 64 < OL_NP) dst[r * OL_NP + lane + 64] = c1 ? u1 + v[r].y : 0.0f;
+            const float u0 = SYM ? v[r].x : (c0 ? utab[r * OL_NP + lane] : 0.0f);
+            const float u1 = SYM ? v[r].y : (c1 ? utab[r * OL_NP + lane + 64] : 0.0f);
+            if (col0 < OL_NP) dst[r * OL_NP + col0] = c0 ? u0 + v[r].x : 0.0f;
+            if (col1 < OL_NP) dst[r * OL_NP + col1] = c1 ? u1 + v[r].y : 0.0f;
         }
     }
 }
 
 // out[0] = recon term + KL, out[1] = recon term, out[2] = KL (fixed summation order)
-__global__ __launch_bounds__(256) void outer_loss_finalize_kernel(const double* __restrict__ per_sample, int B,
+__global__ __launch_bounds__(PAIR_NT) void outer_loss_finalize_kernel(const double* __restrict__ per_sample, int B,
                                                                   float* __restrict__ out) {
-    __shared__ double red[4];
-    double a = 0.0, k = 0.0;
-    for (int i = threadIdx.x; i < B; i += 256) {
-        a += per_sample[2 * i];
-        k += per_sample[2 * i + 1];
-    }
-    a = block_sum<256, double>(a, red);
-    k = block_sum<256, double>(k, red);
+    __shared__ double red[PAIR_NT / 64];
+    const PairSum t = block_pair_sum(per_sample, B, red);
     if (threadIdx.x == 0) {
-        out[0] = (float)(a + k);
-        out[1] = (float)a;
-        out[2] = (float)k;
+        out[0] = (float)(t.a + t.k);
+        out[1] = (float)t.a;
+        out[2] = (float)t.k;
     }
 }
 
-template <int MODE>
+template <int MODE, bool SYM>
 static void launch_outer_loss(int R, unsigned grid, hipStream_t st, const float* nodes, const float* x, int B, int N,
                               const float* mu, const float* logvar, int L, float* gnodes, float* gmu, float* glv,
                               double* per_sample) {
 #define MV_OL_CASE(RR)                                                                                              \
     case RR:                                                                                                        \
-        hipLaunchKernelGGL((outer_loss_kernel<MODE, RR>), dim3(grid), dim3(OL_NT), 0, st, nodes, x, B, N, mu, logvar, L, \
-                           gnodes, gmu, glv, per_sample);                                                           \
+        hipLaunchKernelGGL((outer_loss_kernel<MODE, RR, SYM>), dim3(grid), dim3(OL_NT), 0, st, nodes, x, B, N, mu, logvar, \
+                           L, gnodes, gmu, glv, per_sample);                                                        \
         break;
     switch (R) {
         MV_OL_CASE(1) MV_OL_CASE(2) MV_OL_CASE(3) MV_OL_CASE(4) MV_OL_CASE(5) MV_OL_CASE(6) MV_OL_CASE(7)
         default:
-            hipLaunchKernelGGL((outer_loss_kernel<MODE, 8>), dim3(grid), dim3(OL_NT), 0, st, nodes, x, B, N, mu, logvar, L,
-                               gnodes, gmu, glv, per_sample);
+            hipLaunchKernelGGL((outer_loss_kernel<MODE, 8, SYM>), dim3(grid), dim3(OL_NT), 0, st, nodes, x, B, N, mu, logvar,
+                               L, gnodes, gmu, glv, per_sample);
     }
 #undef MV_OL_CASE
 }
@@ -189,7 +241,7 @@ size_t mdnvae_outer_loss_workspace_bytes(int B) { return sizeof(double) * 2 * (s
 
 int mdnvae_outer_loss_fwdbwd(int mode, const float* nodes, const float* x, int B, int R, int N, const float* mu,
                              const float* logvar, int L, float* grad_nodes, float* grad_mu, float* grad_logvar,
-                             void* workspace, float* loss_out, void* stream) {
+                             int x_symmetric, void* workspace, float* loss_out, void* stream) {
     MV_REQUIRE(mode >= 0 && mode <= MDNVAE_RECON_MSE, E_ARG, "mdnvae_outer_loss_fwdbwd: unknown reconstruction mode %d", mode);
     MV_REQUIRE(B >= 0 && L >= 0, E_ARG, "mdnvae_outer_loss_fwdbwd: bad size");
     MV_REQUIRE(N >= 1 && N <= OL_NP - 1, E_SHAPE, "mdnvae_outer_loss_fwdbwd: N = %d outside 1..%d", N, OL_NP - 1);
@@ -204,18 +256,18 @@ int mdnvae_outer_loss_fwdbwd(int mode, const float* nodes, const float* x, int B
         const int blocks = (B + OL_NT / 64 - 1) / (OL_NT / 64);
         const unsigned grid = (unsigned)(blocks < 2048 ? blocks : 2048);
         double* ps = (double*)workspace;
-        if (mode == MDNVAE_RECON_POISSON_RATE)
-            launch_outer_loss<MDNVAE_RECON_POISSON_RATE>(R, grid, st, nodes, x, B, N, mu, logvar, L, grad_nodes, grad_mu,
-                                                         grad_logvar, ps);
-        else if (mode == MDNVAE_RECON_POISSON_LOG)
-            launch_outer_loss<MDNVAE_RECON_POISSON_LOG>(R, grid, st, nodes, x, B, N, mu, logvar, L, grad_nodes, grad_mu,
-                                                        grad_logvar, ps);
-        else
-            launch_outer_loss<MDNVAE_RECON_MSE>(R, grid, st, nodes, x, B, N, mu, logvar, L, grad_nodes, grad_mu,
-                                                grad_logvar, ps);
+#define MV_OL_MODE(MM)                                                                                          \
+    if (x_symmetric)                                                                                            \
+        launch_outer_loss<MM, true>(R, grid, st, nodes, x, B, N, mu, logvar, L, grad_nodes, grad_mu, grad_logvar, ps); \
+    else                                                                                                        \
+        launch_outer_loss<MM, false>(R, grid, st, nodes, x, B, N, mu, logvar, L, grad_nodes, grad_mu, grad_logvar, ps)
+        if (mode == MDNVAE_RECON_POISSON_RATE) { MV_OL_MODE(MDNVAE_RECON_POISSON_RATE); }
+        else if (mode == MDNVAE_RECON_POISSON_LOG) { MV_OL_MODE(MDNVAE_RECON_POISSON_LOG); }
+        else { MV_OL_MODE(MDNVAE_RECON_MSE); }
+#undef MV_OL_MODE
         MV_LAUNCH_CHECK("outer_loss_kernel");
     }
-    hipLaunchKernelGGL(outer_loss_finalize_kernel, dim3(1), dim3(256), 0, st, (const double*)workspace, B, loss_out);
+    hipLaunchKernelGGL(outer_loss_finalize_kernel, dim3(1), dim3(PAIR_NT), 0, st, (const double*)workspace, B, loss_out);
     MV_LAUNCH_CHECK("outer_loss_finalize_kernel");
     return 0;
 }

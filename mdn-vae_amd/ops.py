@@ -850,10 +850,12 @@ def mdn_loss(comp_mean, x, gate_logits, log_sigma, mu, logvar):
     return mdn_loss_terms(comp_mean, x, gate_logits, log_sigma, mu, logvar)[0]
 
 
-def outer_sum_loss_and_grads(nodes, x, mu, logvar, mode, n_nodes):
+def outer_sum_loss_and_grads(nodes, x, mu, logvar, mode, n_nodes, symmetric_x=False):
     """Reconstruction loss + KL for recon = sum_r g_r g_r^T given by node vectors nodes [B,R,NP]
     (chain decoder with nodes_only; no activation or intercept on the sum), and the gradients of
-    the total (upstream 1), from one pass over x: (terms[3], g_nodes, g_mu, g_logvar)."""
+    the total (upstream 1), from one pass over x: (terms[3], g_nodes, g_mu, g_logvar).
+    `symmetric_x`: the caller vouches that every x[b] is a symmetric matrix (tri_pack has checked
+    this very buffer, say); with input that is not, the node-vector gradient is wrong."""
     nodes, x, mu, logvar = (_c(t.detach()) for t in (nodes, x, mu, logvar))
     if nodes.dim() != 3 or nodes.shape[2] != DEC_NP:
         raise RuntimeError(f"outer-sum loss: nodes {tuple(nodes.shape)} must be [B,R,{DEC_NP}]")
@@ -866,11 +868,12 @@ def outer_sum_loss_and_grads(nodes, x, mu, logvar, mode, n_nodes):
     gmu, glv = torch.empty_like(mu), torch.empty_like(mu)
     ws = torch.empty(_lib.load().mdnvae_outer_loss_workspace_bytes(B), dtype=torch.uint8, device=dev)
     call("mdnvae_outer_loss_fwdbwd", RECON_MODES[mode], ptr(nodes, "nodes"), ptr(x, "x"), B, R, n_nodes, ptr(mu, "mu"),
-         ptr(logvar, "logvar"), mu.shape[1], ptr(gnodes), ptr(gmu), ptr(glv), ws.data_ptr(), ptr(out), stream())
+         ptr(logvar, "logvar"), mu.shape[1], ptr(gnodes), ptr(gmu), ptr(glv), int(bool(symmetric_x)), ws.data_ptr(),
+         ptr(out), stream())
     return out, gnodes, gmu, glv
 
 
-def _mdn_outer_call(nodes, x, logits, log_sigma, mu, logvar, n_nodes):
+def _mdn_outer_call(nodes, x, logits, log_sigma, mu, logvar, n_nodes, symmetric_x=False):
     nodes, x, logits, log_sigma, mu, logvar = (_c(t) for t in (nodes, x, logits, log_sigma, mu, logvar))
     if nodes.dim() != 3 or nodes.shape[2] != DEC_NP:
         raise RuntimeError(f"mdn outer loss: nodes {tuple(nodes.shape)} must be [B,K,{DEC_NP}]")
@@ -887,25 +890,30 @@ def _mdn_outer_call(nodes, x, logits, log_sigma, mu, logvar, n_nodes):
     ws = torch.empty(_lib.load().mdnvae_mdn_workspace_bytes(B), dtype=torch.uint8, device=dev)
     call("mdnvae_mdn_outer_fwdbwd", ptr(nodes, "nodes"), ptr(x, "x"), ptr(logits, "gate_logits"),
          ptr(log_sigma, "log_sigma"), B, K, n_nodes, ptr(mu, "mu"), ptr(logvar, "logvar"), mu.shape[1], ptr(gnodes),
-         ptr(glogits), ptr(gls_rows), ptr(gmu), ptr(glv), ptr(resp), ws.data_ptr(), ptr(out), stream())
+         ptr(glogits), ptr(gls_rows), ptr(gmu), ptr(glv), ptr(resp), int(bool(symmetric_x)), ws.data_ptr(), ptr(out),
+         stream())
     gls = _colsum(gls_rows) if B > 0 else torch.zeros_like(log_sigma)
     return out, gnodes, glogits, gls, gmu, glv, resp
 
 
-def mdn_outer_loss_and_grads(nodes, x, gate_logits, log_sigma, mu, logvar, n_nodes):
+def mdn_outer_loss_and_grads(nodes, x, gate_logits, log_sigma, mu, logvar, n_nodes, symmetric_x=False):
     """The mixture likelihood + KL for component means g_k g_k^T given by their node vectors
     nodes [B,K,NP] (chain decoder with nodes_only), and the gradients of the total (upstream 1),
-    from one pass over x: (terms[3], g_nodes, g_logits, g_log_sigma, g_mu, g_logvar)."""
+    from one pass over x: (terms[3], g_nodes, g_logits, g_log_sigma, g_mu, g_logvar).
+    `symmetric_x`: the caller vouches that every x[b] is a symmetric matrix (tri_pack has checked
+    this very buffer, say); the pass is then a plain stream over x.  With input that is not, the
+    node-vector gradient is wrong."""
     with torch.no_grad():
-        return _mdn_outer_call(nodes, x, gate_logits, log_sigma, mu, logvar, n_nodes)[:6]
+        return _mdn_outer_call(nodes, x, gate_logits, log_sigma, mu, logvar, n_nodes, symmetric_x)[:6]
 
 
 class _MdnOuterLoss(torch.autograd.Function):
     """Differentiable form of the above: the pass runs in forward, backward scales what it saved."""
 
     @staticmethod
-    def forward(ctx, nodes, x, logits, log_sigma, mu, logvar, n_nodes):
-        out, gnodes, glogits, gls, gmu, glv, _ = _mdn_outer_call(nodes, x, logits, log_sigma, mu, logvar, n_nodes)
+    def forward(ctx, nodes, x, logits, log_sigma, mu, logvar, n_nodes, symmetric_x):
+        out, gnodes, glogits, gls, gmu, glv, _ = _mdn_outer_call(nodes, x, logits, log_sigma, mu, logvar, n_nodes,
+                                                                 symmetric_x)
         ctx.save_for_backward(gnodes, glogits, gls, gmu, glv)
         return out
 
@@ -913,11 +921,11 @@ class _MdnOuterLoss(torch.autograd.Function):
     def backward(ctx, gout):
         gnodes, glogits, gls, gmu, glv = ctx.saved_tensors
         g_nll, g_kl = gout[0] + gout[1], gout[0] + gout[2]
-        return gnodes * g_nll, None, glogits * g_nll, gls * g_nll, gmu * g_kl, glv * g_kl, None
+        return gnodes * g_nll, None, glogits * g_nll, gls * g_nll, gmu * g_kl, glv * g_kl, None, None
 
 
-def mdn_outer_loss_terms(nodes, x, gate_logits, log_sigma, mu, logvar, n_nodes):
-    out = _MdnOuterLoss.apply(nodes, x, gate_logits, log_sigma, mu, logvar, n_nodes)
+def mdn_outer_loss_terms(nodes, x, gate_logits, log_sigma, mu, logvar, n_nodes, symmetric_x=False):
+    out = _MdnOuterLoss.apply(nodes, x, gate_logits, log_sigma, mu, logvar, n_nodes, symmetric_x)
     return out[0], out[1], out[2]
 
 

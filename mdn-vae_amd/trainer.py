@@ -72,6 +72,11 @@ def allreduce_sum(flat, group=None, bucket_floats=8 << 20):
         w.wait()
 
 
+def _same_buffer(a, b):
+    return isinstance(a, torch.Tensor) and isinstance(b, torch.Tensor) and a.data_ptr() == b.data_ptr() \
+        and a.numel() == b.numel() and a.is_contiguous() and b.is_contiguous()
+
+
 def _distributed(group=None):
     return dist.is_available() and dist.is_initialized() and dist.get_world_size(group) >= MIN_RANKS_FOR_EXCHANGE
 
@@ -166,9 +171,12 @@ class Trainer:
             # the target, straight from the decoder's node vectors
             m = self.model
             nodes, gate_logits, mu, logvar = m(*inputs, eps=eps, nodes_only=True)
+            # a target that is the very input buffer of a symmetric-input model has had its symmetry
+            # checked by the encoder's packing pass: the likelihood can then stream it
             terms, g_nodes, g_logits, g_ls, g_mu, g_lv = ops.mdn_outer_loss_and_grads(
                 nodes.detach(), target.reshape(target.shape[0], -1), gate_logits.detach(), m.log_sigma.detach(),
-                mu.detach(), logvar.detach(), m.n_nodes)
+                mu.detach(), logvar.detach(), m.n_nodes,
+                symmetric_x=bool(getattr(m, "symmetric_input", False)) and _same_buffer(target, inputs[0]))
             torch.autograd.backward([nodes, gate_logits, mu, logvar, m.log_sigma], [g_nodes, g_logits, g_mu, g_lv, g_ls])
             return terms[0]
         if self.fused_loss and self.loss_mode in ops.RECON_MODES and getattr(self.model, "rank_one_sum_decoder", False):
@@ -177,7 +185,8 @@ class Trainer:
             m = self.model
             nodes, mu, logvar = m(*inputs, eps=eps, nodes_only=True)
             terms, g_nodes, g_mu, g_lv = ops.outer_sum_loss_and_grads(
-                nodes, target.reshape(target.shape[0], -1), mu, logvar, self.loss_mode, m.n_nodes)
+                nodes, target.reshape(target.shape[0], -1), mu, logvar, self.loss_mode, m.n_nodes,
+                symmetric_x=bool(getattr(m, "symmetric_input", False)) and _same_buffer(target, inputs[0]))
             torch.autograd.backward([nodes, mu, logvar], [g_nodes, g_mu, g_lv])
             return terms[0]
         out = self.model(*inputs, eps=eps)
@@ -232,7 +241,8 @@ class Trainer:
             raise ValueError("Trainer.capture: eps must be given (the graph cannot draw fresh noise itself)")
         dev = self.buf.flat_p.device
         self._g_inputs = tuple(t.detach().clone() if isinstance(t, torch.Tensor) else t for t in inputs)
-        self._g_target = target.detach().clone()
+        # an autoencoding target (the input buffer itself) stays the input buffer in the graph
+        self._g_target = self._g_inputs[0] if _same_buffer(target, inputs[0]) else target.detach().clone()
         self._g_eps = eps.detach().clone()
         self._g_step = torch.zeros(1, dtype=torch.int32, device=dev)
         self._g_coef = torch.zeros(2, dtype=torch.float32, device=dev)
@@ -265,7 +275,8 @@ class Trainer:
         for dst, src in zip(self._g_inputs, inputs):
             if isinstance(dst, torch.Tensor):
                 dst.copy_(src)
-        self._g_target.copy_(target)
+        if self._g_target is not self._g_inputs[0]:
+            self._g_target.copy_(target)
         self._g_eps.copy_(eps)
         self._graph.replay()
         self.steps += 1

@@ -219,6 +219,61 @@ def test_outer_sum_loss_from_node_vectors_against_oracle(mode, B, Rch, n, L):
     assert float(g_nodes[:, :, n:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("mode", ["poisson_log", "mse", "poisson_rate"])
+@pytest.mark.parametrize("B,Rch,n,L", [(6, 5, 87, 68), (5, 5, 68, 68), (3, 1, 5, 2), (4, 8, 95, 7), (2, 3, 64, 4), (0, 5, 9, 3)])
+def test_outer_sum_loss_on_symmetric_targets_against_oracle(mode, B, Rch, n, L):
+    """symmetric_x=True (no row sums) against the float64 oracle and against the general form on
+    the same symmetric target."""
+    torch.manual_seed(3 * B + n)
+    nodes = torch.zeros(B, Rch, 96)
+    nodes[:, :, :n] = torch.rand(B, Rch, n) * 0.5 + 0.1
+    x = torch.rand(B, n, n)
+    x = (x + x.transpose(1, 2)).reshape(B, n * n).contiguous()
+    mu, lv = torch.randn(B, L) * 0.3, torch.randn(B, L) * 0.2
+    dev = [t.to(DEV) for t in (nodes, x, mu, lv)]
+    sym = M.ops.outer_sum_loss_and_grads(*dev, mode, n, symmetric_x=True)
+    gen = M.ops.outer_sum_loss_and_grads(*dev, mode, n)
+    if B == 0:
+        assert sym[0].tolist() == [0.0, 0.0, 0.0]
+        return
+    leaves = [t.double().requires_grad_(True) for t in (nodes, mu, lv)]
+    g = leaves[0][:, :, :n]
+    recon = (g.unsqueeze(3) * g.unsqueeze(2)).sum(dim=1).reshape(B, n * n)
+    want = R.vae_loss(recon, x.double(), leaves[1], leaves[2], mode)
+    want.backward()
+    assert abs(sym[0][0].item() - want.item()) <= 1e-5 * abs(want.item())
+    assert abs(sym[0][0].item() - gen[0][0].item()) <= 1e-6 * abs(want.item())
+    for got, other, leaf, name in zip(sym[1:], gen[1:], leaves, ("nodes", "mu", "logvar")):
+        assert _rel(got, leaf.grad) <= 1e-4, name
+        assert _rel(got, other) <= 1e-5, name
+    assert float(sym[1][:, :, n:].abs().max()) == 0.0
+
+
+def test_mm_gate_trainer_streams_a_target_that_is_the_verified_symmetric_input(monkeypatch):
+    """symmetric_input=True and target = the input buffer: the fused step takes the form without
+    row sums; a separate target tensor keeps the general form; both give the same gradients."""
+    fix = load_fixture("mm_gate")
+    params = fixture_params(fix)
+    x = torch.from_numpy(fix["x"]).reshape(-1, 68, 68)
+    x = (0.5 * (x + x.transpose(1, 2))).reshape(-1, 68 * 68).contiguous().to(DEV)
+    eps = torch.from_numpy(fix["eps"]).to(DEV)
+    adjacency = [list(map(int, row)) for row in fix["adjacency"]]
+    seen = []
+    inner = M.ops.outer_sum_loss_and_grads
+    monkeypatch.setattr(M.ops, "outer_sum_loss_and_grads",
+                        lambda *a, **kw: (seen.append(kw.get("symmetric_x")), inner(*a, **kw))[1])
+    got = []
+    for target in (x, x.clone()):
+        model = _load(M.GCNVAE(R=5, n_nodes=68, k=32, n_layers=3, latent_dim=68, symmetric_input=True), params)
+        trainer = M.Trainer(model, "poisson_log")
+        loss = trainer.forward_backward((x, adjacency), target, eps=eps)
+        model.check_inputs()
+        got.append((loss.item(), trainer.buf.flat_g.clone()))
+    assert seen == [True, False]
+    assert abs(got[0][0] - got[1][0]) <= 1e-6 * abs(got[1][0])
+    assert _rel(got[0][1], got[1][1]) <= 1e-5
+
+
 def test_mm_gate_trainer_fused_and_plain_steps_agree():
     """Trainer on the GCN-decoder VAE of function/MM_Gate.py: the step that takes loss and gradients
     from the node vectors and the step through the materialised reconstruction agree, and both match

@@ -128,6 +128,35 @@ def test_rank_one_mixture_from_node_vectors_against_oracle(B, K, n, L):
     assert float(g_nodes[:, :, n:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("B,K,n,L", [(6, 5, 87, 68), (5, 5, 68, 68), (3, 1, 5, 2), (4, 8, 95, 7), (2, 3, 64, 4), (0, 5, 9, 3)])
+def test_rank_one_mixture_on_symmetric_targets_against_oracle(B, K, n, L):
+    """symmetric_x=True (the streaming form, no row sums) against the float64 oracle and against
+    the general form on the same symmetric target."""
+    torch.manual_seed(7 * B + n)
+    nodes = torch.zeros(B, K, 96)
+    nodes[:, :, :n] = torch.rand(B, K, n) * 0.8 + 0.1
+    x = torch.rand(B, n, n)
+    x = (x + x.transpose(1, 2)).reshape(B, n * n).contiguous()
+    logits = torch.randn(B, K)
+    ls = torch.randn(K) * 0.2 + 1.5
+    mu, lv = torch.randn(B, L) * 0.3, torch.randn(B, L) * 0.2
+    dev = [t.to(DEV) for t in (nodes, x, logits, ls, mu, lv)]
+    sym = M.ops.mdn_outer_loss_and_grads(*dev, n, symmetric_x=True)
+    gen = M.ops.mdn_outer_loss_and_grads(*dev, n)
+    if B == 0:
+        assert sym[0].tolist() == [0.0, 0.0, 0.0]
+        return
+    leaves = [t.double().requires_grad_(True) for t in (nodes, logits, ls, mu, lv)]
+    want = _outer_oracle(leaves[0], x.double(), leaves[1], leaves[2], leaves[3], leaves[4], n)
+    want.backward()
+    assert abs(sym[0][0].item() - want.item()) <= 1e-5 * abs(want.item())
+    assert torch.equal(sym[0], gen[0])                       # the likelihood sums are the same operations
+    for got, other, leaf, name in zip(sym[1:], gen[1:], leaves, ("nodes", "logits", "log_sigma", "mu", "logvar")):
+        assert _rel(got, leaf.grad) <= 1e-4, name
+        assert _rel(got, other) <= 1e-5, name
+    assert float(sym[1][:, :, n:].abs().max()) == 0.0
+
+
 def test_rank_one_mixture_matches_the_materialised_path_and_scales_with_upstream():
     torch.manual_seed(3)
     B, K, n, L = 7, 5, 68, 68
@@ -173,3 +202,31 @@ def test_mdn_trainer_fused_and_materialised_steps_agree():
         got[fused] = (loss.item(), trainer.buf.flat_g.clone())
     assert abs(got[True][0] - got[False][0]) <= 1e-5 * abs(got[False][0])
     assert _rel(got[True][1], got[False][1]) <= 1e-4
+
+
+def test_mdn_trainer_streams_a_target_that_is_the_verified_symmetric_input(monkeypatch):
+    """symmetric_input=True and target = the input buffer: the step takes the streaming likelihood
+    (the encoder's packing pass has checked that buffer) and gives the gradients of the general
+    step; a separate target tensor keeps the general form."""
+    fix = load_fixture("mm_gate")
+    params = fixture_params(fix)
+    x = torch.from_numpy(fix["x"]).reshape(-1, 68, 68)
+    x = (0.5 * (x + x.transpose(1, 2))).reshape(-1, 68 * 68).contiguous().to(DEV)
+    eps = torch.from_numpy(fix["eps"]).to(DEV)
+    traits = torch.randn(x.shape[0], 4, generator=torch.Generator().manual_seed(1)).to(DEV)
+    adjacency = [list(map(int, r)) for r in fix["adjacency"]]
+    seen = []
+    inner = M.ops._mdn_outer_call
+    monkeypatch.setattr(M.ops, "_mdn_outer_call", lambda *a: (seen.append(a[-1]), inner(*a))[1])
+    got = []
+    for target in (x, x.clone()):
+        torch.manual_seed(5)
+        model = M.MDNGateVAE(R=5, n_nodes=68, k=32, n_layers=3, latent_dim=68, n_traits=4, symmetric_input=True)
+        model.load_state_dict(params, strict=False)
+        trainer = M.Trainer(model.to(DEV), "mdn")
+        loss = trainer.forward_backward((x, adjacency, traits), target, eps=eps)
+        model.check_inputs()
+        got.append((loss.item(), trainer.buf.flat_g.clone()))
+    assert seen == [True, False]
+    assert abs(got[0][0] - got[1][0]) <= 1e-6 * abs(got[1][0])
+    assert _rel(got[0][1], got[1][1]) <= 1e-5
