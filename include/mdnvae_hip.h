@@ -183,6 +183,17 @@ int mdnvae_bias_act(float* y, const float* bias, long rows, int cols, int act, v
 int mdnvae_add_act(const float* a, const float* b, float* y, long n, int act, void* stream);
 /* grad_pre = grad_y * act'(.) expressed through the activation output y. */
 int mdnvae_act_bwd(const float* y, const float* grad_y, float* grad_pre, long n, int act, void* stream);
+/* Narrow dense layer, at most 8 inputs and 8 outputs (the gate of the trait-gated mixture head, a few
+ * traits -> K logits; BUILD-DEFINED layer, the arithmetic is nn.Linear's): y [B,N] = act(x [B,M] .
+ * w[N,M]^T + bias) in one kernel, and grad_w [N,M] = grad_pre^T . x with grad_b [N] (or NULL) = column
+ * sums of grad_pre in two, the workgroups' partial sums added in index order; accumulate != 0 adds to
+ * grad_w / grad_b.  workspace: mdnvae_narrow_linear_workspace_floats() floats. */
+int mdnvae_narrow_linear_fwd(const float* x, const float* w, const float* bias, long B, int N, int M, int act, float* y,
+                             void* stream);
+size_t mdnvae_narrow_linear_workspace_floats(void);
+int mdnvae_narrow_linear_wgrad(const float* grad_pre, const float* x, long B, int N, int M, float* workspace,
+                               float* grad_w, float* grad_b, int accumulate, void* stream);
+
 /* out[e] = sum_b a[b,e], fixed summation order (bias gradients); accumulate != 0: out[e] += the sum. */
 size_t mdnvae_colsum_workspace_floats(int B, int D);
 int mdnvae_colsum(const float* a, int B, int D, float* workspace, float* out, int accumulate, void* stream);

@@ -87,6 +87,95 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restri
     if (g == 0 && c < D) out[c] = accumulate ? out[c] + s : s;
 }
 
+// ---- narrow dense layers: at most NL_MAX inputs and NL_MAX outputs ----
+// (the gate of the trait-gated mixture head: a handful of traits -> K logits.)  A library GEMM
+// spends 150 us on the [5 x 4] weight gradient of such a layer over a batch of 16384 - its tiles
+// are 16 wide at the least and the reduction runs over the batch in one workgroup column.  Here a
+// thread takes samples, the whole weight lives in LDS (forward) or in registers as accumulators
+// (weight gradient), and the partial gradients of the workgroups are added in index order.
+constexpr int NL_MAX = 8, NL_BLOCKS = 64, NL_VALS = NL_MAX * NL_MAX + NL_MAX;
+
+__global__ __launch_bounds__(256) void narrow_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, long B, int N, int M, int act,
+                                                         float* __restrict__ y) {
+    __shared__ float ws[NL_VALS];                  // w [N][M] then the bias at NL_MAX*NL_MAX
+    if (threadIdx.x < N * M) ws[threadIdx.x] = w[threadIdx.x];
+    if (threadIdx.x < N) ws[NL_MAX * NL_MAX + threadIdx.x] = bias ? bias[threadIdx.x] : 0.0f;
+    __syncthreads();
+    for (long b = (long)blockIdx.x * 256 + threadIdx.x; b < B; b += (long)gridDim.x * 256) {
+        float xv[NL_MAX];
+#pragma unroll
+        for (int m = 0; m < NL_MAX; ++m) xv[m] = m < M ? x[b * M + m] : 0.0f;
+#pragma unroll
+        for (int n = 0; n < NL_MAX; ++n) {
+            if (n < N) {
+                float sum = ws[NL_MAX * NL_MAX + n];
+#pragma unroll
+                for (int m = 0; m < NL_MAX; ++m)
+                    if (m < M) sum = __builtin_fmaf(xv[m], ws[n * M + m], sum);
+                y[b * N + n] = dact(act, sum);
+            }
+        }
+    }
+}
+
+// part[block][n * NL_MAX + m] = sum over the block's samples of g[b][n] x[b][m]; [.. + 64 + n] = sum of g[b][n]
+__global__ __launch_bounds__(256) void narrow_wgrad_partial_kernel(const float* __restrict__ g, const float* __restrict__ x,
+                                                                   long B, int N, int M, float* __restrict__ part) {
+    __shared__ float sm[4][NL_VALS];
+    float acc[NL_MAX][NL_MAX], accb[NL_MAX];
+#pragma unroll
+    for (int n = 0; n < NL_MAX; ++n) {
+        accb[n] = 0.0f;
+#pragma unroll
+        for (int m = 0; m < NL_MAX; ++m) acc[n][m] = 0.0f;
+    }
+    for (long b = (long)blockIdx.x * 256 + threadIdx.x; b < B; b += (long)gridDim.x * 256) {
+        float gv[NL_MAX], xv[NL_MAX];
+#pragma unroll
+        for (int n = 0; n < NL_MAX; ++n) gv[n] = n < N ? g[b * N + n] : 0.0f;
+#pragma unroll
+        for (int m = 0; m < NL_MAX; ++m) xv[m] = m < M ? x[b * M + m] : 0.0f;
+#pragma unroll
+        for (int n = 0; n < NL_MAX; ++n) {
+            accb[n] += gv[n];
+#pragma unroll
+            for (int m = 0; m < NL_MAX; ++m) acc[n][m] = __builtin_fmaf(gv[n], xv[m], acc[n][m]);
+        }
+    }
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+    for (int n = 0; n < NL_MAX; ++n) {
+        const float sb = wave_sum(accb[n]);
+        if (lane == 0) sm[wid][NL_MAX * NL_MAX + n] = sb;
+#pragma unroll
+        for (int m = 0; m < NL_MAX; ++m) {
+            const float sw = wave_sum(acc[n][m]);
+            if (lane == 0) sm[wid][n * NL_MAX + m] = sw;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < NL_VALS)
+        part[(long)blockIdx.x * NL_VALS + threadIdx.x] =
+            (sm[0][threadIdx.x] + sm[1][threadIdx.x]) + (sm[2][threadIdx.x] + sm[3][threadIdx.x]);
+}
+
+__global__ __launch_bounds__(128) void narrow_wgrad_final_kernel(const float* __restrict__ part, int nparts, int N, int M,
+                                                                 int accumulate, float* __restrict__ gw,
+                                                                 float* __restrict__ gb) {
+    const int t = threadIdx.x;
+    if (t >= NL_VALS) return;
+    float sum = 0.0f;
+    for (int p = 0; p < nparts; ++p) sum += part[(long)p * NL_VALS + t];
+    if (t < NL_MAX * NL_MAX) {
+        const int n = t / NL_MAX, m = t - n * NL_MAX;
+        if (n < N && m < M) gw[n * M + m] = accumulate ? gw[n * M + m] + sum : sum;
+    } else if (gb) {
+        const int n = t - NL_MAX * NL_MAX;
+        if (n < N) gb[n] = accumulate ? gb[n] + sum : sum;
+    }
+}
+
 }  // namespace mdnvae
 using namespace mdnvae;
 
@@ -149,6 +238,42 @@ int mdnvae_colsum(const float* a, int B, int D, float* workspace, float* out, in
     hipLaunchKernelGGL(colsum_final_kernel, dim3(cols), dim3(256), 0, (hipStream_t)stream, workspace, nparts, D, accumulate,
                        out);
     MV_LAUNCH_CHECK("colsum_final_kernel");
+    return 0;
+}
+
+static int narrow_blocks(long B) {
+    const long g = (B + 255) / 256;
+    return (int)(g > NL_BLOCKS ? NL_BLOCKS : (g < 1 ? 1 : g));
+}
+
+int mdnvae_narrow_linear_fwd(const float* x, const float* w, const float* bias, long B, int N, int M, int act, float* y,
+                             void* stream) {
+    MV_REQUIRE(B >= 0, E_ARG, "mdnvae_narrow_linear_fwd: negative batch");
+    MV_REQUIRE(N >= 1 && N <= NL_MAX && M >= 1 && M <= NL_MAX, E_SHAPE,
+               "mdnvae_narrow_linear_fwd: a [%d x %d] weight is not narrow (both sides 1..%d)", N, M, NL_MAX);
+    MV_REQUIRE(act >= 0 && act <= MDNVAE_ACT_RELU, E_ARG, "mdnvae_narrow_linear_fwd: unknown activation %d", act);
+    if (B == 0) return 0;
+    MV_REQUIRE(x && w && y, E_ARG, "mdnvae_narrow_linear_fwd: null pointer");
+    hipLaunchKernelGGL(narrow_fwd_kernel, dim3(ew_grid(B)), dim3(256), 0, (hipStream_t)stream, x, w, bias, B, N, M, act, y);
+    MV_LAUNCH_CHECK("narrow_fwd_kernel");
+    return 0;
+}
+
+size_t mdnvae_narrow_linear_workspace_floats(void) { return (size_t)NL_BLOCKS * NL_VALS; }
+
+int mdnvae_narrow_linear_wgrad(const float* grad_pre, const float* x, long B, int N, int M, float* workspace, float* grad_w,
+                               float* grad_b, int accumulate, void* stream) {
+    MV_REQUIRE(B >= 1, E_ARG, "mdnvae_narrow_linear_wgrad: empty batch");
+    MV_REQUIRE(N >= 1 && N <= NL_MAX && M >= 1 && M <= NL_MAX, E_SHAPE,
+               "mdnvae_narrow_linear_wgrad: a [%d x %d] weight is not narrow (both sides 1..%d)", N, M, NL_MAX);
+    MV_REQUIRE(grad_pre && x && workspace && grad_w, E_ARG, "mdnvae_narrow_linear_wgrad: null pointer");
+    const int blocks = narrow_blocks(B);
+    hipLaunchKernelGGL(narrow_wgrad_partial_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, grad_pre, x, B, N, M,
+                       workspace);
+    MV_LAUNCH_CHECK("narrow_wgrad_partial_kernel");
+    hipLaunchKernelGGL(narrow_wgrad_final_kernel, dim3(1), dim3(128), 0, (hipStream_t)stream, workspace, blocks, N, M,
+                       accumulate, grad_w, grad_b);
+    MV_LAUNCH_CHECK("narrow_wgrad_final_kernel");
     return 0;
 }
 

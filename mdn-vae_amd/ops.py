@@ -197,6 +197,36 @@ def _linear_wgrad(gpre, x, into=None):
     return gw
 
 
+NARROW_MAX = 8
+
+
+def _narrow(weight):
+    """A layer at most 8 wide on both sides (the mixture gate): one HIP kernel each way instead of
+    a library GEMM whose smallest tile dwarfs the weight."""
+    return weight.shape[0] <= NARROW_MAX and weight.shape[1] <= NARROW_MAX
+
+
+def _narrow_wgrad(gpre, x, weight_param, bias_param, want_w, want_b):
+    """(gw, gb) of a narrow layer from one pass over the batch; None for what went straight into
+    the parameter's .grad (both or neither: the kernel has one accumulate switch)."""
+    B, N = gpre.shape
+    M = x.shape[1]
+    tw = _grad_target(weight_param) if want_w else None
+    tb = _grad_target(bias_param) if want_b else None
+    direct = (tw is not None) and (tb is not None or not want_b)
+    gw = tw if direct else torch.empty(N, M, dtype=torch.float32, device=x.device)
+    gb = (tb if direct else torch.empty(N, dtype=torch.float32, device=x.device)) if want_b else None
+    ws = torch.empty(_lib.workspace_bytes("mdnvae_narrow_linear_workspace_floats"), dtype=torch.float32, device=x.device)
+    call("mdnvae_narrow_linear_wgrad", ptr(gpre, "grad_pre"), ptr(x, "x"), B, N, M, ptr(ws), ptr(gw), ptr(gb),
+         int(direct), stream())
+    if direct:
+        _grad_added(weight_param)
+        if want_b:
+            _grad_added(bias_param)
+        return None, None
+    return (gw if want_w else None), gb
+
+
 class _LinearAct(torch.autograd.Function):
     """act(x @ W^T + b): the product is a rocBLAS GEMM, bias+activation and the backward's
     elementwise / column-sum parts are HIP kernels."""
@@ -205,8 +235,13 @@ class _LinearAct(torch.autograd.Function):
     def forward(ctx, x, weight, bias, act):
         x, weight = _c(x), _c(weight)
         ptr(x, "x"), ptr(weight, "weight")
-        y = _library_gemm(x, weight.t())
-        call("mdnvae_bias_act", ptr(y), ptr(bias, "bias"), y.shape[0], y.shape[1], act, stream())
+        if _narrow(weight) and x.dim() == 2:
+            y = torch.empty(x.shape[0], weight.shape[0], dtype=torch.float32, device=x.device)
+            call("mdnvae_narrow_linear_fwd", ptr(x), ptr(weight), ptr(bias, "bias"), x.shape[0], weight.shape[0],
+                 weight.shape[1], act, ptr(y), stream())
+        else:
+            y = _library_gemm(x, weight.t())
+            call("mdnvae_bias_act", ptr(y), ptr(bias, "bias"), y.shape[0], y.shape[1], act, stream())
         ctx.save_for_backward(x, weight, y)
         ctx.act = act
         ctx.has_bias = bias is not None
@@ -223,6 +258,10 @@ class _LinearAct(torch.autograd.Function):
         else:
             gpre = gy
         gx = _library_gemm(gpre, weight) if ctx.needs_input_grad[0] else None
+        if _narrow(weight) and x.shape[0] >= 1 and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]):
+            gw, gb = _narrow_wgrad(_c(gpre), x, ctx.params[0], ctx.params[1], ctx.needs_input_grad[1],
+                                   ctx.has_bias and ctx.needs_input_grad[2])
+            return gx, gw, gb, None
         gw = None
         if ctx.needs_input_grad[1]:
             if _small_wgrad_ok(x.shape[0], weight.shape[0], weight.shape[1]):

@@ -162,6 +162,45 @@ def test_small_layer_weight_gradient_kernel(B, N, M):
     assert torch.equal(got, again)
 
 
+@pytest.mark.parametrize("B,N,M,act", [(16384, 5, 4, None), (1000, 8, 8, "tanh"), (257, 1, 1, "relu"), (3, 2, 7, "sigmoid"),
+                                       (1, 5, 4, None)])
+def test_narrow_layer_against_float64(B, N, M, act):
+    """A layer at most 8 wide (the mixture gate, traits -> K logits): forward, weight, bias and
+    input gradients of the one-kernel path against float64 autograd; gradients also when added
+    straight into .grad."""
+    g = torch.Generator().manual_seed(B + N)
+    x = torch.randn(B, M, generator=g)
+    w = torch.randn(N, M, generator=g)
+    b = torch.randn(N, generator=g)
+    up = torch.randn(B, N, generator=g)
+    xd, wd, bd = (t.to(DEV).requires_grad_(True) for t in (x, w, b))
+    y = ops.linear_act(xd, wd, bd, act)
+    y.backward(up.to(DEV))
+    x64, w64, b64 = (t.double().requires_grad_(True) for t in (x, w, b))
+    pre = x64 @ w64.t() + b64
+    y64 = {None: pre, "tanh": torch.tanh(pre), "relu": torch.relu(pre), "sigmoid": torch.sigmoid(pre)}[act]
+    y64.backward(up.double())
+
+    def close(got, want):
+        return float((got.double().cpu() - want).abs().max()) <= 1e-5 * max(float(want.abs().max()), 1e-30)
+
+    assert close(y.detach(), y64.detach())
+    assert close(wd.grad, w64.grad) and close(bd.grad, b64.grad) and close(xd.grad, x64.grad)
+    # the sink path adds to what .grad holds
+    w2, b2 = (t.to(DEV).requires_grad_(True) for t in (w, b))
+    w2.grad, b2.grad = torch.ones_like(w2), torch.ones_like(b2)
+    with ops.accumulate_into_grads():
+        ops.linear_act(x.to(DEV), w2, b2, act).backward(up.to(DEV))
+    assert close(w2.grad - 1.0, w64.grad) and close(b2.grad - 1.0, b64.grad)
+    # no bias
+    w3 = w.to(DEV).requires_grad_(True)
+    ops.linear_act(x.to(DEV), w3, None, act).sum().backward()
+    w3_64 = w.double().requires_grad_(True)
+    pre = x.double() @ w3_64.t()
+    {None: pre, "tanh": torch.tanh(pre), "relu": torch.relu(pre), "sigmoid": torch.sigmoid(pre)}[act].sum().backward()
+    assert close(w3.grad, w3_64.grad)
+
+
 def test_captured_step_replays_the_eager_step():
     """Trainer.capture / replay: three replayed steps leave the same parameters and losses as three
     eager steps from the same start (same kernels, same order), and capture itself changes nothing."""
