@@ -404,6 +404,8 @@ def main():
     ap.add_argument("--graph", action="store_true", help="run the main workload's steps as replays of a captured HIP graph "
                                                           "(single GPU)")
     ap.add_argument("--no-n68", action="store_true", help="skip the short 68 x 68 run reported under 'n68' on one GPU")
+    ap.add_argument("--no-full-variant", action="store_true",
+                    help="skip the short run without the symmetric-input promise reported under 'full_first_layer'")
     ap.add_argument("--no-kernel-clock", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="all-reduce every gradient after backward")
     ap.add_argument("--full-first-layer", action="store_true",
@@ -480,6 +482,15 @@ def main():
         line["n68"] = {"workload": what68, "value": batch * steps68 / el68, "unit": "samples/s", "per_gpu_batch": batch,
                        "steps": steps68, "warmup": 2, "ms_per_step": el68 / steps68 * 1e3,
                        "final_loss_per_sample": loss68 / batch}
+    if world == 1 and not args.no_full_variant and not args.full_first_layer and args.model in ("mm_gate", "mdn_gate"):
+        # the same workload without the promise of symmetric inputs: first layers over all N*N entries,
+        # likelihood pass with row and column sums (what a model built with symmetric_input=False runs)
+        fsteps = max(2, min(args.steps, 4))
+        elf, lossf, _, _, whatf = run_workload(args.model, batch, args.nodes, fsteps, 2, args.pool, device, rank, world,
+                                               False, not args.no_overlap, False)
+        line["full_first_layer"] = {"workload": whatf, "value": batch * fsteps / elf, "unit": "samples/s",
+                                    "per_gpu_batch": batch, "steps": fsteps, "warmup": 2,
+                                    "ms_per_step": elf / fsteps * 1e3, "final_loss_per_sample": lossf / batch}
     if world == 1 and not args.no_script_batch and args.model in ("mm_gate", "mdn_gate"):
         # the scripts' own batch size (function/VAE_CNN_NN.py:53): launch-bound when issued call by
         # call, so the step is also timed as one replayed HIP graph

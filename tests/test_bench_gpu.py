@@ -28,3 +28,6 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
         assert key in roof, key
     assert roof["bound"] in ("hbm", "mfma") and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9
     assert d["script_batch"]["graph"]["value"] > 0 and d["n68"]["value"] > 0
+    # the same workload without the symmetric-input promise is reported next to the headline
+    assert d["full_first_layer"]["value"] > 0 and "packed upper triangle" not in d["full_first_layer"]["workload"]
+    assert "packed upper triangle" in d["config"]["workload"]
