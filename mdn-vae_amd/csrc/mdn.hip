@@ -26,6 +26,26 @@ constexpr int MDN_NT = 256;              // four waves per workgroup, one sample
 constexpr int MDN_MAXK = 8;
 constexpr float LOG_2PI = 1.8378770664093453f;
 
+// Exponent of component k (the lane's own) of one sample, t_k = u_k / 2 + D log sigma_k with
+// u_k = ss_k / sigma_k^2, taken relative to (about) the smallest t over the K owning lanes.  t runs
+// to 1e4 and beyond (D = 7569), where one fp32 step is 1e-3: adding the O(1) log mixture weight to
+// it directly rounds the weight away, and with it the responsibilities of near-tied components.
+// Differences keep the precision: rel_k = (u_k - u_m) / 2 + D (log sigma_k - log sigma_m) with m
+// the lane whose fp32 t is smallest; the part common to all components, t_m + (D/2) log 2 pi, joins
+// the per-sample total in double as `offset` (nll_b = offset - logsumexp_k(log pi_k - rel_k)).
+struct MixtureExponent { float rel; double offset; };
+__device__ __forceinline__ MixtureExponent mixture_exponent(bool owner, float ss, float inv_sigma2, float log_sigma,
+                                                            int D) {
+    const float u = ss * inv_sigma2;
+    const float t = owner ? 0.5f * u + (float)D * log_sigma : INFINITY;
+    const float tmin = -wave_max_all(-t);
+    const unsigned long long at_min = __ballot(owner && t == tmin);
+    const int m = at_min ? __builtin_ctzll(at_min) : 0;
+    const float um = __shfl(u, m), lsm = __shfl(log_sigma, m);
+    return MixtureExponent{owner ? 0.5f * (u - um) + (float)D * (log_sigma - lsm) : 0.0f,
+                           0.5 * (double)um + (double)D * ((double)lsm + 0.5 * (double)LOG_2PI)};
+}
+
 // Rows of D floats start at arbitrary 4-byte phases when D is not a multiple of 4 (87*87 = 7569);
 // the hardware takes 16-byte vector accesses at any 4-byte aligned address, so rows are walked as
 // quads of their own elements through this 4-byte aligned vector type.
@@ -112,11 +132,9 @@ __global__ __launch_bounds__(MDN_NT) void mdn_fwd_kernel(const float* __restrict
         if (lane < K) gl = logits[(long)b * K + lane];
         const float gmax = wave_max_all(gl);
         const float gsum = wave_sum_all(lane < K ? expf(gl - gmax) : 0.0f);
-        if (lane < K) {
-            const float ls = log_sigma[lane];
-            const float logpi = gl - gmax - logf(gsum);
-            a = logpi - 0.5f * ssk * expf(-2.0f * ls) - (float)D * (ls + 0.5f * LOG_2PI);
-        }
+        const float ls = lane < K ? log_sigma[lane] : 0.0f;
+        const MixtureExponent me = mixture_exponent(lane < K, ssk, expf(-2.0f * ls), ls, D);
+        if (lane < K) a = (gl - gmax - logf(gsum)) - me.rel;
         const float amax = wave_max_all(a);
         const float asum = wave_sum_all(lane < K ? expf(a - amax) : 0.0f);
         const float lse = amax + logf(asum);
@@ -125,7 +143,7 @@ __global__ __launch_bounds__(MDN_NT) void mdn_fwd_kernel(const float* __restrict
             ss_out[(long)b * K + lane] = ssk;
         }
         if (lane == 0) {
-            per_sample[2 * b] = -(double)lse;
+            per_sample[2 * b] = me.offset - (double)lse;
             per_sample[2 * b + 1] = (double)kl;
         }
     }
@@ -454,12 +472,13 @@ __global__ __launch_bounds__(MDN_NT) void mdn_outer_kernel(const float* __restri
         if (lane < K) gl = logits[(long)b * K + lane];
         const float gmax = wave_max_all(gl);
         const float gsum = wave_sum_all(lane < K ? expf(gl - gmax) : 0.0f);
+        const float ls = lane < K ? log_sigma[lane] : 0.0f;
+        if (lane < K) is2 = expf(-2.0f * ls);
+        const MixtureExponent me = mixture_exponent(lane < K, ssk, is2, ls, D);
         if (lane < K) {
-            const float ls = log_sigma[lane];
             const float logpi = gl - gmax - logf(gsum);
-            is2 = expf(-2.0f * ls);
             pi = expf(logpi);
-            a = logpi - 0.5f * ssk * is2 - (float)D * (ls + 0.5f * LOG_2PI);
+            a = logpi - me.rel;
         }
         const float amax = wave_max_all(a);
         const float asum = wave_sum_all(lane < K ? expf(a - amax) : 0.0f);
@@ -473,7 +492,7 @@ __global__ __launch_bounds__(MDN_NT) void mdn_outer_kernel(const float* __restri
             glsig_rows[(long)b * K + lane] = r * ((float)D - ssk * is2);
         }
         if (lane == 0) {
-            per_sample[2 * b] = -(double)lse;
+            per_sample[2 * b] = me.offset - (double)lse;
             per_sample[2 * b + 1] = (double)kl;
         }
         float* dst = gnodes + (long)b * K * MO_NP;

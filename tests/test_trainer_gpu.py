@@ -325,7 +325,9 @@ def test_headline_step_at_full_size_is_additive_over_subjects_and_path_independe
     for name, g in full[1].items():
         scale = float(g.abs().max())
         assert float((g - (lo[1][name] + hi[1][name])).abs().max()) <= 1e-4 * scale, name
-        # two different fp32 summations over 16384 heavy-tailed subjects (values up to ~95, strong
-        # cancellation): they differ by ~1.5e-3 of the largest entry on the first-layer weights, as
-        # each differs from float64; an indexing or scaling mistake would show as O(1)
+        # the two first layers round differently (folded weights, other summation order), so the
+        # ReLU masks of a few near-zero pre-activations among the 16 M differ; each flip moves one
+        # subject's whole rank-one term (entries up to ~95) in the first-layer weight gradients:
+        # ~1e-3 of their largest entry, which is also how far each path is from float64 there.
+        # An indexing or scaling mistake would show as O(1).
         assert float((g - plain[1][name]).abs().max()) <= 5e-3 * scale, name
