@@ -137,6 +137,16 @@ int mdnvae_decoder_fwd(const float* z, const float* wt, int B, int N, int L, int
                        int xlat_channels, int components, float* out, float* xlat, float* nodes, float* layer_in,
                        void* stream);
 
+/* Weight (+ bias row) gradients of all count = R*NL layers of a decoder in panel form:
+ * dwt [count][MDNVAE_DEC_KP][MDNVAE_DEC_NP] = layer_in[rl]^T . layer_dpre[rl] with the two
+ * [count][B][96] buffers mdnvae_decoder_bwd has filled (the autograd of the F.linear / GCN layers of
+ * function/VAE_CNN_NN.py:172-181, function/MM_Gate.py:86-92 with respect to their weights).  Split
+ * over the batch, partial panels added in slab order.  workspace:
+ * mdnvae_decoder_wgrad_workspace_floats(B, count) floats; all pointers 16-byte aligned. */
+size_t mdnvae_decoder_wgrad_workspace_floats(int B, int count);
+int mdnvae_decoder_wgrad(const float* layer_in, const float* layer_dpre, int B, int count, float* workspace, float* dwt,
+                         void* stream);
+
 /* floats in each of layer_in / layer_dpre for a batch of B */
 size_t mdnvae_decoder_bwd_rows_floats(int B, int R, int NL);
 /* Backward: grad_out [B,N*N], optional grad_xlat [B,N] -> grad_z [B,L]; per layer the input rows

@@ -144,6 +144,106 @@ static int ts_slabs(int B, int N, int M) {
     return (int)(s < 1 ? 1 : s);
 }
 
+// ---- weight gradients of the chain decoder's panels ----
+// dwt[rl] [96 x 96] = layer_in[rl]^T . layer_dpre[rl] for all R*NL (channel, layer) pairs of a
+// decoder at once: layer_in / layer_dpre are [RL][B][96] (input rows with the constant-1 column,
+// gradients of the pre-activations).  Same split over the batch as above; a workgroup owns one whole
+// 96 x 96 panel for one slab of samples, its four waves a 48 x 48 quarter each as 3 x 3 tiles of the
+// 16x16x4 fp32 matrix instruction (a 96-wide panel does not fill the 64 x 128 tile of the kernel
+// above: 56 % of its matrix work would be padding).  Rows of both operands are 96 contiguous floats,
+// so a chunk of 32 samples is one contiguous 12 KB run of each, fetched 16 bytes per lane one chunk
+// ahead.  LDS row stride 112 floats: the two sample rows that the 32 lanes of one LDS pass read start
+// 16 banks apart.
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+constexpr int PW = 96, PW_LD = 112, PW_KC = 32, PW_NT = 256, PW_Q = PW_KC * PW / 4 / PW_NT;   // 3 float4 per thread
+
+__device__ __forceinline__ void pw_fetch(const float* __restrict__ H, const float* __restrict__ D, int b0, int b_end,
+                                         float4 (&ch)[PW_Q], float4 (&cd)[PW_Q]) {
+#pragma unroll
+    for (int i = 0; i < PW_Q; ++i) {
+        const int q = i * PW_NT + threadIdx.x, r = q / (PW / 4), c4 = (q - r * (PW / 4)) * 4;
+        const int b = b0 + r;
+        float4 vh = make_float4(0.f, 0.f, 0.f, 0.f), vd = vh;
+        if (b < b_end) {
+            vh = *reinterpret_cast<const float4*>(H + (long)b * PW + c4);
+            vd = *reinterpret_cast<const float4*>(D + (long)b * PW + c4);
+        }
+        ch[i] = vh;
+        cd[i] = vd;
+    }
+}
+__device__ __forceinline__ void pw_commit(const float4 (&ch)[PW_Q], const float4 (&cd)[PW_Q], float* __restrict__ hs,
+                                          float* __restrict__ ds) {
+#pragma unroll
+    for (int i = 0; i < PW_Q; ++i) {
+        const int q = i * PW_NT + threadIdx.x, r = q / (PW / 4), c4 = (q - r * (PW / 4)) * 4;
+        *reinterpret_cast<float4*>(hs + r * PW_LD + c4) = ch[i];
+        *reinterpret_cast<float4*>(ds + r * PW_LD + c4) = cd[i];
+    }
+}
+
+// grid: (slabs, RL); part[slab][rl][96][96]
+__global__ __launch_bounds__(PW_NT, 2) void panel_wgrad_partial_kernel(const float* __restrict__ layer_in,
+                                                                       const float* __restrict__ layer_dpre, int B,
+                                                                       int slab_rows, float* __restrict__ part) {
+    __shared__ __attribute__((aligned(16))) float hs[2][PW_KC * PW_LD];
+    __shared__ __attribute__((aligned(16))) float ds[2][PW_KC * PW_LD];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wr = (wave >> 1) * 48, wc = (wave & 1) * 48;
+    const int rl = blockIdx.y;
+    const float* H = layer_in + (long)rl * B * PW;
+    const float* D = layer_dpre + (long)rl * B * PW;
+    const int b_begin = blockIdx.x * slab_rows, b_end = min(B, b_begin + slab_rows);
+    f32x4 acc[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float4 ch[PW_Q], cd[PW_Q];
+    pw_fetch(H, D, b_begin, b_end, ch, cd);
+    pw_commit(ch, cd, hs[0], ds[0]);
+    __syncthreads();
+    const int kk = lane >> 4, l16 = lane & 15;
+    int cur = 0;
+    for (int b0 = b_begin; b0 < b_end; b0 += PW_KC, cur ^= 1) {
+        const bool more = b0 + PW_KC < b_end;
+        if (more) pw_fetch(H, D, b0 + PW_KC, b_end, ch, cd);
+        const float* ha = hs[cur] + kk * PW_LD + wr + l16;
+        const float* db = ds[cur] + kk * PW_LD + wc + l16;
+#pragma unroll
+        for (int k = 0; k < PW_KC; k += 4) {
+            float a[3], b[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                a[i] = ha[k * PW_LD + 16 * i];
+                b[i] = db[k * PW_LD + 16 * i];
+            }
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) pw_commit(ch, cd, hs[cur ^ 1], ds[cur ^ 1]);
+        __syncthreads();
+    }
+    float* dst = part + ((long)blockIdx.x * gridDim.y + rl) * PW * PW;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dst[(wr + 16 * i + 4 * kk + e) * PW + wc + 16 * j + l16] = acc[i][j][e];
+}
+
+// slabs: some 640 workgroups in all, at least 64 samples per slab
+static int pw_slabs(int B, int count) {
+    long s = (640 + count - 1) / count;
+    const long most = (B + 63) / 64;
+    if (s > most) s = most;
+    if (s > 64) s = 64;
+    return (int)(s < 1 ? 1 : s);
+}
+
 }  // namespace mdnvae
 using namespace mdnvae;
 
@@ -173,6 +273,31 @@ int mdnvae_linear_wgrad(const float* grad_pre, const float* x, int B, int N, int
     const long count = (long)N * M;
     hipLaunchKernelGGL(tsgemm_reduce_kernel, dim3((unsigned)((count / 4 + 63) / 64)), dim3(256), 0, (hipStream_t)stream,
                        workspace, used, count, accumulate, grad_w);
+    MV_LAUNCH_CHECK("tsgemm_reduce_kernel");
+    return 0;
+}
+
+size_t mdnvae_decoder_wgrad_workspace_floats(int B, int count) {
+    if (B < 1 || count < 1) return 0;
+    return (size_t)pw_slabs(B, count) * count * PW * PW;
+}
+
+int mdnvae_decoder_wgrad(const float* layer_in, const float* layer_dpre, int B, int count, float* workspace, float* dwt,
+                         void* stream) {
+    MV_REQUIRE(B >= 1 && count >= 1 && count <= 65535, E_ARG, "mdnvae_decoder_wgrad: bad size");
+    MV_REQUIRE(PW == MDNVAE_DEC_KP && PW == MDNVAE_DEC_NP, E_SHAPE, "mdnvae_decoder_wgrad: panels must be 96 x 96");
+    MV_REQUIRE(layer_in && layer_dpre && workspace && dwt, E_ARG, "mdnvae_decoder_wgrad: null pointer");
+    MV_REQUIRE(aligned16(layer_in) && aligned16(layer_dpre) && aligned16(workspace) && aligned16(dwt), E_ALIGN,
+               "mdnvae_decoder_wgrad: operands must be 16-byte aligned");
+    const int slabs = pw_slabs(B, count);
+    const int slab_rows = ((B + slabs - 1) / slabs + PW_KC - 1) / PW_KC * PW_KC;
+    const int used = (B + slab_rows - 1) / slab_rows;
+    hipLaunchKernelGGL(panel_wgrad_partial_kernel, dim3(used, count), dim3(PW_NT), 0, (hipStream_t)stream, layer_in,
+                       layer_dpre, B, slab_rows, workspace);
+    MV_LAUNCH_CHECK("panel_wgrad_partial_kernel");
+    const long n = (long)count * PW * PW;
+    hipLaunchKernelGGL(tsgemm_reduce_kernel, dim3((unsigned)((n / 4 + 63) / 64)), dim3(256), 0, (hipStream_t)stream,
+                       workspace, used, n, 0, dwt);
     MV_LAUNCH_CHECK("tsgemm_reduce_kernel");
     return 0;
 }

@@ -603,8 +603,14 @@ class _ChainDecoder(torch.autograd.Function):
              int(spec.components), ptr(gout),
              ptr(gxlat), ptr(gz), ptr(hin), ptr(dp), ptr(ga), ptr(nodes), ptr(node_grad), int(saved_hin is not None),
              ptr(gz_parts), stream())
-        # weight (+bias, last row) gradient of every layer: [KP x B] . [B x NP] library GEMMs
-        dwt = torch.bmm(hin.transpose(1, 2), dp)
+        # weight (+bias, last row) gradient of every layer: [KP x B] . [B x NP], split over the batch
+        dwt = torch.empty(RL, DEC_KP, DEC_NP, dtype=torch.float32, device=dev)
+        if B > 0:
+            ws = torch.empty(_lib.workspace_bytes_f("mdnvae_decoder_wgrad_workspace_floats", B, RL), dtype=torch.float32,
+                             device=dev)
+            call("mdnvae_decoder_wgrad", ptr(hin), ptr(dp), B, RL, ptr(ws), ptr(dwt), stream())
+        else:
+            dwt.zero_()
         import ctypes
         n = spec.R * spec.NL
         kind, n_out, k = (ctypes.c_int * n)(), (ctypes.c_int * n)(), (ctypes.c_int * n)()
