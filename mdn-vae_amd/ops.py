@@ -179,6 +179,26 @@ def _library_gemm(a, b):
     return torch.mm(a, b)
 
 
+def _library_fused_linear(x, w_t, bias, relu):
+    """x @ w_t + bias, with ReLU if asked, as one library GEMM with an epilogue (one call site, so a
+    benchmark can time it)."""
+    if relu:
+        return torch._addmm_activation(bias, x, w_t, use_gelu=False)
+    return torch.addmm(bias, x, w_t)
+
+
+def _library_linear(x, w_t, bias, act):
+    """act(x @ w_t + bias) [B,H] for a [K,H] view w_t of the weight.  With a bias and ReLU or no
+    activation the library GEMM applies them in its own epilogue (one pass less over the [B,H]
+    result); other cases take the plain GEMM and the bias/activation kernel."""
+    if bias is not None and x.shape[0] > 0 and (
+            act == ACTS[None] or (act == ACTS["relu"] and hasattr(torch, "_addmm_activation"))):
+        return _library_fused_linear(x, w_t, bias, act == ACTS["relu"])
+    y = _library_gemm(x, w_t)
+    call("mdnvae_bias_act", ptr(y), ptr(bias, "bias"), y.shape[0], y.shape[1], act, stream())
+    return y
+
+
 def _small_wgrad_ok(B, n_out, n_in):
     """Layers whose weight is small next to the batch: the split-over-the-batch kernel beats a
     library GEMM that has only a handful of output tiles."""
@@ -240,8 +260,7 @@ class _LinearAct(torch.autograd.Function):
             call("mdnvae_narrow_linear_fwd", ptr(x), ptr(weight), ptr(bias, "bias"), x.shape[0], weight.shape[0],
                  weight.shape[1], act, ptr(y), stream())
         else:
-            y = _library_gemm(x, weight.t())
-            call("mdnvae_bias_act", ptr(y), ptr(bias, "bias"), y.shape[0], y.shape[1], act, stream())
+            y = _library_linear(x, weight.t(), bias, act)
         ctx.save_for_backward(x, weight, y)
         ctx.act = act
         ctx.has_bias = bias is not None
@@ -310,8 +329,7 @@ class _SymLinearAct(torch.autograd.Function):
         H, T = weight.shape[0], xt.shape[1]
         wt = torch.empty(H, T, dtype=torch.float32, device=xt.device)
         call("mdnvae_tri_fold", ptr(weight, "weight"), H, n_nodes, T, ptr(wt), stream())
-        y = _library_gemm(xt, wt.t())
-        call("mdnvae_bias_act", ptr(y), ptr(bias, "bias"), y.shape[0], y.shape[1], act, stream())
+        y = _library_linear(xt, wt.t(), bias, act)
         ctx.save_for_backward(xt, y)
         ctx.act, ctx.n_nodes, ctx.has_bias = act, n_nodes, bias is not None
         ctx.params = (weight, bias)

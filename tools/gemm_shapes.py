@@ -22,6 +22,7 @@ for _ in range(3):
     trainer.step((x, adjacency, traits), x, eps=eps)
 log = []
 inner = ops._library_gemm
+inner_fused = ops._library_fused_linear
 
 
 def timed(a, b):
@@ -34,6 +35,18 @@ def timed(a, b):
 
 
 ops._library_gemm = timed
+
+
+def timed_fused(a, b, bias, relu):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    out = inner_fused(a, b, bias, relu)
+    e1.record()
+    log.append((tuple(a.shape), a.stride(), tuple(b.shape), b.stride(), e0, e1))
+    return out
+
+
+ops._library_fused_linear = timed_fused
 trainer.step((x, adjacency, traits), x, eps=eps)
 torch.cuda.synchronize()
 for sa, sta, sb, stb, e0, e1 in log:
