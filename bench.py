@@ -201,6 +201,9 @@ ABI_TAGS = {
                            else ("chain_bwd_saved_kernel" if a[-3] else "chain_bwd_mfma_kernel"),
                            lambda a: _decoder_work(a, 1)),
     "mdnvae_adam_step": ("adam_kernel", lambda a: 28.0 * a[4]),
+    # (param, grad_t, m_t, v_t, H, N, ...): the weight in and out, the folded gradient in, both folded moments in and out
+    "mdnvae_adam_step_folded": ("adam_folded_moments_kernel+apply_folded_step_kernel",
+                                lambda a: 4.0 * a[4] * (2 * a[5] * a[5] + 7 * (a[5] * (a[5] + 1) // 2))),
     # args: (x, B, N, ld, out, asym, stream): read N*N, write the triangle, per matrix
     "mdnvae_tri_pack": ("tri_pack_kernel", lambda a: 4.0 * a[1] * (a[2] * a[2] + a[2] * (a[2] + 1) // 2)),
 }

@@ -306,6 +306,18 @@ int mdnvae_adam_step_dev(float* param, const float* grad, float* exp_avg, float*
                          float* coef_dev, float lr, float beta1, float beta2, float eps, float grad_scale,
                          void* stream);
 
+/* Adam for the weight [H][N*N] of a symmetric-input first layer (function/MM_Gate.py:157-158 on
+ * symmetric connectomes) from its gradient folded onto the upper triangle: grad_t [t][H], t the
+ * row-major walk of the triangle (what the weight-gradient GEMM on the packed input produces;
+ * w_ij and w_ji share the value).  exp_avg_t / exp_avg_sq_t [N(N+1)/2][H] hold the moments in the same
+ * layout; both mirror entries of param take the step.  Same numbers as mdnvae_tri_unfold followed by
+ * mdnvae_adam_step.  grad_t is consumed (its first N(N+1)/2 rows hold the steps afterwards).
+ * coef_dev (or NULL): the device pair a preceding mdnvae_adam_step_dev on the same stream has
+ * left; `step` is ignored then. */
+int mdnvae_adam_step_folded(float* param, float* grad_t, float* exp_avg_t, float* exp_avg_sq_t, int H, int N,
+                            int step, const float* coef_dev, float lr, float beta1, float beta2, float eps,
+                            float grad_scale, void* stream);
+
 /* ---- trait-gated Gaussian-mixture likelihood (BUILD-DEFINED: the reference has no such code) ----
  * comp_mean [B,K,D] component means, x [B,D], gate_logits [B,K] (from the traits), log_sigma [K];
  *   nll = -sum_b logsumexp_k( log softmax(gate_logits)_bk

@@ -364,6 +364,13 @@ class GCNVAE(nn.Module):
         h12 = self.fc222(a12, act="relu")
         return self.fc21(h11), self.fc22(h12)
 
+    def folded_grad_params(self):
+        """[(parameter, n_nodes)]: the weights whose gradient the symmetric-input first layers produce
+        folded onto the upper triangle (a trainer may exchange and apply it in that form)."""
+        if not self.symmetric_input:
+            return []
+        return [(self.fc11.weight, self.n_nodes), (self.fc12.weight, self.n_nodes)]
+
     def check_inputs(self):
         """Raises if a batch seen since the last call was not symmetric although the model was
         built with symmetric_input=True (its outputs for that batch are then wrong).  Reads one

@@ -47,8 +47,10 @@ class FlatBuffers:
     def numel(self):
         return self.offsets[-1]
 
-    def zero_grad(self):
-        self.flat_g.zero_()
+    def zero_grad(self, start=0):
+        """Zero the gradient buffer from element `start` on (the front may hold gradients that the
+        step overwrites or never reads)."""
+        self.flat_g[start:].zero_()
         for p, o in zip(self.params, self.offsets):      # re-attach views if something reset .grad
             if p.grad is None or p.grad.data_ptr() != self.flat_g.data_ptr() + 4 * o:
                 p.grad = self.flat_g[o:o + p.numel()].view(p.shape)
@@ -91,14 +93,33 @@ class Trainer:
     sum.  The rest of the flat gradient buffer is reduced in buckets after backward."""
 
     def __init__(self, model, loss_mode, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, group=None, fused_loss=True,
-                 overlap_floats=1 << 20, direct_grads=True):
+                 overlap_floats=1 << 20, direct_grads=True, folded_adam=True):
         self.model, self.loss_mode, self.group = model, loss_mode, group
         self.lr, self.betas, self.eps = lr, betas, eps
         early = _distributed(group) and overlap_floats
-        # the early-reduced matrices sit together at the front: what is left is one all-reduce
-        self.buf = FlatBuffers(model, front=(lambda p: p.numel() >= overlap_floats) if early else None)
+        # `folded_adam`: weights of symmetric-input first layers keep their gradient folded onto the
+        # upper triangle all the way into Adam (moments in the folded layout, both mirror entries
+        # take the step): step() then never writes, zeroes or re-reads their unfolded gradient.
+        provider = getattr(model, "folded_grad_params", None)
+        self._fold = {id(p): (p, n) for p, n in (provider() if (provider and folded_adam and direct_grads) else [])
+                      if p.requires_grad}
+        # those weights first, then the other early-reduced matrices: what is left is one range
+        self.buf = FlatBuffers(model, front=(lambda p: id(p) in self._fold or bool(early and p.numel() >= overlap_floats))
+                               if (early or self._fold) else None)
+        if self._fold:
+            head = self.buf.params[:len(self._fold)]
+            if not all(id(p) in self._fold for p in head):       # keep them a prefix of the buffers
+                order = [p for p in self.buf.params if id(p) in self._fold]
+                raise RuntimeError(f"Trainer: folded-gradient parameters are not a prefix of the flat buffers ({len(order)})")
+        self._fold_end = self.buf.offsets[len(self._fold)] if self._fold else 0
         self.exp_avg = torch.zeros_like(self.buf.flat_p)
         self.exp_avg_sq = torch.zeros_like(self.buf.flat_p)
+        self._fold_m, self._fold_v = {}, {}
+        for key, (p, n) in self._fold.items():
+            shape = (n * (n + 1) // 2, p.shape[0])
+            self._fold_m[key] = torch.zeros(shape, dtype=torch.float32, device=p.device)
+            self._fold_v[key] = torch.zeros(shape, dtype=torch.float32, device=p.device)
+        self._defer_fold = False    # inside step(): folded gradients are not unfolded into .grad
         self.steps = 0
         self.fused_loss = fused_loss
         self.direct_grads = direct_grads
@@ -135,7 +156,7 @@ class Trainer:
             self._pending.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         return hook
 
-    def forward_backward(self, inputs, target, eps=None):
+    def forward_backward(self, inputs, target, eps=None, _defer_fold=False):
         """inputs: positional arguments of model.forward; returns the detached loss (0-dim).
         loss_mode "mdn" trains a model whose forward returns (component means, gate logits, mu,
         logvar) and whose .loss() is the trait-gated mixture likelihood + KL.
@@ -145,9 +166,13 @@ class Trainer:
         if not self.direct_grads:
             return self._forward_backward(inputs, target, eps)
         exchange = bool(self._hook_of)
-        with ops.accumulate_into_grads(ready=self._grad_ready if exchange else None,
-                                       folded=self._folded_grad if exchange else None):
-            return self._forward_backward(inputs, target, eps)
+        self._defer_fold = bool(_defer_fold and self._fold)
+        try:
+            with ops.accumulate_into_grads(ready=self._grad_ready if exchange else None,
+                                           folded=self._folded_grad if (exchange or self._fold) else None):
+                return self._forward_backward(inputs, target, eps)
+        finally:
+            self._defer_fold = False
 
     def _grad_ready(self, param):
         hook = self._hook_of.get(id(param))
@@ -158,14 +183,24 @@ class Trainer:
         """Weight gradient of a symmetric-input first layer, still folded onto the upper triangle
         ([T, H], half the elements of the weight): that is what crosses the links.  The SUM commutes
         with writing each value to (i,j) and (j,i), which optimizer_step does once the transfer is in."""
-        if id(param) not in self._hook_of:   # a small layer: unfold now, its range goes with the buckets
+        hooked, folded_adam = id(param) in self._hook_of, id(param) in self._fold
+        if not hooked and not folded_adam:   # a small layer: unfold now, its range goes with the buckets
             call("mdnvae_tri_unfold", ptr(gt), gt.shape[1], n_nodes, gt.shape[1], 1, ptr(param.grad), 1, stream())
             return
-        work = dist.all_reduce(gt, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        if not _distributed(self.group):
+            work = None
+            if not self._defer_fold:         # a caller outside step() may read .grad
+                call("mdnvae_tri_unfold", ptr(gt), gt.shape[1], n_nodes, gt.shape[1], 1, ptr(param.grad), 1, stream())
+        elif hooked:
+            work = dist.all_reduce(gt, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        else:                                # below the early-exchange size: summed where it is consumed
+            work = "late"
         self._folded.append((work, gt, param, n_nodes))
 
     def _forward_backward(self, inputs, target, eps=None):
-        self.buf.zero_grad()
+        self._folded.clear()
+        # inside step() the unfolded gradients of the folded-Adam weights are neither written nor read
+        self.buf.zero_grad(self._fold_end if self._defer_fold else 0)
         if self.loss_mode == "mdn" and self.fused_loss:
             # rank-one component means: likelihood, KL and all their gradients from one pass over
             # the target, straight from the decoder's node vectors
@@ -211,17 +246,41 @@ class Trainer:
         for w in self._pending:
             w.wait()
         self._pending.clear()
-        for work, gt, param, n_nodes in self._folded:
-            work.wait()
-            call("mdnvae_tri_unfold", ptr(gt), gt.shape[1], n_nodes, gt.shape[1], 1, ptr(param.grad), 1, stream())
-        self._folded.clear()
         self.steps += 1
-        call("mdnvae_adam_step", ptr(self.buf.flat_p), ptr(self.buf.flat_g), ptr(self.exp_avg), ptr(self.exp_avg_sq),
-             self.buf.numel, self.steps, float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps),
-             1.0, stream())
+        self._apply_adam(None)
+
+    def _apply_adam(self, dev_state):
+        """Adam over the flat buffers, and over the folded-gradient weights in their own layout.
+        dev_state = (step counter, coefficient pair) on the device for a captured step, else None."""
+        folded = []
+        for work, gt, param, n_nodes in self._folded:
+            if work == "late":
+                dist.all_reduce(gt, op=dist.ReduceOp.SUM, group=self.group)
+            elif work is not None:
+                work.wait()
+            if id(param) in self._fold:
+                folded.append((gt, param, n_nodes))
+            else:
+                call("mdnvae_tri_unfold", ptr(gt), gt.shape[1], n_nodes, gt.shape[1], 1, ptr(param.grad), 1, stream())
+        self._folded.clear()
+        if len(folded) != len(self._fold):
+            raise RuntimeError("Trainer: a symmetric-input weight received no folded gradient in this step (a backward "
+                               "pass outside Trainer.forward_backward?); build the trainer with folded_adam=False")
+        lo = self._fold_end
+        args = (float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps), 1.0, stream())
+        rest = (ptr(self.buf.flat_p[lo:]), ptr(self.buf.flat_g[lo:]), ptr(self.exp_avg[lo:]), ptr(self.exp_avg_sq[lo:]),
+                self.buf.numel - lo)
+        if dev_state is None:
+            call("mdnvae_adam_step", *rest, self.steps, *args)
+        else:
+            call("mdnvae_adam_step_dev", *rest, dev_state[0].data_ptr(), ptr(dev_state[1]), *args)
+        for gt, param, n_nodes in folded:
+            call("mdnvae_adam_step_folded", ptr(param.data), ptr(gt), ptr(self._fold_m[id(param)]),
+                 ptr(self._fold_v[id(param)]), param.shape[0], n_nodes, max(self.steps, 1),
+                 ptr(dev_state[1]) if dev_state is not None else None, *args)
 
     def step(self, inputs, target, eps=None):
-        loss = self.forward_backward(inputs, target, eps)
+        loss = self.forward_backward(inputs, target, eps, _defer_fold=True)
         self.optimizer_step()
         return loss
 
@@ -246,13 +305,13 @@ class Trainer:
         self._g_eps = eps.detach().clone()
         self._g_step = torch.zeros(1, dtype=torch.int32, device=dev)
         self._g_coef = torch.zeros(2, dtype=torch.float32, device=dev)
-        keep = [t.clone() for t in (self.buf.flat_p, self.exp_avg, self.exp_avg_sq)]
+        state = [self.buf.flat_p, self.exp_avg, self.exp_avg_sq] + list(self._fold_m.values()) + \
+            list(self._fold_v.values())
+        keep = [t.clone() for t in state]
 
         def one():
-            loss = self.forward_backward(self._g_inputs, self._g_target, self._g_eps)
-            call("mdnvae_adam_step_dev", ptr(self.buf.flat_p), ptr(self.buf.flat_g), ptr(self.exp_avg),
-                 ptr(self.exp_avg_sq), self.buf.numel, self._g_step.data_ptr(), ptr(self._g_coef), float(self.lr),
-                 float(self.betas[0]), float(self.betas[1]), float(self.eps), 1.0, stream())
+            loss = self.forward_backward(self._g_inputs, self._g_target, self._g_eps, _defer_fold=True)
+            self._apply_adam((self._g_step, self._g_coef))
             return loss
 
         side = torch.cuda.Stream(device=dev)
@@ -264,7 +323,7 @@ class Trainer:
         self._graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._graph):
             self._g_loss = one()
-        for dst, src in zip((self.buf.flat_p, self.exp_avg, self.exp_avg_sq), keep):
+        for dst, src in zip(state, keep):
             dst.copy_(src)
         self._g_step.fill_(self.steps)
         return self

@@ -275,9 +275,11 @@ def test_direct_gradients_equal_autograd_accumulation():
             model.load_state_dict(params, strict=False)
             trainer = M.Trainer(model.to(DEV), "poisson_log", fused_loss=fused, direct_grads=direct)
             trainer.forward_backward((x, adjacency), x, eps=eps)
-            got[direct] = trainer.buf.flat_g.clone()
-        scale = float(got[False].abs().max())
-        assert float((got[True] - got[False]).abs().max()) <= 1e-6 * scale, fused
+            # by name: the two trainers lay the flat buffers out differently
+            got[direct] = {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+        scale = max(float(g.abs().max()) for g in got[False].values())
+        for name, want in got[False].items():
+            assert float((got[True][name] - want).abs().max()) <= 1e-6 * scale, (fused, name)
     # += semantics: a second backward without zeroing doubles the buffer
     model = M.GCNVAE(R=5, n_nodes=68, k=32, n_layers=3, latent_dim=68, symmetric_input=True)
     model.load_state_dict(params, strict=False)
@@ -331,3 +333,36 @@ def test_headline_step_at_full_size_is_additive_over_subjects_and_path_independe
         # ~1e-3 of their largest entry, which is also how far each path is from float64 there.
         # An indexing or scaling mistake would show as O(1).
         assert float((g - plain[1][name]).abs().max()) <= 5e-3 * scale, name
+
+
+def test_folded_adam_steps_equal_unfolded_steps():
+    """Trainer(folded_adam=True) - moments of the symmetric-input first-layer weights kept folded,
+    both mirror entries stepped from one value - against the trainer that unfolds the gradient and
+    runs the flat Adam: same losses and parameters after several eager steps and after graph replays."""
+    fix = load_fixture("mm_gate")
+    params = fixture_params(fix)
+    x = torch.from_numpy(fix["x"]).reshape(-1, 68, 68)
+    x = (0.5 * (x + x.transpose(1, 2))).reshape(-1, 68 * 68).contiguous().to(DEV)
+    eps = torch.from_numpy(fix["eps"]).to(DEV)
+    adjacency = [list(map(int, r)) for r in fix["adjacency"]]
+    out = {}
+    for folded in (False, True):
+        model = M.GCNVAE(R=5, n_nodes=68, k=32, n_layers=3, latent_dim=68, symmetric_input=True)
+        model.load_state_dict(params, strict=False)
+        trainer = M.Trainer(model.to(DEV), "poisson_log", folded_adam=folded)
+        assert bool(trainer._fold) == folded
+        losses = [float(trainer.step((x, adjacency), x, eps=eps).item()) for _ in range(3)]
+        trainer.capture((x, adjacency), x, eps)
+        losses += [float(trainer.replay((x, adjacency), x, eps).item()) for _ in range(2)]
+        model.check_inputs()
+        out[folded] = (losses, {k: v.detach().clone() for k, v in model.named_parameters()})
+        if folded:      # forward_backward on its own still leaves every .grad filled in
+            trainer.forward_backward((x, adjacency), x, eps=eps)
+            g11 = model.fc11.weight.grad.reshape(-1, 68, 68)
+            assert float(g11.abs().max()) > 0 and torch.equal(g11, g11.transpose(1, 2))
+    # same formulas, two compilations of them: agreement to rounding, carried over five steps
+    for a, b in zip(out[True][0], out[False][0]):
+        assert abs(a - b) <= 1e-5 * abs(b)
+    for name, want in out[False][1].items():
+        got = out[True][1][name]
+        assert float((got - want).abs().max()) <= 2e-5 * float(want.abs().max()), name

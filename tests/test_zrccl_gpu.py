@@ -39,7 +39,8 @@ def test_one_rank_rccl_step_equals_the_local_step():
         for _ in range(3):
             loss = trainer.forward_backward((x, adjacency), x, eps=eps)
             # both first-layer weight gradients travel folded (half size), unfolded after the sum
-            assert len(trainer._folded) == (2 if distributed else 0)
+            assert len(trainer._folded) == 2
+            assert all((work is not None) == distributed for work, _, _, _ in trainer._folded)
             assert all(gt.shape == (M.ops.tri_row_stride(68), 1024) for _, gt, _, _ in trainer._folded)
             trainer.optimizer_step()
             assert not trainer._folded and not trainer._pending
