@@ -17,34 +17,39 @@ typedef tri_v4 tri_v4u __attribute__((aligned(4)));
 __device__ __forceinline__ int tri_index(int i, int j, int N) { return i * N - ((i * (i - 1)) >> 1) + (j - i); }
 
 // One workgroup per matrix (a sample of x, or the weights of one output unit).  The matrix is
-// staged in LDS so that the transposed element comes from LDS (stride N dwords, N odd or even both
-// spread over the banks well enough for a pass that is bound by the global traffic).
+// staged in LDS (16-byte pieces in, 16-byte LDS writes) so that the transposed element comes from
+// LDS (stride N dwords: conflict-free for odd N, eight-way for N = 68).
 //   FOLD = false: out[t] = m[i][j], *asym |= (m[i][j] != m[j][i])
 //   FOLD = true : out[t] = m[i][j] + m[j][i] (i < j), m[i][i]
 template <bool FOLD>
 __global__ __launch_bounds__(256) void tri_pack_kernel(const float* __restrict__ src, int N, int T, int ld,
                                                        float* __restrict__ out, int* __restrict__ asym) {
-    extern __shared__ float sm[];
+    extern __shared__ __attribute__((aligned(16))) float sm[];
     const int P = N * N;
     const float* m = src + (long)blockIdx.x * P;
     float* o = out + (long)blockIdx.x * ld;
-    if (threadIdx.x < ld - T) o[T + threadIdx.x] = 0.0f;           // padding columns of the row
     const int P4 = P >> 2;
-    for (int q = threadIdx.x; q < P4; q += 256) {
-        const tri_v4 v = __builtin_nontemporal_load(reinterpret_cast<const tri_v4u*>(m) + q);
-        sm[4 * q] = v.x; sm[4 * q + 1] = v.y; sm[4 * q + 2] = v.z; sm[4 * q + 3] = v.w;
-    }
+    for (int q = threadIdx.x; q < P4; q += 256)
+        reinterpret_cast<tri_v4*>(sm)[q] = __builtin_nontemporal_load(reinterpret_cast<const tri_v4u*>(m) + q);
     for (int p = (P4 << 2) + threadIdx.x; p < P; p += 256) sm[p] = m[p];
     __syncthreads();
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    // thread -> consecutive entries t of the packed row (whole cache lines per wave store, every lane
+    // busy); the row i of entry t from the root of t = i(2N+1-i)/2, corrected by at most one step
+    const float c = (float)(2 * N + 1);
     bool differs = false;
-    for (int i = wid; i < N; i += 4) {
-        const int t0 = tri_index(i, i, N);
-        for (int j = i + lane; j < N; j += 64) {
+    for (int t = threadIdx.x; t < ld; t += 256) {
+        float v = 0.0f;                                            // padding columns of the row
+        if (t < T) {
+            int i = (int)(0.5f * (c - sqrtf(c * c - 8.0f * (float)t)));
+            i = i < 0 ? 0 : (i > N - 1 ? N - 1 : i);
+            if (tri_index(i, i, N) > t) --i;
+            else if (i + 1 < N && tri_index(i + 1, i + 1, N) <= t) ++i;
+            const int j = i + (t - tri_index(i, i, N));
             const float a = sm[i * N + j], b = sm[j * N + i];
-            if (FOLD) o[t0 + (j - i)] = (j == i) ? a : a + b;
-            else { o[t0 + (j - i)] = a; differs |= !(a == b); }
+            if (FOLD) v = (j == i) ? a : a + b;
+            else { v = a; differs |= !(a == b); }
         }
+        o[t] = v;
     }
     if (!FOLD && differs) atomicOr(asym, 1);
 }
