@@ -218,7 +218,7 @@ __device__ __forceinline__ int acc_row(int j, int lane) { return (j & 3) + 8 * (
 // A wave owns 32 output columns of a layer, and its slice of the layer's panel lives in its
 // registers in the matrix-core operand layout: register i of lane (h = lane >> 5, c = lane & 31)
 // holds w[2i + h][n0 + c].  The next layer's slice is fetched from global memory (L2 resident: every
-// workgroup reads the same panels) while the current product runs, so LDS carries activations only
+// workgroup reads the same panels) around the current product, so LDS carries activations only
 // and a workgroup needs little of it - several tiles are resident per CU and hide each other's
 // latencies.
 constexpr int PANEL_REGS = KP / 2;
@@ -275,7 +275,7 @@ __global__ __launch_bounds__(CH_NT, 2) void chain_fwd_mfma_kernel(DecArgs a, con
     const int r_begin = blockIdx.y * rper, r_end = min(a.R, r_begin + rper);
     if (r_begin >= r_end) return;
     const int s_begin = r_begin * a.NL, s_end = r_end * a.NL;      // this workgroup's layer steps per tile
-    float wcur[PANEL_REGS], wnext[PANEL_REGS];
+    float wcur[PANEL_REGS];
     panel_fetch(wt + ((long)s_begin * KP) * NP, wave * 32, lane, wcur);
     int cur = 0;
     load_latent_tile(z, blockIdx.x * CH_TS, a.B, a.L, abuf0);
@@ -290,7 +290,6 @@ __global__ __launch_bounds__(CH_NT, 2) void chain_fwd_mfma_kernel(DecArgs a, con
                 const int s = r * a.NL + l;
                 const bool last_step = s == s_end - 1;
                 const bool more = !last_step || tile + (int)gridDim.x < ntiles;
-                if (more) panel_fetch(wt + ((long)(last_step ? s_begin : s + 1) * KP) * NP, wave * 32, lane, wnext);
                 // Every layer's input rows (with the ones column) are kept for the backward pass: they
                 // are its weight-gradient operand and, as the previous layer's output, give that
                 // layer's activation slope without recomputing the chain.  The first layer's input
@@ -305,6 +304,11 @@ __global__ __launch_bounds__(CH_NT, 2) void chain_fwd_mfma_kernel(DecArgs a, con
                     }
                 }
                 const f32x16 acc = panel_product(abuf0 + cur * KP * CH_LD, wcur, lane);
+                // One panel slice in registers: the next step's slice is fetched over the one just used,
+                // its L2 latency covered by the epilogue below and by the other resident workgroup.  (A
+                // second slice fetched ahead of the product costs 48 registers and 48 moves per step
+                // and, measured, 25 us of the 174 at B = 16384.)
+                if (more) panel_fetch(wt + ((long)(last_step ? s_begin : s + 1) * KP) * NP, wave * 32, lane, wcur);
                 const int act = layer_act(a.acts, l);
                 float* nxt = abuf0 + (cur ^ 1) * KP * CH_LD;
                 if (l == a.NL - 1) {
@@ -329,10 +333,6 @@ __global__ __launch_bounds__(CH_NT, 2) void chain_fwd_mfma_kernel(DecArgs a, con
                         nxt[n * CH_LD + sr] = v;
                         if (hin && b0 + sr < a.B) hin[((long)(s + 1) * a.B + b0 + sr) * KP + n] = v;
                     }
-                }
-                if (more) {
-#pragma unroll
-                    for (int i = 0; i < PANEL_REGS; ++i) wcur[i] = wnext[i];
                 }
                 __syncthreads();
                 cur ^= 1;
