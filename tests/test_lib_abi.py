@@ -37,6 +37,31 @@ def test_argument_rejection_needs_no_gpu():
     assert rc < 0 and b"mode" in lib.mdnvae_last_error()
 
 
+def test_shape_limits_of_the_dense_and_optimizer_entry_points_need_no_gpu():
+    lib = _lib.load()
+    # a weight wider than 8 on either side is not a narrow layer
+    assert lib.mdnvae_narrow_linear_fwd(None, None, None, 4, 9, 4, 0, None, None) < 0
+    assert b"narrow" in lib.mdnvae_last_error()
+    assert lib.mdnvae_narrow_linear_wgrad(None, None, 0, 4, 4, None, None, None, 0, None) < 0      # empty batch
+    assert lib.mdnvae_narrow_linear_workspace_floats() >= 64 * 72
+    # decoder panel gradients: sizes first, then pointers
+    assert lib.mdnvae_decoder_wgrad(None, None, 0, 20, None, None, None) < 0
+    assert lib.mdnvae_decoder_wgrad(None, None, 64, 20, None, None, None) < 0 and b"null" in lib.mdnvae_last_error()
+    assert lib.mdnvae_decoder_wgrad_workspace_floats(16384, 20) == 32 * 20 * 96 * 96
+    assert lib.mdnvae_decoder_wgrad_workspace_floats(8, 20) == 20 * 96 * 96
+    # folded Adam: a host step count is needed when no device coefficients are given
+    assert lib.mdnvae_adam_step_folded(None, None, None, None, 1024, 87, 0, None, 1e-3, 0.9, 0.999, 1e-8, 1.0, None) < 0
+    assert b"step" in lib.mdnvae_last_error()
+    assert lib.mdnvae_adam_step_folded(None, None, None, None, 1024, 87, 1, None, 1e-3, 0.9, 0.999, 1e-8, 1.0, None) < 0
+    assert b"null" in lib.mdnvae_last_error()
+    # symmetric-target likelihood passes: same argument checks as the general form
+    assert lib.mdnvae_mdn_outer_fwdbwd(None, None, None, None, 4, 9, 87, None, None, 0, None, None, None, None, None, None,
+                                       1, None, None, None) < 0
+    assert b"components" in lib.mdnvae_last_error()
+    assert lib.mdnvae_outer_loss_fwdbwd(1, None, None, 4, 5, 96, None, None, 0, None, None, None, 1, None, None, None) < 0
+    assert b"N = 96" in lib.mdnvae_last_error()
+
+
 def test_host_wrappers_refuse_cpu_tensors():
     a = torch.zeros(2, 4)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
