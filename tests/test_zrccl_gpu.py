@@ -30,23 +30,24 @@ def test_one_rank_rccl_step_equals_the_local_step():
     eps = torch.from_numpy(fix["eps"]).to(DEV)
     adjacency = [list(map(int, r)) for r in fix["adjacency"]]
 
-    def run(distributed):
+    def run(distributed, overlap=True):
         model = M.GCNVAE(R=5, n_nodes=68, k=32, n_layers=3, latent_dim=68, symmetric_input=True)
         model.load_state_dict(params, strict=False)
-        trainer = M.Trainer(model.to(DEV), "poisson_log")
-        assert bool(trainer._hook_of) == distributed          # the big first-layer matrices reduce early
+        trainer = M.Trainer(model.to(DEV), "poisson_log", **({} if overlap else {"overlap_floats": 0}))
+        assert bool(trainer._hook_of) == (distributed and overlap)   # the big first-layer matrices reduce early
         losses = []
         for _ in range(3):
             loss = trainer.forward_backward((x, adjacency), x, eps=eps)
             # both first-layer weight gradients travel folded (half size), unfolded after the sum
             assert len(trainer._folded) == 2
             assert all((work is not None) == distributed for work, _, _, _ in trainer._folded)
+            assert all(work == "late" for work, _, _, _ in trainer._folded) == (distributed and not overlap)
             assert all(gt.shape == (M.ops.tri_row_stride(68), 1024) for _, gt, _, _ in trainer._folded)
             trainer.optimizer_step()
             assert not trainer._folded and not trainer._pending
             losses.append(float(loss.item()))
         torch.cuda.synchronize()
-        if distributed:                                       # big matrices first, the rest is one range
+        if distributed and overlap:                           # big matrices first, the rest is one range
             assert trainer._rest == [(2 * 1024 * 68 * 68, trainer.buf.numel)]
         return losses, {k: v.detach().clone() for k, v in model.named_parameters()}
 
@@ -58,11 +59,14 @@ def test_one_rank_rccl_step_equals_the_local_step():
     try:
         dist.barrier()
         exchanged = run(True)
+        late = run(True, overlap=False)                       # everything reduced after backward
         stats = M.FeatureStats(8, torch.zeros(8, device=DEV), DEV).update(torch.rand(64, 8, device=DEV)).allreduce()
         assert stats.n == 64
     finally:
         T.MIN_RANKS_FOR_EXCHANGE = 2
         dist.destroy_process_group()
     assert exchanged[0] == local[0]
+    assert late[0] == local[0]
     for name, value in local[1].items():
         assert torch.equal(exchanged[1][name], value), name
+        assert torch.equal(late[1][name], value), name
