@@ -209,6 +209,14 @@ ABI_TAGS = {
 }
 HBM_TAGS = {v[0] for v in ABI_TAGS.values() if isinstance(v[0], str)} | {
     "chain_fwd_mfma_kernel+outer_epilogue_kernel", "outer_grad_kernel+chain_bwd_mfma_kernel"}
+# matrix-core entry points with a fixed tag (work in flops; kept out of HBM_TAGS)
+ABI_TAGS.update({
+    # (layer_in, layer_dpre, B, count, ...): one 96 x 96 x B product per (channel, layer)
+    "mdnvae_decoder_wgrad": ("panel_wgrad_partial_kernel+tsgemm_reduce_kernel",
+                             lambda a: 2.0 * a[2] * a[3] * ops.DEC_KP * ops.DEC_NP),
+    # (grad_pre, x, B, N, M, ...)
+    "mdnvae_linear_wgrad": ("tsgemm_partial_kernel+tsgemm_reduce_kernel", lambda a: 2.0 * a[2] * a[3] * a[4]),
+})
 
 
 def install_clock(clock):
