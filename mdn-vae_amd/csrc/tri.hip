@@ -18,7 +18,8 @@ __device__ __forceinline__ int tri_index(int i, int j, int N) { return i * N - (
 
 // One workgroup per matrix (a sample of x, or the weights of one output unit).  The matrix is
 // staged in LDS (16-byte pieces in, 16-byte LDS writes) so that the transposed element comes from
-// LDS (stride N dwords: conflict-free for odd N, eight-way for N = 68).
+// LDS (stride N dwords: conflict-free for odd N, eight-way for N = 68 - an odd padded stride was
+// measured there and bought nothing: the pass is bound by its global traffic).
 //   FOLD = false: out[t] = m[i][j], *asym |= (m[i][j] != m[j][i])
 //   FOLD = true : out[t] = m[i][j] + m[j][i] (i < j), m[i][i]
 template <bool FOLD>
