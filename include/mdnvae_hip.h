@@ -344,6 +344,18 @@ int mdnvae_mdn_outer_fwdbwd(const float* nodes, const float* x, const float* gat
                             int B, int K, int N, const float* mu, const float* logvar, int L, float* grad_nodes,
                             float* grad_logits, float* grad_log_sigma_rows, float* grad_mu, float* grad_logvar,
                             float* resp, int x_symmetric, void* workspace, float* loss_out, void* stream);
+/* mdnvae_mdn_outer_fwdbwd without the workspace argument, for callers that cannot allocate device
+ * memory (code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc).  It has
+ * no counterpart in the reference.  The per-sample partial sums live in a static 1 MiB device array
+ * inside the library (one copy per GPU, held until the process ends); the call allocates and frees
+ * nothing.  B <= 65536, larger batches are rejected (code -2).  Same results as
+ * mdnvae_mdn_outer_fwdbwd.  All calls on one GPU share that array: calls that overlap in time on one
+ * GPU (two streams, two threads) race; calls on one stream do not. */
+int mdnvae_mdn_outer_fwdbwd_static(const float* nodes, const float* x, const float* gate_logits,
+                                   const float* log_sigma, int B, int K, int N, const float* mu, const float* logvar,
+                                   int L, float* grad_nodes, float* grad_logits, float* grad_log_sigma_rows,
+                                   float* grad_mu, float* grad_logvar, float* resp, int x_symmetric, float* loss_out,
+                                   void* stream);
 int mdnvae_mdn_loss_bwd(const float* comp_mean, const float* x, const float* gate_logits, const float* log_sigma,
                         const float* resp, const float* sumsq, int B, int K, int D, const float* mu,
                         const float* logvar, int L, const float* grad_loss, float* grad_comp, float* grad_logits,

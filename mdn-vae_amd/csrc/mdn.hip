@@ -19,6 +19,7 @@
 // forward.
 #include "common.h"
 #include "../../include/mdnvae_hip.h"
+#include <mutex>
 
 namespace mdnvae {
 
@@ -535,6 +536,42 @@ static unsigned mdn_grid(int B) {
     return (unsigned)(blocks < MDN_MAX_BLOCKS_N ? blocks : MDN_MAX_BLOCKS_N);
 }
 
+// ---- static scratch of the entry point that allocates nothing ----
+// Two doubles per sample (likelihood term, KL term) for at most MDN_STATIC_MAX_B samples: 1 MiB that
+// every GPU the library runs on holds until the process ends.  In host code the array's name is
+// only a stand-in; the device address comes from hipGetSymbolAddress, once per device.
+constexpr int MDN_STATIC_MAX_B = 65536;
+static __device__ __align__(256) double scratch[2 * MDN_STATIC_MAX_B];
+
+constexpr int MDN_MAX_DEVICES = 64;
+static std::mutex g_scratch_mutex;
+static double* g_scratch_ptr[MDN_MAX_DEVICES] = {};
+
+// Device address of `scratch` on the current device (looked up on the first call there).
+static int static_scratch(const char* fn, double** out) {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) {
+        ::mdnvae::set_error("%s: hipGetDevice failed: %s", fn, hipGetErrorString(e));
+        return (int)e;
+    }
+    MV_REQUIRE(dev >= 0 && dev < MDN_MAX_DEVICES, E_ARG, "%s: device ordinal %d outside 0..%d", fn, dev,
+               MDN_MAX_DEVICES - 1);
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[dev]) {
+        void* p = nullptr;
+        e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !p) {
+            ::mdnvae::set_error("%s: hipGetSymbolAddress(scratch) failed on device %d: %s", fn, dev,
+                                hipGetErrorString(e));
+            return e != hipSuccess ? (int)e : E_ARG;
+        }
+        g_scratch_ptr[dev] = static_cast<double*>(p);
+    }
+    *out = g_scratch_ptr[dev];
+    return 0;
+}
+
 extern "C" {
 
 // forward: 2 doubles per sample; backward: one float per (sample, component)
@@ -564,40 +601,68 @@ int mdnvae_mdn_loss_fwd(const float* comp_mean, const float* x, const float* gat
     return 0;
 }
 
-int mdnvae_mdn_outer_fwdbwd(const float* nodes, const float* x, const float* gate_logits, const float* log_sigma,
-                            int B, int K, int N, const float* mu, const float* logvar, int L, float* grad_nodes,
-                            float* grad_logits, float* grad_log_sigma_rows, float* grad_mu, float* grad_logvar,
-                            float* resp, int x_symmetric, void* workspace, float* loss_out, void* stream) {
-    MV_REQUIRE(B >= 0 && L >= 0, E_ARG, "mdnvae_mdn_outer_fwdbwd: bad size");
-    MV_REQUIRE(N >= 1 && N <= MO_NP - 1, E_SHAPE, "mdnvae_mdn_outer_fwdbwd: N = %d outside 1..%d", N, MO_NP - 1);
-    MV_REQUIRE(K >= 1 && K <= MDN_MAXK, E_SHAPE, "mdnvae_mdn_outer_fwdbwd: %d components (1..%d supported)", K,
-               MDN_MAXK);
-    MV_REQUIRE(workspace && loss_out, E_ARG, "mdnvae_mdn_outer_fwdbwd: workspace/loss_out is null");
-    hipStream_t st = (hipStream_t)stream;
+// Shared body of the two rank-one entry points: `per_sample` (2 doubles per sample) is either the
+// caller's workspace or this device's static scratch array.
+static int mdn_outer_launch(const char* fn, const float* nodes, const float* x, const float* gate_logits,
+                            const float* log_sigma, int B, int K, int N, const float* mu, const float* logvar, int L,
+                            float* grad_nodes, float* grad_logits, float* grad_log_sigma_rows, float* grad_mu,
+                            float* grad_logvar, float* resp, int x_symmetric, double* per_sample, float* loss_out,
+                            hipStream_t st) {
+    MV_REQUIRE(B >= 0 && L >= 0, E_ARG, "%s: bad size", fn);
+    MV_REQUIRE(N >= 1 && N <= MO_NP - 1, E_SHAPE, "%s: N = %d outside 1..%d", fn, N, MO_NP - 1);
+    MV_REQUIRE(K >= 1 && K <= MDN_MAXK, E_SHAPE, "%s: %d components (1..%d supported)", fn, K, MDN_MAXK);
+    MV_REQUIRE(per_sample && loss_out, E_ARG, "%s: workspace/loss_out is null", fn);
     if (B > 0) {
         MV_REQUIRE(nodes && x && gate_logits && log_sigma && grad_nodes && grad_logits && grad_log_sigma_rows && resp,
-                   E_ARG, "mdnvae_mdn_outer_fwdbwd: null pointer");
-        MV_REQUIRE(L == 0 || (mu && logvar), E_ARG, "mdnvae_mdn_outer_fwdbwd: mu/logvar is null");
-        MV_REQUIRE((grad_mu == nullptr) == (grad_logvar == nullptr), E_ARG,
-                   "mdnvae_mdn_outer_fwdbwd: grad_mu and grad_logvar come together");
+                   E_ARG, "%s: null pointer", fn);
+        MV_REQUIRE(L == 0 || (mu && logvar), E_ARG, "%s: mu/logvar is null", fn);
+        MV_REQUIRE((grad_mu == nullptr) == (grad_logvar == nullptr), E_ARG, "%s: grad_mu and grad_logvar come together",
+                   fn);
 #define CALL(KK)                                                                                                     \
     if (x_symmetric)                                                                                                 \
         hipLaunchKernelGGL((mdn_outer_kernel<KK, true>),                                                             \
                            dim3(mdn_outer_grid(B)),                                                                  \
                            dim3(MDN_NT), 0, st, nodes, x, gate_logits, log_sigma, B, N, mu, logvar, L, grad_nodes,   \
-                           grad_logits, grad_log_sigma_rows, grad_mu, grad_logvar, resp, (double*)workspace);        \
+                           grad_logits, grad_log_sigma_rows, grad_mu, grad_logvar, resp, per_sample);                \
     else                                                                                                             \
         hipLaunchKernelGGL((mdn_outer_kernel<KK, false>),                                                            \
                            dim3(mdn_outer_grid(B)),                                                                  \
                            dim3(MDN_NT), 0, st, nodes, x, gate_logits, log_sigma, B, N, mu, logvar, L, grad_nodes,   \
-                           grad_logits, grad_log_sigma_rows, grad_mu, grad_logvar, resp, (double*)workspace)
+                           grad_logits, grad_log_sigma_rows, grad_mu, grad_logvar, resp, per_sample)
         MV_MDN_DISPATCH(K, CALL)
 #undef CALL
         MV_LAUNCH_CHECK("mdn_outer_kernel");
     }
-    hipLaunchKernelGGL(mdn_finalize_kernel, dim3(1), dim3(PAIR_NT), 0, st, (const double*)workspace, B, loss_out);
+    hipLaunchKernelGGL(mdn_finalize_kernel, dim3(1), dim3(PAIR_NT), 0, st, (const double*)per_sample, B, loss_out);
     MV_LAUNCH_CHECK("mdn_finalize_kernel");
     return 0;
+}
+
+int mdnvae_mdn_outer_fwdbwd(const float* nodes, const float* x, const float* gate_logits, const float* log_sigma,
+                            int B, int K, int N, const float* mu, const float* logvar, int L, float* grad_nodes,
+                            float* grad_logits, float* grad_log_sigma_rows, float* grad_mu, float* grad_logvar,
+                            float* resp, int x_symmetric, void* workspace, float* loss_out, void* stream) {
+    return mdn_outer_launch("mdnvae_mdn_outer_fwdbwd", nodes, x, gate_logits, log_sigma, B, K, N, mu, logvar, L,
+                            grad_nodes, grad_logits, grad_log_sigma_rows, grad_mu, grad_logvar, resp, x_symmetric,
+                            (double*)workspace, loss_out, (hipStream_t)stream);
+}
+
+int mdnvae_mdn_outer_fwdbwd_static(const float* nodes, const float* x, const float* gate_logits,
+                                   const float* log_sigma, int B, int K, int N, const float* mu, const float* logvar,
+                                   int L, float* grad_nodes, float* grad_logits, float* grad_log_sigma_rows,
+                                   float* grad_mu, float* grad_logvar, float* resp, int x_symmetric, float* loss_out,
+                                   void* stream) {
+    MV_REQUIRE(B <= MDN_STATIC_MAX_B, E_SHAPE,
+               "mdnvae_mdn_outer_fwdbwd_static: B = %d exceeds the static scratch (at most %d samples per call); "
+               "use mdnvae_mdn_outer_fwdbwd with a workspace",
+               B, MDN_STATIC_MAX_B);
+    double* per_sample = nullptr;
+    if (int rc = static_scratch("mdnvae_mdn_outer_fwdbwd_static", &per_sample)) return rc;
+    // every sample's pair is written by the sweep before the finalize launch (same stream) reads it,
+    // so nothing of the previous call's contents has to be cleared
+    return mdn_outer_launch("mdnvae_mdn_outer_fwdbwd_static", nodes, x, gate_logits, log_sigma, B, K, N, mu, logvar,
+                            L, grad_nodes, grad_logits, grad_log_sigma_rows, grad_mu, grad_logvar, resp, x_symmetric,
+                            per_sample, loss_out, (hipStream_t)stream);
 }
 
 int mdnvae_mdn_loss_bwd(const float* comp_mean, const float* x, const float* gate_logits, const float* log_sigma,
