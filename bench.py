@@ -378,7 +378,8 @@ def run_workload(model_name, batch, nodes, steps, warmup, pool_batches, device, 
         if world > 1 or REHEARSE_EXCHANGE:
             dist.barrier()
         torch.cuda.synchronize()
-        el = torch.tensor([time.perf_counter() - t0], device=device, dtype=torch.float64)
+        staged = (world > 1 or REHEARSE_EXCHANGE) and dist.get_backend() == "gloo"
+        el = torch.tensor([time.perf_counter() - t0], device="cpu" if staged else device, dtype=torch.float64)
         if world > 1 or REHEARSE_EXCHANGE:
             dist.all_reduce(el, op=dist.ReduceOp.MAX)
         return float(el.item()), out
@@ -429,9 +430,10 @@ def main():
     ap.add_argument("--no-overlap", action="store_true", help="all-reduce every gradient after backward")
     ap.add_argument("--full-first-layer", action="store_true",
                     help="FNN-encoder models: run the first layers on all N*N entries instead of the packed triangle")
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL).  gloo on device tensors "
-                                                      "hung in this image when two ranks shared one GPU, so the "
-                                                      "multi-rank path is rehearsed on the CPU by tests/test_trainer_cpu.py")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend (nccl = RCCL over xGMI).  gloo is a rehearsal path (ranks may share "
+                         "a GPU): the trainer stages device buffers through pinned host memory for it, because gloo's "
+                         "own handling of device tensors aborted / stalled in this image")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -387,7 +387,7 @@ int mdnvae_trace_norm(const double* a, int d, double* out2, void* stream);
  * function/VAE_CNN_NN.py:268-271: max_value = real.max(); real/max_value; max(generated/max_value, 0);
  * :273-289: per-matrix mean squared error behind compute_mse / compute_psnr. */
 size_t mdnvae_max_workspace_floats(void);
-/* out[0] = max(x[0..n)); inputs finite. */
+/* out[0] = max(x[0..n)) with np.max semantics: a NaN anywhere gives NaN.  x 4-byte aligned. */
 int mdnvae_max(const float* x, long n, float* workspace, float* out, void* stream);
 /* out = x / denom[0] (denom on the device), clamped below at `lo` when clamp != 0. */
 int mdnvae_div_clamp(const float* x, const float* denom, int clamp, float lo, long n, float* out, void* stream);

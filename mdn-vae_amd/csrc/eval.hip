@@ -19,25 +19,44 @@ __device__ __forceinline__ float block_max(float v, float* scratch) {
     return r;
 }
 
+// 16-byte loads at 4-byte alignment (the hardware's unaligned access mode): a view that starts at any
+// float of a larger tensor (a test split of 87 x 87 rows) is read as it is.
+typedef float max_v4 __attribute__((ext_vector_type(4)));
+typedef max_v4 max_v4u __attribute__((aligned(4)));
+
+// np.max semantics: a NaN anywhere makes the maximum NaN (fmaxf alone would drop it).
 __global__ __launch_bounds__(256) void max_partial_kernel(const float* __restrict__ x, long n, float* __restrict__ part) {
     __shared__ float scratch[4];
     float m = -INFINITY;
+    bool nan = false;
     const long n4 = n >> 2;
-    const float4* x4 = reinterpret_cast<const float4*>(x);
+    const max_v4u* x4 = reinterpret_cast<const max_v4u*>(x);
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
-        const float4 v = x4[i];
+        const max_v4 v = x4[i];
+        nan |= (v.x != v.x) | (v.y != v.y) | (v.z != v.z) | (v.w != v.w);
         m = fmaxf(fmaxf(m, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
     }
-    for (long i = (n4 << 2) + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) m = fmaxf(m, x[i]);
+    for (long i = (n4 << 2) + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float v = x[i];
+        nan |= v != v;
+        m = fmaxf(m, v);
+    }
     m = block_max(m, scratch);
-    if (threadIdx.x == 0) part[blockIdx.x] = m;
+    const int any_nan = __syncthreads_or(nan);
+    if (threadIdx.x == 0) part[blockIdx.x] = any_nan ? NAN : m;
 }
 __global__ __launch_bounds__(256) void max_final_kernel(const float* __restrict__ part, int nparts, float* __restrict__ out) {
     __shared__ float scratch[4];
     float m = -INFINITY;
-    for (int i = threadIdx.x; i < nparts; i += 256) m = fmaxf(m, part[i]);
+    bool nan = false;
+    for (int i = threadIdx.x; i < nparts; i += 256) {
+        const float v = part[i];
+        nan |= v != v;
+        m = fmaxf(m, v);
+    }
     m = block_max(m, scratch);
-    if (threadIdx.x == 0) out[0] = m;
+    const int any_nan = __syncthreads_or(nan);
+    if (threadIdx.x == 0) out[0] = any_nan ? NAN : m;
 }
 
 // out = x / denom[0], optionally clamped from below at `lo`
@@ -75,7 +94,7 @@ size_t mdnvae_max_workspace_floats(void) { return MAX_PARTS; }
 int mdnvae_max(const float* x, long n, float* workspace, float* out, void* stream) {
     MV_REQUIRE(n >= 1, E_ARG, "mdnvae_max: empty input has no maximum");
     MV_REQUIRE(x && workspace && out, E_ARG, "mdnvae_max: null pointer");
-    MV_REQUIRE(aligned16(x), E_ALIGN, "mdnvae_max: input must be 16-byte aligned");
+    MV_REQUIRE((reinterpret_cast<uintptr_t>(x) & 3u) == 0, E_ALIGN, "mdnvae_max: input must be 4-byte aligned");
     long g = (n / 4 + 255) / 256;
     const int parts = (int)(g > MAX_PARTS ? MAX_PARTS : (g < 1 ? 1 : g));
     hipLaunchKernelGGL(max_partial_kernel, dim3(parts), dim3(256), 0, (hipStream_t)stream, x, n, workspace);

@@ -65,7 +65,8 @@ class FeatureStats:
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
             flat = torch.cat([self.sum, self.gram.reshape(-1),
                               torch.tensor([float(self.n)], dtype=torch.float64, device=self.device)])
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+            from .trainer import all_reduce_sum_
+            all_reduce_sum_(flat, group)       # device memory under RCCL, staged through the host under gloo
             self.sum = flat[: self.dim].contiguous()
             self.gram = flat[self.dim: self.dim + self.dim * self.dim].reshape(self.dim, self.dim).contiguous()
             self.n = int(round(float(flat[-1])))

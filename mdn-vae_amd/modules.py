@@ -274,10 +274,22 @@ class MultiChannelGCNDecoder(nn.Module):
         self.init_fc = nn.ModuleList([Linear(latent_dim, n_nodes) for _ in range(R)])
         self.channel_gcns = nn.ModuleList([ChannelGCN(n_nodes, k, n_layers) for _ in range(R)])
         self._adj_key = None
+        self._adj_ident = None
+        self._adj_src = None
         self._adj = None
         self._spec = None
 
     def _adjacency(self, adjacency, device):
+        """int32 device copy of the adjacency and the chain spec built on it.  The conversion (a host
+        list walk, or a device-to-host copy for a tensor) runs only when the object changes: the same
+        list object, or the same tensor storage at the same version, is a cache hit - so a step
+        issues no host synchronisation for it and can be captured into a HIP graph."""
+        if isinstance(adjacency, torch.Tensor):
+            ident = ("t", adjacency.data_ptr(), adjacency._version, tuple(adjacency.shape), str(device))
+        else:
+            ident = ("o", id(adjacency), len(adjacency), str(device))
+        if ident == self._adj_ident and self._adj is not None:
+            return self._adj
         arr = np.asarray([list(map(int, a)) for a in adjacency], dtype=np.int32) if not isinstance(adjacency, torch.Tensor) \
             else adjacency.detach().cpu().numpy().astype(np.int32)
         key = (arr.tobytes(), str(device))
@@ -291,6 +303,8 @@ class MultiChannelGCNDecoder(nn.Module):
             layers = [dict(kind="linear", act=None)] + [dict(kind="gcn", act="sigmoid", adj=self._adj)
                                                         for _ in range(self.n_layers)]
             self._spec = ops.ChainSpec(self.n_nodes, self.latent_dim, self.R, layers, epi_act=None, xlat_channels=0)
+        self._adj_ident = ident
+        self._adj_src = adjacency        # keeps the object alive so its id() stays its own
         return self._adj
 
     def components(self, z, adjacency):

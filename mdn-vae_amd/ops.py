@@ -143,8 +143,10 @@ def _grad_target(param):
     """The `.grad` tensor the active sink may add into, or None."""
     if _SINK is None or param is None:
         return None
+    if not isinstance(param, torch.nn.Parameter) or not param.is_leaf:
+        return None          # e.g. weight * mask: autograd carries the gradient to the leaf itself
     g = getattr(param, "grad", None)
-    if g is None or not g.is_cuda or g.dtype != torch.float32 or g.shape != param.shape or not g.is_contiguous():
+    if g is None or g.dtype != torch.float32 or g.shape != param.shape or not g.is_contiguous():
         return None
     return g
 

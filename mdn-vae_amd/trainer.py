@@ -62,6 +62,40 @@ class FlatBuffers:
 MIN_RANKS_FOR_EXCHANGE = 2
 
 
+class _Done:
+    """A finished collective (what the host-staged path returns where RCCL returns a Work)."""
+
+    def wait(self):
+        return True
+
+
+_HOST_STAGE = {}
+
+
+def _host_staged(group):
+    """gloo moves host memory.  Its own handling of device tensors is not dependable in this image
+    (two ranks on one GPU: an all-reduce left pending while others were issued and waited for first
+    never completed; an earlier run aborted inside the call), so for a gloo group device buffers are
+    copied to pinned host memory, summed there and copied back.  RCCL ("nccl") takes device memory."""
+    return dist.get_backend(group) == "gloo"
+
+
+def all_reduce_sum_(t, group=None, async_op=False):
+    """In-place SUM all-reduce of one contiguous tensor; returns an object with .wait()."""
+    if t.is_cuda and _host_staged(group):
+        n = t.numel()
+        host = _HOST_STAGE.get(t.dtype)
+        if host is None or host.numel() < n:
+            host = _HOST_STAGE[t.dtype] = torch.empty(max(n, 1 << 20), dtype=t.dtype, pin_memory=True)
+        view = host[:n].view(t.shape)
+        view.copy_(t)                                  # blocking: the producing kernels have finished
+        dist.all_reduce(view, op=dist.ReduceOp.SUM, group=group)
+        t.copy_(view)
+        return _Done()
+    work = dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+    return work if async_op else _Done()
+
+
 def allreduce_sum(flat, group=None, bucket_floats=8 << 20):
     """In-place SUM all-reduce of a flat buffer in buckets of `bucket_floats` (32 MiB): large
     enough that each xGMI ring step moves megabytes, small enough to pipeline."""
@@ -69,7 +103,7 @@ def allreduce_sum(flat, group=None, bucket_floats=8 << 20):
         return
     works = []
     for o in range(0, flat.numel(), bucket_floats):
-        works.append(dist.all_reduce(flat[o:o + bucket_floats], op=dist.ReduceOp.SUM, group=group, async_op=True))
+        works.append(all_reduce_sum_(flat[o:o + bucket_floats], group, async_op=True))
     for w in works:
         w.wait()
 
@@ -126,7 +160,9 @@ class Trainer:
         self._hook_of = {}          # id(param) -> its early all-reduce hook
         self._pending = []          # async all-reduces launched from hooks during backward
         self._folded = []           # (all-reduce, folded gradient [T,H], param, n_nodes) awaiting their unfold
-        self._rest = [(0, self.buf.numel)]   # flat ranges still to be reduced after backward
+        # flat ranges still to be reduced after backward; the unfolded gradient region of the
+        # folded-Adam weights is never written or read inside step(), so it is not exchanged either
+        self._rest = [(self._fold_end, self.buf.numel)]
         if _distributed(group) and overlap_floats:
             self._install_overlap_hooks(overlap_floats)
 
@@ -138,8 +174,10 @@ class Trainer:
                 hook = self._make_hook(o, p.numel())
                 p.register_post_accumulate_grad_hook(hook)
                 self._hook_of[id(p)] = hook      # the direct-gradient path calls it itself
-        rest, pos = [], 0
+        rest, pos = [], self._fold_end
         for lo, hi in sorted(early):
+            if hi <= pos:
+                continue
             if lo > pos:
                 rest.append((pos, lo))
             pos = hi
@@ -153,7 +191,7 @@ class Trainer:
             if param.grad.data_ptr() != flat.data_ptr():      # autograd replaced the view: copy back
                 flat.copy_(param.grad.reshape(-1))
                 param.grad = flat.view(param.shape)
-            self._pending.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            self._pending.append(all_reduce_sum_(flat, self.group, async_op=True))
         return hook
 
     def forward_backward(self, inputs, target, eps=None, _defer_fold=False):
@@ -192,7 +230,7 @@ class Trainer:
             if not self._defer_fold:         # a caller outside step() may read .grad
                 call("mdnvae_tri_unfold", ptr(gt), gt.shape[1], n_nodes, gt.shape[1], 1, ptr(param.grad), 1, stream())
         elif hooked:
-            work = dist.all_reduce(gt, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            work = all_reduce_sum_(gt, self.group, async_op=True)
         else:                                # below the early-exchange size: summed where it is consumed
             work = "late"
         self._folded.append((work, gt, param, n_nodes))
@@ -255,7 +293,7 @@ class Trainer:
         folded = []
         for work, gt, param, n_nodes in self._folded:
             if work == "late":
-                dist.all_reduce(gt, op=dist.ReduceOp.SUM, group=self.group)
+                all_reduce_sum_(gt, self.group)
             elif work is not None:
                 work.wait()
             if id(param) in self._fold:
@@ -326,6 +364,7 @@ class Trainer:
         for dst, src in zip(state, keep):
             dst.copy_(src)
         self._g_step.fill_(self.steps)
+        self._g_step_holds = self.steps      # the count the device counter holds
         return self
 
     def replay(self, inputs, target, eps):
@@ -337,8 +376,11 @@ class Trainer:
         if self._g_target is not self._g_inputs[0]:
             self._g_target.copy_(target)
         self._g_eps.copy_(eps)
+        if self._g_step_holds != self.steps:     # eager steps since the last replay moved the host count on
+            self._g_step.fill_(self.steps)
         self._graph.replay()
         self.steps += 1
+        self._g_step_holds = self.steps
         return self._g_loss
 
     def hinge_step(self, fc, sc, eps_with=None, eps_without=None, generator=None, margin=0.01):

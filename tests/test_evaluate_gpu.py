@@ -35,6 +35,30 @@ def test_normalise_mse_psnr(M, n, cols):
     assert M.evaluate.compute_psnr(r_got, g_got) == pytest.approx(want_psnr, rel=1e-6)
 
 
+@pytest.mark.parametrize("n_train", [1, 2, 3, 4])
+def test_normalise_on_a_split_that_starts_at_any_float(M, n_train):
+    """The test split of 87 x 87 rows (7569 floats each) starts 16-byte aligned only when n_train is
+    a multiple of 4; the maximum behind the normalisation must take the view as it is."""
+    rng = np.random.default_rng(n_train)
+    rows = rng.gamma(0.3, 2.0, (7, 87 * 87)).astype(np.float32)
+    dev = torch.from_numpy(rows).cuda()
+    test = dev[n_train:]                          # what data.train_test_split hands back: a view
+    real, gen = test, (test * 0.9).contiguous()
+    r_want, g_want = R.normalise_for_metrics(rows[n_train:], rows[n_train:] * np.float32(0.9))
+    r_got, g_got = M.evaluate.normalise_for_metrics(real, gen)
+    assert np.array_equal(r_got.cpu().numpy(), r_want) and np.array_equal(g_got.cpu().numpy(), g_want)
+
+
+def test_maximum_propagates_nan_like_numpy(M):
+    x = torch.rand(3, 1001, device="cuda")
+    assert float(M.evaluate._max(x)) == float(x.max())
+    x[1, 17] = float("nan")
+    assert np.isnan(float(M.evaluate._max(x)))
+    x[1, 17] = 0.0
+    x[2, 1000] = float("nan")                    # in the tail past the last whole quad
+    assert np.isnan(float(M.evaluate._max(x)))
+
+
 def test_identical_inputs_have_zero_mse(M):
     x = torch.rand(4, 100, device="cuda")
     assert float(M.evaluate.matrix_mse(x, x).abs().max()) == 0.0

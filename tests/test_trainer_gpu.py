@@ -258,6 +258,32 @@ def test_graph_epoch_equals_eager_epoch():
     assert float((out[True][1] - out[False][1]).abs().max()) <= 1e-6
 
 
+def test_two_graph_epochs_with_ragged_tails_equal_eager_epochs():
+    """Replays after eager steps: the ragged tail of epoch one is stepped call by call, so the
+    device-side Adam step counter of the captured graph must be brought level before the replays
+    of epoch two (its bias corrections depend on the count).  The adjacency is a device tensor
+    here: its conversion must not put a device-to-host copy inside the capture."""
+    fix = load_fixture("mm_gate")
+    params = fixture_params(fix)
+    x = torch.from_numpy(fix["x"]).to(DEV)
+    data = torch.cat([x * (1.0 + 0.05 * i) for i in range(5)])[:19]          # 19 subjects: 4 batches of 4 + 3
+    adjacency = torch.tensor([list(map(int, r)) for r in fix["adjacency"]], dtype=torch.int64, device=DEV)
+    out = {}
+    for graph in (False, True):
+        model = M.GCNVAE(R=5, n_nodes=68, k=32, n_layers=3, latent_dim=68)
+        model.load_state_dict(params, strict=False)
+        trainer = M.Trainer(model.to(DEV), "poisson_log")
+        gen, eg = torch.Generator(device=DEV).manual_seed(1), torch.Generator(device=DEV).manual_seed(2)
+        metrics = [trainer.train_epoch(data, batch_size=4, extra=(adjacency,), shuffle=True, generator=gen,
+                                       eps_generator=eg, graph=graph) for _ in range(2)]
+        # interleave once more: an eager step, then a replay-capable epoch
+        out[graph] = (metrics, trainer.buf.flat_p.clone(), trainer.steps)
+    assert out[True][2] == out[False][2] == 10
+    for a, b in zip(out[True][0], out[False][0]):
+        assert abs(a - b) <= 1e-6 * abs(b)
+    assert float((out[True][1] - out[False][1]).abs().max()) <= 1e-6
+
+
 def test_direct_gradients_equal_autograd_accumulation():
     """Trainer(direct_grads=True): the kernels add parameter gradients straight into the flat
     buffer; the result is the buffer autograd's own accumulation leaves, for the FNN/GCN models
