@@ -20,6 +20,7 @@
 #include "common.h"
 #include "../../include/mdnvae_hip.h"
 #include <mutex>
+#include <type_traits>
 
 namespace mdnvae {
 
@@ -50,6 +51,7 @@ __device__ __forceinline__ MixtureExponent mixture_exponent(bool owner, float ss
 // Rows of D floats start at arbitrary 4-byte phases when D is not a multiple of 4 (87*87 = 7569);
 // the hardware takes 16-byte vector accesses at any 4-byte aligned address, so rows are walked as
 // quads of their own elements through this 4-byte aligned vector type.
+#define MV_LDS_PTR_(p) ((__attribute__((address_space(3))) void*)(p))
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef v4f v4fu __attribute__((aligned(4)));
 
@@ -507,6 +509,384 @@ __global__ __launch_bounds__(MDN_NT) void mdn_outer_kernel(const float* __restri
     }
 }
 
+
+// ---- symmetric targets, second form: the sample's matrix streamed through wave-private LDS ----
+// For symmetric x and m = g g^T everything the likelihood and its gradient need follows from the
+// K matrix-vector products y_k = x g_k and the sum of squares of x:
+//   ss_k        = sum_ij (g_i g_j - x_ij)^2 = |g_k|^4 - 2 g_k.y_k + sum_ij x_ij^2
+//   (r_k g_k)_c = g_kc |g_k|^2 - y_kc                   (row sums = column sums)
+// so a row of x costs one packed multiply-add per component, a third of forming the residual.
+// Every input of a sample arrives through ONE in-order stream of LDS-DMA operations per wave: the
+// node vectors (1 KiB pieces, 16 bytes per lane, into a header area), the gate row and the latent
+// rows (4 bytes per lane), then x[b] as a flat run of 1 KiB pieces that starts at the 128-byte
+// boundary at or below its first element (whole cache lines per piece), into a ring of MS_RING pieces; MS_AHEAD steps are in
+// flight and the stream runs on into the wave's next sample without a gap.  The only wait is the
+// issuing wave's own counted vmcnt; no other load is issued inside the loop and the result stores
+// are counted exactly, so nothing drains the stream.  N is a template parameter: the whole schedule
+// of a sample (which piece goes to which ring slot, which rows are complete after which piece, every
+// LDS offset) is fixed at compile time and the loop body has no control flow and next to no scalar
+// arithmetic - with N at run time the kernel spent more time on that than on the stream.  Lane c
+// owns columns c and c+64 as one packed pair.  The piece in ring slot 0 is also written to a mirror
+// slot behind the last one, so a row that starts in the last slot reads on without wrapping.  After
+// the sweep every per-component quantity is uniform over the wave (sums by DPP, no LDS), so the
+// log-sum-exp over the components is plain arithmetic.
+#ifndef MS_AHEAD_N
+#define MS_AHEAD_N 4
+#endif
+#ifndef MS_RING_N
+#define MS_RING_N 8
+#endif
+#ifndef MS_WAVES_N
+#define MS_WAVES_N 4
+#endif
+#ifndef MS_NT_N
+#define MS_NT_N 1
+#endif
+#ifndef MS_BURST_N
+#define MS_BURST_N 1
+#endif
+#ifndef MS_ALIGN_N
+#define MS_ALIGN_N 128
+#endif
+constexpr int MS_ALIGN = MS_ALIGN_N;                 // bytes a sample's run is aligned down to (16 .. 128)
+constexpr int MS_SLACK = MS_ALIGN / 4 - 1;           // floats the sample's first element can lie into its run
+constexpr int MS_BURST = MS_BURST_N;                 // steps issued back to back (a contiguous run of that many KiB)
+constexpr int MS_AHEAD = MS_AHEAD_N;                 // stream steps in flight per wave, at least
+constexpr int MS_RING = MS_RING_N;                   // ring slots (power of two, >= MS_AHEAD + 2)
+constexpr int MS_WAVES = MS_WAVES_N;                 // waves per workgroup
+constexpr int MS_PIECE = 256;                        // floats per piece (64 lanes x 16 bytes)
+constexpr int MS_RINGF = MS_RING * MS_PIECE;
+constexpr int MS_GS = 8;                             // floats per row of the broadcast table (K <= 8)
+constexpr int MS_MAXL = 128;                         // latent width this sweep takes
+static_assert((MS_RING & (MS_RING - 1)) == 0 && MS_RING >= MS_AHEAD + MS_BURST + 1, "ring too small for the steps in flight");
+// steps of a sample (and the first MS_AHEAD of the next) issued once consumer step c has issued its share
+__host__ __device__ constexpr int ms_issued_upto(int c, int steps) {
+    const int e = c - c % MS_BURST + MS_AHEAD + MS_BURST;
+    return e < steps + MS_AHEAD ? e : steps + MS_AHEAD;
+}
+__host__ __device__ constexpr int ms_hdr_pieces(int K) { return (K * MO_NP + MS_PIECE - 1) / MS_PIECE; }
+// header: node vectors [K][MO_NP] as they lie in memory, gate row (64), mu (128), logvar (128)
+__host__ __device__ constexpr int ms_hdr_floats(int K) { return ms_hdr_pieces(K) * MS_PIECE + 64 + 2 * MS_MAXL; }
+// per wave: ring + mirror slot, header, broadcast table
+__host__ __device__ constexpr int ms_wave_floats(int K) {
+    return MS_RINGF + MS_PIECE + ms_hdr_floats(K) + MO_NP * MS_GS;
+}
+// pieces of x per sample: enough for any phase of its first element, rounded up to whole turns of
+// the ring so that every sample's run starts in slot 0 (the surplus pieces re-read one granule)
+__host__ __device__ constexpr int ms_x_pieces_used(int N) { return (MS_SLACK + N * N + MS_PIECE - 1) / MS_PIECE; }
+__host__ __device__ constexpr int ms_x_pieces(int N) { return (ms_x_pieces_used(N) + MS_RING - 1) / MS_RING * MS_RING; }
+// the piece after whose arrival row r is complete whatever the phase (worst case: MS_SLACK floats)
+__host__ __device__ constexpr int ms_row_piece(int r, int N) { return (MS_SLACK + (r + 1) * N - 1) / MS_PIECE; }
+// first row that is NOT complete after piece p
+__host__ __device__ constexpr int ms_rows_after(int p, int N) {
+    int r = 0;
+    while (r < N && ms_row_piece(r, N) <= p) ++r;
+    return r;
+}
+
+// One LDS-DMA operation: lane l copies BYTES (16 or 4) from base + off to lds_base + BYTES * l (base
+// uniform, off per lane).  The wait for it is the issuing wave's own counted vmcnt (ms_wait); the
+// compiler does not see these loads.
+template <int BYTES>
+__device__ __forceinline__ void ms_dma(const void* base, unsigned off, unsigned lds_base) {
+    unsigned keep;
+    if constexpr (BYTES == 16) {
+#if MS_NT_N
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(off), "s"(base), "s"(lds_base) : "memory");
+#else
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(off), "s"(base), "s"(lds_base) : "memory");
+#endif
+    } else {
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(off), "s"(base), "s"(lds_base) : "memory");
+    }
+}
+template <int N_LEFT>
+__device__ __forceinline__ void ms_wait() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_LEFT) : "memory");
+}
+// Result stores of the streamed sweep, one instruction each by construction: vmcnt counts stores and
+// LDS-DMA operations together, in issue order, so the waits must know exactly how many stores lie
+// between the pieces they wait for and the newest operation.
+__device__ __forceinline__ void ms_store(float* p, float v) {
+    asm volatile("global_store_dword %0, %1, off" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void ms_store(double* p, double v) {
+    asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(p), "v"(v) : "memory");
+}
+// sum over the wave, the same value in every lane (DPP adds, then one lane read)
+__device__ __forceinline__ float ms_sum(float v) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wave_sum_dpp(v)), 63));
+}
+template <int I, int E, typename F>
+__device__ __forceinline__ void ms_static_for(F&& f) {
+    if constexpr (I < E) {
+        f(std::integral_constant<int, I>{});
+        ms_static_for<I + 1, E>(f);
+    }
+}
+// The uniform addresses of one sample's inputs.
+struct MsSample {
+    const char* xrun;      // 16-byte aligned start of the run of x
+    unsigned xlast;        // offset in the run of the last granule that holds an element of the sample
+    const char* nodes;     // its node vectors
+    const float *gate, *mu, *lv;
+};
+
+template <int K, int N>
+__global__ __launch_bounds__(MS_WAVES * 64) void mdn_outer_sym_kernel(
+    const float* __restrict__ nodes, const float* __restrict__ x, const float* __restrict__ logits,
+    const float* __restrict__ log_sigma, int B, const float* __restrict__ mu, const float* __restrict__ logvar, int L,
+    float* __restrict__ gnodes, float* __restrict__ glogits, float* __restrict__ glsig_rows, float* __restrict__ gmu,
+    float* __restrict__ glogvar, float* __restrict__ resp, double* __restrict__ per_sample) {
+    constexpr int HP = ms_hdr_pieces(K), TPX = ms_x_pieces(N), STEPS = HP + 1 + TPX, D = N * N;
+    static_assert(N <= MO_NP - 1 && N >= 64 && STEPS > MS_AHEAD, "shape outside the streamed sweep");
+    __shared__ __attribute__((aligned(1024))) float lds[MS_WAVES * ms_wave_floats(K)];
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wave = blockIdx.x * MS_WAVES + wid;
+    const int nwaves = gridDim.x * MS_WAVES;
+    if (wave >= B) return;
+    float* ring = lds + wid * ms_wave_floats(K);                 // [MS_RING + 1 slots][MS_PIECE]
+    float* hdr = ring + MS_RINGF + MS_PIECE;                       // node vectors | gate row | mu | logvar
+    float* h_gate = hdr + HP * MS_PIECE;
+    float* h_mu = h_gate + 64;
+    float* h_lv = h_mu + MS_MAXL;
+    float* gs = hdr + ms_hdr_floats(K);                            // [row][MS_GS]
+    const unsigned ring_base = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)MV_LDS_PTR_(ring));
+    const unsigned hdr_base = ring_base + (MS_RINGF + MS_PIECE) * 4;
+    const unsigned gate_base = hdr_base + HP * MS_PIECE * 4;
+    constexpr bool HAS1 = N > 64;                                  // N >= 64: every lane owns column `lane`
+    const bool c1 = lane + 64 < N;
+    const unsigned lane16 = lane * 16;
+    // lanes of the last header piece that lie past the sample's node vectors re-read its last granule
+    const unsigned noff_last = min(lane16, (unsigned)(K * MO_NP * 4 - 16 - (HP - 1) * MS_PIECE * 4));
+    const unsigned goff = (lane < K ? lane : K - 1) * 4;
+    const unsigned loff0 = (lane < L ? lane : L - 1) * 4, loff1 = (lane + 64 < L ? lane + 64 : L - 1) * 4;
+
+    float ls[K], is2[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        ls[k] = log_sigma[k];
+        is2[k] = expf(-2.0f * ls[k]);
+    }
+    ms_wait<0>();      // from here on the only vector-memory operations are the stream's and the result stores
+
+    auto sample_at = [&](int b) {
+        MsSample sm;
+        const unsigned long a = reinterpret_cast<unsigned long>(x + (long)b * D);
+        sm.xrun = reinterpret_cast<const char*>(a & ~(unsigned long)(MS_ALIGN - 1));
+        sm.xlast = (unsigned)((((a & (unsigned long)(MS_ALIGN - 1)) + (unsigned long)D * 4ul) - 1ul) & ~15ul);
+        sm.nodes = reinterpret_cast<const char*>(nodes + (long)b * K * MO_NP);
+        sm.gate = logits + (long)b * K;
+        sm.mu = mu + (long)b * L;
+        sm.lv = logvar + (long)b * L;
+        return sm;
+    };
+    // step j of a sample's part of the stream: HP header pieces, the small rows, TPX pieces of x
+    auto issue = [&](const MsSample& sm, auto jc) {
+        constexpr int j = decltype(jc)::value;
+        if constexpr (j < HP - 1) {
+            ms_dma<16>(sm.nodes + j * (MS_PIECE * 4), lane16, hdr_base + j * (MS_PIECE * 4));
+        } else if constexpr (j == HP - 1) {
+            ms_dma<16>(sm.nodes + j * (MS_PIECE * 4), noff_last, hdr_base + j * (MS_PIECE * 4));
+        } else if constexpr (j == HP) {
+            ms_dma<4>(sm.gate, goff, gate_base);
+            ms_dma<4>(sm.mu, loff0, gate_base + 64 * 4);
+            ms_dma<4>(sm.mu, loff1, gate_base + 128 * 4);
+            ms_dma<4>(sm.lv, loff0, gate_base + (64 + MS_MAXL) * 4);
+            ms_dma<4>(sm.lv, loff1, gate_base + (128 + MS_MAXL) * 4);
+        } else {
+            constexpr int p = j - HP - 1, slot = p & (MS_RING - 1);
+            // lanes past the sample's last granule (and all lanes of a surplus piece) re-read it
+            const unsigned off = min(lane16 + (unsigned)(p * MS_PIECE * 4), sm.xlast);
+            // the mirror copy first: once the piece itself counts as landed, so does its mirror
+            if constexpr (slot == 0) ms_dma<16>(sm.xrun, off, ring_base + MS_RINGF * 4);
+            ms_dma<16>(sm.xrun, off, ring_base + slot * (MS_PIECE * 4));
+        }
+    };
+    // After a sample's result stores (S of them, all younger than the MS_AHEAD steps then in flight)
+    // the next MS_AHEAD waits leave those stores outstanding as well.
+    constexpr int S_PLAIN = 2 * K + 5, S_LATENT = S_PLAIN + 4;
+    const bool latent_grads = gmu != nullptr;
+
+    // wave w takes samples w, w + nwaves, ...: at any time the waves work on one contiguous window of x
+    // (one consecutive block of samples per wave was measured 4 % slower)
+    const int b_begin = wave, b_end = B, b_step = nwaves;
+    MsSample cur = sample_at(b_begin);
+    ms_static_for<0, MS_AHEAD>([&](auto jc) { issue(cur, jc); });
+    bool first = true;
+    for (int b = b_begin; b < b_end; b += b_step) {
+        // past its last sample the stream re-reads this sample's first steps: harmless, a few KB per wave
+        const MsSample nxt = sample_at(b + b_step < b_end ? b + b_step : b);
+        const int shift = (int)((reinterpret_cast<unsigned long>(x + (long)b * D) & (unsigned long)(MS_ALIGN - 1)) >> 2);
+        // one more step goes out, then all but the MS_AHEAD youngest operations (and the stores
+        // behind them) have completed: step c of this sample is in LDS
+        auto step = [&](auto cc) {
+            constexpr int c = decltype(cc)::value;
+            if constexpr (c % MS_BURST == 0) {
+                ms_static_for<c + MS_AHEAD, ms_issued_upto(c, STEPS)>([&](auto tc) {
+                    constexpr int t = decltype(tc)::value;
+                    if constexpr (t < STEPS) issue(cur, tc);
+                    else issue(nxt, std::integral_constant<int, t - STEPS>{});
+                });
+            }
+            constexpr int W = ms_issued_upto(c, STEPS) - (c + 1);       // steps younger than step c
+            if constexpr (c < MS_AHEAD) {
+                if (first) ms_wait<W>();
+                else if (latent_grads) ms_wait<W + S_LATENT>();
+                else ms_wait<W + S_PLAIN>();
+            } else {
+                ms_wait<W>();
+            }
+        };
+        // ---- header: node vectors -> registers (own columns) and the broadcast table gs[row][k] ----
+        ms_static_for<0, HP + 1>(step);
+        mo_v2 g[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            g[k].x = hdr[k * MO_NP + lane];
+            g[k].y = (HAS1 && c1) ? hdr[k * MO_NP + lane + 64] : 0.0f;
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            gs[lane * MS_GS + k] = g[k].x;
+            if (lane + 64 < MO_NP) gs[(lane + 64) * MS_GS + k] = g[k].y;
+        }
+        // latent part and gate row (all of it from the header); the latent gradients wait in
+        // registers for the store burst at the end of the sample
+        float kl = 0.0f, lat_m[2] = {0.0f, 0.0f}, lat_v[2] = {0.0f, 0.0f};
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int i = m * 64 + lane;
+            if (i < L) {
+                const float mm = h_mu[i], lv = h_lv[i];
+                const float e = __expf(lv);
+                kl += -0.5f * (1.0f + lv - mm * mm - e);
+                lat_m[m] = mm;
+                lat_v[m] = 0.5f * (e - 1.0f);
+            }
+        }
+        float logpi[K];
+        {
+            float gl[K], gmax = -INFINITY, gsum = 0.0f;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                gl[k] = h_gate[k];
+                gmax = fmaxf(gmax, gl[k]);
+            }
+#pragma unroll
+            for (int k = 0; k < K; ++k) gsum += __expf(gl[k] - gmax);
+            const float lg = __logf(gsum);
+#pragma unroll
+            for (int k = 0; k < K; ++k) logpi[k] = gl[k] - gmax - lg;
+        }
+        // ---- the sweep ----
+        mo_v2 y[K], sx2 = mo_v2{0.0f, 0.0f};
+#pragma unroll
+        for (int k = 0; k < K; ++k) y[k] = mo_v2{0.0f, 0.0f};
+        const float* xrow = ring + shift + lane;          // this lane's element of row 0
+        ms_static_for<0, TPX>([&](auto pc) {
+            constexpr int p = decltype(pc)::value;
+            step(std::integral_constant<int, HP + 1 + p>{});
+            constexpr int r_lo = p == 0 ? 0 : ms_rows_after(p - 1, N), r_hi = ms_rows_after(p, N);
+            ms_static_for<r_lo, r_hi>([&](auto rc) {
+                constexpr int r = decltype(rc)::value;
+                constexpr int off = (r * N) & (MS_RINGF - 1);
+                mo_v2 xv;
+                xv.x = xrow[off];
+                xv.y = HAS1 ? xrow[off + 64] : 0.0f;
+                sx2 = __builtin_elementwise_fma(xv, xv, sx2);
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    const float gi = gs[r * MS_GS + k];
+                    y[k] = __builtin_elementwise_fma(xv, mo_v2{gi, gi}, y[k]);
+                }
+            });
+        });
+        // what the lanes without a second column gathered is whatever lay behind the row: drop it
+        if (!c1) sx2.y = 0.0f;
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+            if (!c1) y[k].y = 0.0f;
+        // ---- per-sample scalars: everything below is the same in every lane ----
+        const float sx = ms_sum(sx2.x + sx2.y);
+        const float klsum = ms_sum(kl);
+        float gg[K], ss[K], u[K], t[K];
+        float tmin = INFINITY;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            gg[k] = ms_sum(fmaf(g[k].x, g[k].x, g[k].y * g[k].y));
+            const float q = ms_sum(fmaf(g[k].x, y[k].x, g[k].y * y[k].y));
+            ss[k] = fmaxf(fmaf(gg[k], gg[k], sx) - 2.0f * q, 0.0f);
+            u[k] = ss[k] * is2[k];
+            t[k] = 0.5f * u[k] + (float)D * ls[k];
+            tmin = fminf(tmin, t[k]);
+        }
+        // exponents relative to the component with the smallest one (see mixture_exponent)
+        float um = 0.0f, lsm = 0.0f;
+#pragma unroll
+        for (int k = K - 1; k >= 0; --k) {
+            if (t[k] == tmin) {
+                um = u[k];
+                lsm = ls[k];
+            }
+        }
+        float a[K], amax = -INFINITY, asum = 0.0f;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            a[k] = logpi[k] - (0.5f * (u[k] - um) + (float)D * (ls[k] - lsm));
+            amax = fmaxf(amax, a[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) asum += __expf(a[k] - amax);
+        const float lse = amax + __logf(asum);
+        const double offset = 0.5 * (double)um + (double)D * ((double)lsm + 0.5 * (double)LOG_2PI);
+        float r_own = 0.0f, gl_own = 0.0f, gs_own = 0.0f;
+        float* dst = gnodes + (long)b * K * MO_NP;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const float r = __expf(a[k] - lse);
+            if (lane == k) {
+                r_own = r;
+                gl_own = __expf(logpi[k]) - r;
+                gs_own = r * ((float)D - ss[k] * is2[k]);
+            }
+            const float ck2 = 2.0f * r * is2[k];
+            ms_store(dst + k * MO_NP + lane, ck2 * fmaf(g[k].x, gg[k], -y[k].x));
+            if (lane + 64 < MO_NP) ms_store(dst + k * MO_NP + lane + 64, c1 ? ck2 * fmaf(g[k].y, gg[k], -y[k].y) : 0.0f);
+        }
+        if (lane < K) {
+            ms_store(resp + (long)b * K + lane, r_own);
+            ms_store(glogits + (long)b * K + lane, gl_own);
+            ms_store(glsig_rows + (long)b * K + lane, gs_own);
+        }
+        if (lane == 0) {
+            ms_store(per_sample + 2 * b, offset - (double)lse);
+            ms_store(per_sample + 2 * b + 1, (double)klsum);
+        }
+        if (latent_grads) {
+            // always four stores: lanes past the row's end repeat its last element
+            const int last = L - 1;
+            const float last_m = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(last >= 64 ? lat_m[1] : lat_m[0]), last & 63));
+            const float last_v = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(last >= 64 ? lat_v[1] : lat_v[0]), last & 63));
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const bool live = m * 64 + lane < L;
+                const long j = (long)b * L + (live ? m * 64 + lane : last);
+                ms_store(gmu + j, live ? lat_m[m] : last_m);
+                ms_store(glogvar + j, live ? lat_v[m] : last_v);
+            }
+        }
+        first = false;
+        cur = nxt;
+    }
+    // nothing of this wave's stream may still be in flight when its LDS goes to another workgroup
+    ms_wait<0>();
+}
+
 }  // namespace mdnvae
 using namespace mdnvae;
 
@@ -530,6 +910,20 @@ using namespace mdnvae;
 static unsigned mdn_outer_grid(int B) {
     const int blocks = (B + MDN_NT / 64 - 1) / (MDN_NT / 64);
     return (unsigned)(blocks < 2048 ? blocks : 2048);
+}
+#ifndef MDN_SYM_OLD
+#define MDN_SYM_OLD 0
+#endif
+#ifndef MS_BLOCKS_PER_CU_N
+#define MS_BLOCKS_PER_CU_N 2
+#endif
+// LDS-streamed symmetric sweep: every workgroup resident at once (its LDS admits MS_BLOCKS_PER_CU_N per
+// CU), and as many waves as give each the same number of samples
+static unsigned mdn_sym_grid(int B) {
+    const long max_waves = 256L * MS_BLOCKS_PER_CU_N * MS_WAVES;
+    const long per_wave = (B + max_waves - 1) / max_waves;
+    const long waves = (B + per_wave - 1) / per_wave;
+    return (unsigned)((waves + MS_WAVES - 1) / MS_WAVES);
 }
 static unsigned mdn_grid(int B) {
     const int blocks = (B + MDN_NT / 64 - 1) / (MDN_NT / 64);
@@ -618,12 +1012,24 @@ static int mdn_outer_launch(const char* fn, const float* nodes, const float* x, 
         MV_REQUIRE(L == 0 || (mu && logvar), E_ARG, "%s: mu/logvar is null", fn);
         MV_REQUIRE((grad_mu == nullptr) == (grad_logvar == nullptr), E_ARG, "%s: grad_mu and grad_logvar come together",
                    fn);
+        // The LDS-streamed sweep exists for the two connectome sizes of the scripts (87 x 87 raw,
+        // 68 x 68 cortical crop), 16-byte aligned node vectors and a latent row of at most MS_MAXL;
+        // other symmetric input takes the row-wise symmetric sweep.
+        const bool streamed = !MDN_SYM_OLD && x_symmetric && (N == 87 || N == 68) && aligned16(nodes) && L >= 1 &&
+                              L <= MS_MAXL;
+#define MV_SYM_STREAM(KK, NN)                                                                                        \
+    hipLaunchKernelGGL((mdn_outer_sym_kernel<KK, NN>), dim3(mdn_sym_grid(B)), dim3(MS_WAVES * 64), 0, st, nodes, x,  \
+                       gate_logits, log_sigma, B, mu, logvar, L, grad_nodes, grad_logits, grad_log_sigma_rows,       \
+                       grad_mu, grad_logvar, resp, per_sample)
 #define CALL(KK)                                                                                                     \
-    if (x_symmetric)                                                                                                 \
-        hipLaunchKernelGGL((mdn_outer_kernel<KK, true>),                                                             \
-                           dim3(mdn_outer_grid(B)),                                                                  \
-                           dim3(MDN_NT), 0, st, nodes, x, gate_logits, log_sigma, B, N, mu, logvar, L, grad_nodes,   \
-                           grad_logits, grad_log_sigma_rows, grad_mu, grad_logvar, resp, per_sample);                \
+    if (streamed && N == 87)                                                                                         \
+        MV_SYM_STREAM(KK, 87);                                                                                       \
+    else if (streamed)                                                                                               \
+        MV_SYM_STREAM(KK, 68);                                                                                       \
+    else if (x_symmetric)                                                                                            \
+        hipLaunchKernelGGL((mdn_outer_kernel<KK, true>), dim3(mdn_outer_grid(B)), dim3(MDN_NT), 0, st, nodes, x,     \
+                           gate_logits, log_sigma, B, N, mu, logvar, L, grad_nodes, grad_logits,                     \
+                           grad_log_sigma_rows, grad_mu, grad_logvar, resp, per_sample);                             \
     else                                                                                                             \
         hipLaunchKernelGGL((mdn_outer_kernel<KK, false>),                                                            \
                            dim3(mdn_outer_grid(B)),                                                                  \
@@ -631,6 +1037,7 @@ static int mdn_outer_launch(const char* fn, const float* nodes, const float* x, 
                            grad_logits, grad_log_sigma_rows, grad_mu, grad_logvar, resp, per_sample)
         MV_MDN_DISPATCH(K, CALL)
 #undef CALL
+#undef MV_SYM_STREAM
         MV_LAUNCH_CHECK("mdn_outer_kernel");
     }
     hipLaunchKernelGGL(mdn_finalize_kernel, dim3(1), dim3(PAIR_NT), 0, st, (const double*)per_sample, B, loss_out);

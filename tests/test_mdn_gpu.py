@@ -150,11 +150,49 @@ def test_rank_one_mixture_on_symmetric_targets_against_oracle(B, K, n, L):
     want = _outer_oracle(leaves[0], x.double(), leaves[1], leaves[2], leaves[3], leaves[4], n)
     want.backward()
     assert abs(sym[0][0].item() - want.item()) <= 1e-5 * abs(want.item())
-    assert torch.equal(sym[0], gen[0])                       # the likelihood sums are the same operations
+    # 87 and 68 take the LDS-streamed sweep (sums of squares from |g|^4 - 2 g.xg + |x|^2), the other
+    # sizes the row-wise one: the same numbers as the general form up to fp32 rounding either way
+    assert _rel(sym[0], gen[0]) <= 2e-6
     for got, other, leaf, name in zip(sym[1:], gen[1:], leaves, ("nodes", "logits", "log_sigma", "mu", "logvar")):
         assert _rel(got, leaf.grad) <= 1e-4, name
-        assert _rel(got, other) <= 1e-5, name
+        assert _rel(got, other) <= 5e-5, name
     assert float(sym[1][:, :, n:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("B,K,n,L,kind", [(300, 5, 87, 68, "sc"), (257, 8, 68, 128, "rand"), (64, 1, 87, 4, "rand"),
+                                           (33, 3, 68, 70, "sc"), (2049, 5, 87, 68, "rand"), (1, 5, 87, 68, "sc"),
+                                           (40, 5, 87, 130, "rand")])
+def test_streamed_symmetric_sweep_against_oracle(B, K, n, L, kind):
+    """The LDS-streamed sweep (n = 87 / 68, latent rows up to 128 wide; wider rows fall back to the
+    row-wise sweep) on batches that give waves several samples each and ragged tails, with x starting
+    at an odd float of a larger buffer (every sample's run then starts at a different phase), on
+    uniform and on heavy-tailed structural-connectome targets."""
+    torch.manual_seed(B + n + L)
+    nodes = torch.zeros(B, K, 96)
+    nodes[:, :, :n] = torch.rand(B, K, n) * 0.8 + 0.1
+    if kind == "sc":
+        x = M.data.synthetic_sc(B, n, seed=B, device=DEV).cpu()
+    else:
+        x = torch.rand(B, n, n)
+        x = (x + x.transpose(1, 2)).reshape(B, n * n)
+    logits = torch.randn(B, K)
+    ls = torch.randn(K) * 0.2 + (2.5 if kind == "sc" else 1.5)
+    mu, lv = torch.randn(B, L) * 0.3, torch.randn(B, L) * 0.2
+    big = torch.empty(B * n * n + 7, device=DEV)
+    xd = big[3:3 + B * n * n].view(B, n * n)
+    xd.copy_(x)
+    dev = [t.to(DEV) for t in (nodes, logits, ls, mu, lv)]
+    terms, g_nodes, g_logits, g_ls, g_mu, g_lv = M.ops.mdn_outer_loss_and_grads(dev[0], xd, *dev[1:], n, symmetric_x=True)
+    leaves = [t.double().requires_grad_(True) for t in (nodes, logits, ls, mu, lv)]
+    want = _outer_oracle(leaves[0], x.double(), leaves[1], leaves[2], leaves[3], leaves[4], n)
+    want.backward()
+    assert abs(terms[0].item() - want.item()) <= 1e-5 * abs(want.item())
+    for got, leaf, name in zip((g_nodes, g_logits, g_ls, g_mu, g_lv), leaves, ("nodes", "logits", "log_sigma", "mu", "logvar")):
+        assert _rel(got, leaf.grad) <= 1e-4, name
+    assert float(g_nodes[:, :, n:].abs().max()) == 0.0
+    # per-sample: every sample's node gradient, not only the largest entries of the batch
+    per = (g_nodes.double().cpu() - leaves[0].grad).abs().amax(dim=(1, 2)) / leaves[0].grad.abs().amax(dim=(1, 2)).clamp_min(1e-30)
+    assert float(per.max()) <= 2e-4
 
 
 def test_rank_one_mixture_matches_the_materialised_path_and_scales_with_upstream():

