@@ -29,6 +29,7 @@ import mdnvae_amd as M  # noqa: E402
 from mdnvae_amd import ops  # noqa: E402
 
 PEAK_FP32_MATRIX_TFLOPS = 157.3   # v_mfma_f32_32x32x2_f32, dense
+PEAK_BF16_MATRIX_TFLOPS = 2500.0  # v_mfma_f32_32x32x16_bf16, dense
 PEAK_HBM_GBPS = 8000.0
 # fabric-side bytes / algorithmic bytes from the rocprofv3 TCC counters (FETCH_SIZE x2 + WRITE_SIZE,
 # separate passes; profiles/r01_c_loss_pmc_traffic.md, profiles/r01_h_pmc_traffic.md); kernels without a collected pass report null
@@ -209,6 +210,18 @@ ABI_TAGS = {
 }
 HBM_TAGS = {v[0] for v in ABI_TAGS.values() if isinstance(v[0], str)} | {
     "chain_fwd_mfma_kernel+outer_epilogue_kernel", "outer_grad_kernel+chain_bwd_mfma_kernel"}
+ABI_TAGS.update({
+    # (src, R, K, ld, ...) / (src, Kd, R, ld, ...): the fp32 source in, three bf16 parts out
+    "mdnvae_split_rows": ("split_rows_kernel", lambda a: 10.0 * a[1] * a[2]),
+    "mdnvae_split_cols": ("split_cols_kernel", lambda a: 10.0 * a[1] * a[2]),
+    # (y, grad_y, grad_pre, n, act): two reads, one write
+    "mdnvae_act_bwd": ("act_bwd_kernel", lambda a: 12.0 * a[3]),
+    "mdnvae_tri_fold": ("tri_pack_kernel<fold>", lambda a: 4.0 * a[1] * (a[2] * a[2] + a[2] * (a[2] + 1) // 2)),
+})
+HBM_TAGS |= {"split_rows_kernel", "split_cols_kernel", "act_bwd_kernel", "tri_pack_kernel<fold>"}
+# bf16 matrix-core work: (a, b, M, N, K, m_valid, ...) executes six bf16 MFMA products per fp32 multiply-add
+BF16_TAGS = {"split_gemm_kernel"}
+ABI_TAGS["mdnvae_split_gemm"] = ("split_gemm_kernel", lambda a: 12.0 * a[5] * a[3] * a[4])
 # matrix-core entry points with a fixed tag (work in flops; kept out of HBM_TAGS)
 ABI_TAGS.update({
     # (layer_in, layer_dpre, B, count, ...): one 96 x 96 x B product per (channel, layer)
@@ -293,7 +306,7 @@ def kernel_table(clock, elapsed):
         per_launch = r["seconds"] / max(r["launches"], 1)
         hbm = tag in HBM_TAGS
         rate = r["work"] / r["seconds"] / (1e9 if hbm else 1e12)
-        peak = PEAK_HBM_GBPS if hbm else PEAK_FP32_MATRIX_TFLOPS
+        peak = PEAK_HBM_GBPS if hbm else (PEAK_BF16_MATRIX_TFLOPS if tag in BF16_TAGS else PEAK_FP32_MATRIX_TFLOPS)
         kernels[tag] = dict(bound="hbm" if hbm else "mfma", achieved=rate, peak=peak, unit="GB/s" if hbm else "TFLOP/s",
                             frac=rate / peak, launches=r["launches"], avg_ms=per_launch * 1e3,
                             share_of_step=r["seconds"] / elapsed,

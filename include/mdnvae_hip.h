@@ -237,6 +237,26 @@ int mdnvae_tri_fold(const float* w, long H, int N, int ld, float* out, void* str
 int mdnvae_tri_unfold(const float* g, long H, int N, long stride_t, long stride_h, float* grad_w, int accumulate,
                       void* stream);
 
+/* ---- the big first layers on the bf16 matrix cores at fp32 accuracy ---------------------------
+ * self.fc11(x) / self.fc12(x) with ReLU (function/MM_Gate.py:157-158) and the weight gradients autograd
+ * derives for them.  Every fp32 operand is split into three bf16 parts (x = x1 + x2 + x3 exactly) and
+ * the product keeps the six part products of relative size >= 2^-16, accumulated in fp32: the terms
+ * left out are of the size of one fp32 rounding.
+ * Split operands are opaque buffers of mdnvae_split_operand_bytes(rows, k) bytes holding an operand
+ * [rows][k] (rows padded to a multiple of 32, k to a multiple of 16) in MFMA-fragment tiles. */
+size_t mdnvae_split_operand_bytes(long rows, long k);
+/* operand[row_tile0 * 32 + r][c] = src[r][c] for src [R][ld] fp32, c < K (K a multiple of 16). */
+int mdnvae_split_rows(const float* src, long R, long K, long ld, long row_tile0, void* out, void* stream);
+/* operand[row_tile0 * 32 + c][r] = src[r][c] for src [Kd][ld] fp32, c < R: the transposed operand (of
+ * k extent Kd rounded up to 16, zero filled) that a weight-gradient product takes. */
+int mdnvae_split_cols(const float* src, long Kd, long R, long ld, long row_tile0, void* out, void* stream);
+/* out[m][n] = sum_k a[m][k] b[n][k] (+ bias[n], ReLU when relu != 0) for m < m_valid: columns
+ * n < n_split go to out0 (bias0), the others to out1 (bias1) at column n - n_split; row stride ld_out.
+ * M a multiple of tile_m (128 or 256), N and n_split multiples of 256, K of 16. */
+int mdnvae_split_gemm(const void* a, const void* b, long M, long N, long K, long m_valid, const float* bias0,
+                      const float* bias1, int relu, float* out0, float* out1, long n_split, long ld_out, int tile_m,
+                      void* stream);
+
 /* ---- conv / ResNet encoder ---------------------------------------------------------------
  * The ATen conv2d / instance_norm / relu / max_pool2d calls (and their autograd) of the encoder
  * stack, function/VAE_CNN_NN.py:83-98 (ResidualBlock), :110-137 (ec, max_pool), :155-159 (encode).

@@ -1,0 +1,310 @@
+// The two big dense layers of the FNN encoder towers, self.fc11 / self.fc12 of function/MM_Gate.py:157-158
+// (Linear(N*N, 1024) + ReLU each, on the same input), and the weight gradients autograd derives for
+// them, on the bf16 matrix cores at fp32 accuracy.
+//
+// An fp32 number is the exact sum of three bf16 numbers (8 significand bits each): x = x1 + x2 + x3.
+// A product of two such sums, kept to the terms of relative size >= 2^-16,
+//     x w ~= x1 w1 + (x1 w2 + x2 w1) + (x1 w3 + x2 w2 + x3 w1),
+// leaves out only terms of 2^-24 and below, the size of one fp32 rounding.  Each of the six terms is a
+// bf16 MFMA product accumulated in fp32, so a GEMM costs 6 bf16 products per fp32 one - 6/16 of the
+// fp32 matrix rate - and both operands of every MFMA are reused three times from registers.
+//
+// Operands are split ahead of the GEMM into a tiled layout whose unit is exactly one MFMA operand
+// fragment, [row tile of 32][k step of 16][part 3][k half 2][row 32][8 bf16] (1 KiB per fragment, the
+// three parts of a (tile, step) contiguous): the GEMM stages fragments by LDS-DMA as whole 1 KiB
+// pieces (fully coalesced, no address arithmetic per element) and reads them back with one
+// conflict-free ds_read_b128 per lane.  Both operands are "k-contiguous" ([M][K] and [N][K]): the
+// forward product takes x [B][T] and the folded weights [H][T]; the weight gradient takes x^T [T][B]
+// and grad_pre^T [H][B], which the column-splitting kernel writes straight from the row-major tensors.
+#include "common.h"
+#include "../../include/mdnvae_hip.h"
+
+namespace mdnvae {
+
+typedef __bf16 sg_frag __attribute__((ext_vector_type(8)));
+typedef float sg_acc __attribute__((ext_vector_type(16)));
+typedef float sg_v4 __attribute__((ext_vector_type(4)));
+
+constexpr int SG_FRAG = 1024;                 // bytes of one fragment (32 rows x 16 k, bf16)
+constexpr int SG_STEP = 3 * SG_FRAG;          // the three parts of one (row tile, k step)
+
+// x = b[0] + b[1] + b[2] (each rounded to nearest; the remainders are exact in fp32)
+__device__ __forceinline__ void sg_split(float x, __bf16 (&b)[3]) {
+    b[0] = (__bf16)x;
+    const float r1 = x - (float)b[0];
+    b[1] = (__bf16)r1;
+    const float r2 = r1 - (float)b[1];
+    b[2] = (__bf16)r2;
+}
+
+__device__ __forceinline__ void sg_emit(const float (&v)[8], char* dst) {
+    sg_frag p[3];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        __bf16 b[3];
+        sg_split(v[e], b);
+        p[0][e] = b[0];
+        p[1][e] = b[1];
+        p[2][e] = b[2];
+    }
+#pragma unroll
+    for (int s = 0; s < 3; ++s) *reinterpret_cast<sg_frag*>(dst + s * SG_FRAG) = p[s];
+}
+
+// src [R][ld] fp32, K columns used (multiple of 16) -> tiled parts, operand row = src row, k = src
+// column.  One workgroup: 32 rows x 64 columns; a thread owns 8 consecutive columns of one row, which
+// is one 16-byte chunk of each part.  Rows >= R are written as zeros.
+__global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict__ src, int R, int K, long ld,
+                                                         int row_tile0, char* __restrict__ out) {
+    const int rt = blockIdx.x, r = threadIdx.x >> 3, c = threadIdx.x & 7;
+    const int k0 = blockIdx.y * 64 + c * 8;
+    if (k0 >= K) return;
+    const int row = rt * 32 + r;
+    float v[8];
+    if (row < R) {
+        const sg_v4 a = *reinterpret_cast<const sg_v4*>(src + (long)row * ld + k0);
+        const sg_v4 b = *reinterpret_cast<const sg_v4*>(src + (long)row * ld + k0 + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+        v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = 0.0f;
+    }
+    const int ks = k0 >> 4, h = (k0 >> 3) & 1, KS = K >> 4;
+    sg_emit(v, out + ((long)(row_tile0 + rt) * KS + ks) * SG_STEP + h * 512 + r * 16);
+}
+
+// src [Kd][ld] fp32, R columns used -> tiled parts with operand row = src COLUMN and k = src row (the
+// transposed operand of a weight-gradient product).  One workgroup: 64 src rows x 32 src columns
+// through LDS; k beyond Kd is written as zeros (the tiled operand holds ceil(Kd/16) steps).
+__global__ __launch_bounds__(256) void split_cols_kernel(const float* __restrict__ src, int Kd, int R, long ld,
+                                                         int row_tile0, int KS, char* __restrict__ out) {
+    __shared__ float tile[64][33];
+    const int rt = blockIdx.x, kb = blockIdx.y * 64;
+    {
+        const int rr = threadIdx.x >> 3, c4 = (threadIdx.x & 7) * 4;
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            const int kk = kb + pass * 32 + rr, col = rt * 32 + c4;
+            sg_v4 a = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (kk < Kd) {
+                if (col + 3 < R) a = *reinterpret_cast<const sg_v4*>(src + (long)kk * ld + col);
+                else {
+                    if (col < R) a.x = src[(long)kk * ld + col];
+                    if (col + 1 < R) a.y = src[(long)kk * ld + col + 1];
+                    if (col + 2 < R) a.z = src[(long)kk * ld + col + 2];
+                }
+            }
+            tile[pass * 32 + rr][c4] = a.x;
+            tile[pass * 32 + rr][c4 + 1] = a.y;
+            tile[pass * 32 + rr][c4 + 2] = a.z;
+            tile[pass * 32 + rr][c4 + 3] = a.w;
+        }
+    }
+    __syncthreads();
+    const int r = threadIdx.x & 31, q = threadIdx.x >> 5;        // q = (k step within the 64, half)
+    const int ks = (kb >> 4) + (q >> 1), h = q & 1;
+    if (ks >= KS) return;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = tile[q * 8 + e][r];
+    sg_emit(v, out + ((long)(row_tile0 + rt) * KS + ks) * SG_STEP + h * 512 + r * 16);
+}
+
+// ---- the product ----
+// C [M][N] = sum_k A[m][k] B[n][k] over tiled, split operands.  Workgroup of 8 waves (2 x 4), output
+// tile (2 * WM * 32) x 256, wave tile (WM * 32) x 64; one k step (16) per barrier: the six MFMAs per
+// fragment pair make a step 48 (WM = 4) or 24 (WM = 2) MFMAs per wave, long enough to cover the
+// staging of the next step, which is issued first (LDS-DMA into the other buffer).
+#define SG_GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+#define SG_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+enum { SG_EPI_BIAS_RELU = 0, SG_EPI_PLAIN = 1 };
+
+template <int WM, int EPI>
+__global__ __launch_bounds__(512) void split_gemm_kernel(const char* __restrict__ A, const char* __restrict__ Bop,
+                                                         int KS, int ntm, int ntn, int m_valid,
+                                                         const float* __restrict__ bias0, const float* __restrict__ bias1,
+                                                         float* __restrict__ out0, float* __restrict__ out1, int n_split,
+                                                         long ld_out) {
+    constexpr int TA = 2 * WM, TB = 8;                   // fragment rows-tiles of A / B per workgroup
+    constexpr int STAGE = (TA + TB) * SG_STEP;
+    constexpr int PIECES = (TA + TB) * 3;
+    constexpr int PPW = (PIECES + 7) / 8;                // pieces per wave (the last may be missing)
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wid >> 2, wn = wid & 3;
+    // tiles of one XCD (blocks g, g+8, ...) are consecutive: they share A row tiles through its L2
+    const int ntiles = ntm * ntn;
+    int tl = blockIdx.x;
+    if ((ntiles & 7) == 0) tl = (blockIdx.x & 7) * (ntiles >> 3) + (blockIdx.x >> 3);
+    const int tm = tl / ntn, tn = tl - tm * ntn;
+
+    // this wave's staging pieces: piece q = wid + 8 i is part (q % 3) of fragment row-tile (q / 3)
+    const char* src[PPW];
+    int dst[PPW];
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+        const int q = wid + 8 * i;
+        const int t = q / 3, part = q - 3 * t;
+        const bool isA = t < TA;
+        const long row_tile = isA ? (long)tm * TA + t : (long)tn * TB + (t - TA);
+        src[i] = (isA ? A : Bop) + row_tile * KS * SG_STEP + part * SG_FRAG + lane * 16;
+        dst[i] = q * SG_FRAG;
+    }
+    auto stage = [&](int buf, int ks) {
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            if (PIECES % 8 == 0 || wid + 8 * i < PIECES)
+                __builtin_amdgcn_global_load_lds(SG_GLOBAL_PTR(src[i] + (long)ks * SG_STEP),
+                                                 SG_LDS_PTR(smem + buf * STAGE + dst[i]), 16, 0, 0);
+        }
+    };
+
+    sg_acc acc[WM][2];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    stage(0, 0);
+    __syncthreads();
+    for (int ks = 0; ks < KS; ++ks) {
+        const int buf = ks & 1;
+        if (ks + 1 < KS) stage(buf ^ 1, ks + 1);
+        const char* sa = smem + buf * STAGE + (wm * WM) * SG_STEP + lane * 16;
+        const char* sb = smem + buf * STAGE + (TA + wn * 2) * SG_STEP + lane * 16;
+        sg_frag a[WM][3], b[2][3];
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int s = 0; s < 3; ++s) a[i][s] = *reinterpret_cast<const sg_frag*>(sa + i * SG_STEP + s * SG_FRAG);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int s = 0; s < 3; ++s) b[j][s] = *reinterpret_cast<const sg_frag*>(sb + j * SG_STEP + s * SG_FRAG);
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                // smallest terms first
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);
+            }
+        __syncthreads();
+    }
+
+    // epilogue: accumulator register e of a 32 x 32 tile is row (e & 3) + 8 (e >> 2) + 4 (lane >> 5),
+    // column lane & 31
+    const int n_tile0 = tn * 256 + wn * 64;
+    const bool second = n_tile0 >= n_split;
+    float* out = second ? out1 : out0;
+    const float* bias = second ? bias1 : bias0;
+    const int n_base = n_tile0 - (second ? n_split : 0);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n_base + j * 32 + (lane & 31);
+        const float bv = EPI == SG_EPI_BIAS_RELU ? bias[n] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < WM; ++i) {
+            const int m0 = (tm * TA + wm * WM + i) * 32 + 4 * (lane >> 5);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + (e & 3) + 8 * (e >> 2);
+                float v = acc[i][j][e];
+                if (EPI == SG_EPI_BIAS_RELU) v = fmaxf(v + bv, 0.0f);
+                if (m < m_valid) out[(long)m * ld_out + n] = v;
+            }
+        }
+    }
+}
+
+}  // namespace mdnvae
+using namespace mdnvae;
+
+extern "C" {
+
+size_t mdnvae_split_operand_bytes(long rows, long k) {
+    const long rt = (rows + 31) / 32, ks = (k + 15) / 16;
+    return (size_t)(rt > 0 ? rt : 0) * (size_t)(ks > 0 ? ks : 0) * SG_STEP;
+}
+
+int mdnvae_split_rows(const float* src, long R, long K, long ld, long row_tile0, void* out, void* stream) {
+    MV_REQUIRE(R >= 0 && K >= 0 && ld >= K && row_tile0 >= 0, E_ARG, "mdnvae_split_rows: bad shape");
+    MV_REQUIRE(K % 16 == 0 && ld % 4 == 0, E_SHAPE, "mdnvae_split_rows: K must be a multiple of 16 and ld of 4");
+    if (R == 0 || K == 0) return 0;
+    MV_REQUIRE(src && out, E_ARG, "mdnvae_split_rows: null pointer");
+    MV_REQUIRE(aligned16(src) && aligned16(out), E_ALIGN, "mdnvae_split_rows: operands must be 16-byte aligned");
+    const long rt = (R + 31) / 32, kb = (K + 63) / 64;
+    MV_REQUIRE(rt <= 0x7fffffffL && kb <= 65535, E_SHAPE, "mdnvae_split_rows: shape too large for one launch");
+    hipLaunchKernelGGL(split_rows_kernel, dim3((unsigned)rt, (unsigned)kb), dim3(256), 0, (hipStream_t)stream, src,
+                       (int)R, (int)K, ld, (int)row_tile0, (char*)out);
+    MV_LAUNCH_CHECK("split_rows_kernel");
+    return 0;
+}
+
+int mdnvae_split_cols(const float* src, long Kd, long R, long ld, long row_tile0, void* out, void* stream) {
+    MV_REQUIRE(R >= 0 && Kd >= 0 && ld >= R && row_tile0 >= 0, E_ARG, "mdnvae_split_cols: bad shape");
+    MV_REQUIRE(ld % 4 == 0, E_SHAPE, "mdnvae_split_cols: ld must be a multiple of 4");
+    if (R == 0 || Kd == 0) return 0;
+    MV_REQUIRE(src && out, E_ARG, "mdnvae_split_cols: null pointer");
+    MV_REQUIRE(aligned16(src) && aligned16(out), E_ALIGN, "mdnvae_split_cols: operands must be 16-byte aligned");
+    const long rt = (R + 31) / 32, kb = (Kd + 63) / 64, KS = (Kd + 15) / 16;
+    MV_REQUIRE(rt <= 0x7fffffffL && kb <= 65535, E_SHAPE, "mdnvae_split_cols: shape too large for one launch");
+    hipLaunchKernelGGL(split_cols_kernel, dim3((unsigned)rt, (unsigned)kb), dim3(256), 0, (hipStream_t)stream, src,
+                       (int)Kd, (int)R, ld, (int)row_tile0, (int)KS, (char*)out);
+    MV_LAUNCH_CHECK("split_cols_kernel");
+    return 0;
+}
+
+int mdnvae_split_gemm(const void* a, const void* b, long M, long N, long K, long m_valid, const float* bias0,
+                      const float* bias1, int relu, float* out0, float* out1, long n_split, long ld_out, int tile_m,
+                      void* stream) {
+    MV_REQUIRE(M >= 1 && N >= 1 && K >= 16 && m_valid >= 0 && m_valid <= M, E_ARG, "mdnvae_split_gemm: bad shape");
+    MV_REQUIRE(tile_m == 256 || tile_m == 128, E_ARG, "mdnvae_split_gemm: tile_m must be 128 or 256");
+    MV_REQUIRE(M % tile_m == 0 && N % 256 == 0 && K % 16 == 0, E_SHAPE,
+               "mdnvae_split_gemm: M must be a multiple of tile_m, N of 256, K of 16 (pad the split operands)");
+    MV_REQUIRE(n_split >= 256 && n_split % 256 == 0 && n_split <= N, E_SHAPE,
+               "mdnvae_split_gemm: n_split must be a multiple of 256 within N");
+    MV_REQUIRE(a && b && out0 && (n_split == N || out1), E_ARG, "mdnvae_split_gemm: null pointer");
+    MV_REQUIRE(!relu || (bias0 && (n_split == N || bias1)), E_ARG, "mdnvae_split_gemm: the bias + ReLU epilogue needs biases");
+    MV_REQUIRE(aligned16(a) && aligned16(b), E_ALIGN, "mdnvae_split_gemm: operands must be 16-byte aligned");
+    const long ntm = M / tile_m, ntn = N / 256;
+    MV_REQUIRE(ntm * ntn <= 0x7fffffffL, E_SHAPE, "mdnvae_split_gemm: too many tiles");
+    const int KS = (int)(K / 16);
+    hipStream_t st = (hipStream_t)stream;
+#define SG_LAUNCH(WM, EPI)                                                                                          \
+    do {                                                                                                            \
+        const size_t lds = 2 * (size_t)(2 * WM + 8) * SG_STEP;                                                      \
+        static bool raised = false;                                                                                 \
+        if (!raised) {                                                                                              \
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(split_gemm_kernel<WM, EPI>),     \
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);       \
+            MV_REQUIRE(e == hipSuccess, (int)e, "mdnvae_split_gemm: cannot raise the LDS limit: %s",                \
+                       hipGetErrorString(e));                                                                       \
+            raised = true;                                                                                          \
+        }                                                                                                           \
+        hipLaunchKernelGGL((split_gemm_kernel<WM, EPI>), dim3((unsigned)(ntm * ntn)), dim3(512), lds, st,           \
+                           (const char*)a, (const char*)b, KS, (int)ntm, (int)ntn, (int)m_valid, bias0, bias1,      \
+                           out0, out1 ? out1 : out0, (int)n_split, ld_out);                                         \
+    } while (0)
+    if (tile_m == 256) {
+        if (relu) SG_LAUNCH(4, SG_EPI_BIAS_RELU);
+        else SG_LAUNCH(4, SG_EPI_PLAIN);
+    } else {
+        if (relu) SG_LAUNCH(2, SG_EPI_BIAS_RELU);
+        else SG_LAUNCH(2, SG_EPI_PLAIN);
+    }
+#undef SG_LAUNCH
+    MV_LAUNCH_CHECK("split_gemm_kernel");
+    return 0;
+}
+
+}  // extern "C"

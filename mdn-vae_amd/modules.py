@@ -349,10 +349,16 @@ class GCNVAE(nn.Module):
     # reconstruction: the trainer may take loss and gradients from them directly
     rank_one_sum_decoder = True
 
-    def __init__(self, R=5, n_nodes=68, k=32, n_layers=3, latent_dim=68, symmetric_input=False):
+    def __init__(self, R=5, n_nodes=68, k=32, n_layers=3, latent_dim=68, symmetric_input=False, first_layer_gemm="split"):
         super().__init__()
         self.n_nodes = n_nodes
         self.symmetric_input = symmetric_input
+        if first_layer_gemm not in ("split", "library"):
+            raise ValueError("first_layer_gemm must be 'split' or 'library'")
+        # "split": with symmetric_input and batches of at least ops.SPLIT_GEMM_MIN_BATCH both first layers
+        # run as one hand-written MFMA product on three-way bf16 splits (fp32 accuracy); "library":
+        # always the library's fp32 GEMMs
+        self.first_layer_gemm = first_layer_gemm
         self.register_buffer("_asym", torch.zeros(1, dtype=torch.int32), persistent=False)
         D = n_nodes * n_nodes
         self.fc11 = Linear(D, 1024)
@@ -370,8 +376,12 @@ class GCNVAE(nn.Module):
         every batch; `check_inputs()` reports a violation."""
         if self.symmetric_input:
             xt = ops.tri_pack(x, self.n_nodes, self._asym)
-            a11 = ops.sym_linear_act(xt, self.fc11.weight, self.fc11.bias, "relu", self.n_nodes)
-            a12 = ops.sym_linear_act(xt, self.fc12.weight, self.fc12.bias, "relu", self.n_nodes)
+            if self.first_layer_gemm == "split" and xt.shape[0] >= ops.SPLIT_GEMM_MIN_BATCH:
+                a11, a12 = ops.sym_linear_pair(xt, self.fc11.weight, self.fc11.bias, self.fc12.weight, self.fc12.bias,
+                                               self.n_nodes)
+            else:
+                a11 = ops.sym_linear_act(xt, self.fc11.weight, self.fc11.bias, "relu", self.n_nodes)
+                a12 = ops.sym_linear_act(xt, self.fc12.weight, self.fc12.bias, "relu", self.n_nodes)
         else:
             a11, a12 = self.fc11(x, act="relu"), self.fc12(x, act="relu")
         h11 = self.fc111(a11, act="relu")
@@ -419,9 +429,10 @@ class MDNGateVAE(GCNVAE):
 
     rank_one_sum_decoder = False        # its channels are mixture components, not summands
 
-    def __init__(self, R=5, n_nodes=68, k=32, n_layers=3, latent_dim=68, n_traits=4, symmetric_input=False):
+    def __init__(self, R=5, n_nodes=68, k=32, n_layers=3, latent_dim=68, n_traits=4, symmetric_input=False,
+                 first_layer_gemm="split"):
         super().__init__(R=R, n_nodes=n_nodes, k=k, n_layers=n_layers, latent_dim=latent_dim,
-                         symmetric_input=symmetric_input)
+                         symmetric_input=symmetric_input, first_layer_gemm=first_layer_gemm)
         self.gate = Linear(n_traits, R)
         self.log_sigma = nn.Parameter(torch.zeros(R))
 

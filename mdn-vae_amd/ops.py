@@ -367,6 +367,97 @@ def sym_linear_act(x_tri, weight, bias=None, act=None, n_nodes=None):
     return _SymLinearAct.apply(x_tri, weight, bias, ACTS[act], n_nodes)
 
 
+# ---------------------------------------------------------------------------------------
+# both symmetric-input first layers as one split-bf16 product (fp32 accuracy on the bf16 matrix cores)
+# ---------------------------------------------------------------------------------------
+SPLIT_GEMM_MIN_BATCH = 1024      # below this the 256-row output tiles leave most of the chip idle
+
+
+def _split_operand(rows, k, device):
+    return torch.empty(int(_lib.load().mdnvae_split_operand_bytes(rows, k)), dtype=torch.uint8, device=device)
+
+
+def _round_up(v, m):
+    return (v + m - 1) // m * m
+
+
+class _SymLinearPair(torch.autograd.Function):
+    """relu(x W1^T + b1), relu(x W2^T + b2) for symmetric x given as packed upper triangles xt [B,T]
+    (self.fc11 / self.fc12 of function/MM_Gate.py:157-158, which read the same input): the two folded
+    weights are stacked, every operand is split into three bf16 parts, and ONE hand-written MFMA
+    kernel forms the product with bias + ReLU in its epilogue; the backward forms both folded weight
+    gradients [T,H] with the same kernel from x^T and grad_pre^T."""
+
+    @staticmethod
+    def forward(ctx, xt, w1, b1, w2, b2, n_nodes):
+        w1, w2 = _c(w1), _c(w2)
+        B, T = xt.shape
+        H = w1.shape[0]
+        if w2.shape != w1.shape or H % 256 != 0 or T % 16 != 0 or b1 is None or b2 is None:
+            raise RuntimeError(f"sym_linear_pair: two [H,N*N] weights with biases, H a multiple of 256 (got {tuple(w1.shape)}, "
+                               f"{tuple(w2.shape)}), T a multiple of 16 (got {T})")
+        dev = xt.device
+        wt = torch.empty(2 * H, T, dtype=torch.float32, device=dev)
+        call("mdnvae_tri_fold", ptr(w1, "weight"), H, n_nodes, T, ptr(wt[:H]), stream())
+        call("mdnvae_tri_fold", ptr(w2, "weight"), H, n_nodes, T, ptr(wt[H:]), stream())
+        wb = _split_operand(2 * H, T, dev)
+        call("mdnvae_split_rows", ptr(wt), 2 * H, T, T, 0, wb.data_ptr(), stream())
+        Mp = _round_up(B, 256)
+        xa = _split_operand(Mp, T, dev)
+        call("mdnvae_split_rows", ptr(xt, "x"), B, T, T, 0, xa.data_ptr(), stream())
+        y1 = torch.empty(B, H, dtype=torch.float32, device=dev)
+        y2 = torch.empty(B, H, dtype=torch.float32, device=dev)
+        call("mdnvae_split_gemm", xa.data_ptr(), wb.data_ptr(), Mp, 2 * H, T, B, ptr(b1, "bias"), ptr(b2, "bias"), 1,
+             ptr(y1), ptr(y2), H, H, 256, stream())
+        ctx.save_for_backward(xt, y1, y2)
+        ctx.n_nodes = n_nodes
+        ctx.params = (w1, b1, w2, b2)
+        return y1, y2
+
+    @staticmethod
+    def backward(ctx, g1, g2):
+        xt, y1, y2 = ctx.saved_tensors
+        w1, b1, w2, b2 = ctx.params
+        B, T = xt.shape
+        H, n, dev = y1.shape[1], ctx.n_nodes, xt.device
+        gpre = []
+        for y, g in ((y1, g1), (y2, g2)):
+            gp = torch.empty_like(y)
+            call("mdnvae_act_bwd", ptr(y), ptr(_c(g)), ptr(gp), gp.numel(), ACTS["relu"], stream())
+            gpre.append(gp)
+        gws = [None, None]
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[3]:
+            Kp = _round_up(B, 16)
+            pb = _split_operand(2 * H, Kp, dev)
+            for i, gp in enumerate(gpre):
+                call("mdnvae_split_cols", ptr(gp), B, H, H, i * (H // 32), pb.data_ptr(), stream())
+            Tp = _round_up(T, 128)
+            xb = _split_operand(Tp, Kp, dev)
+            call("mdnvae_split_cols", ptr(xt), B, T, T, 0, xb.data_ptr(), stream())
+            gts = [torch.empty(T, H, dtype=torch.float32, device=dev) for _ in range(2)]
+            call("mdnvae_split_gemm", xb.data_ptr(), pb.data_ptr(), Tp, 2 * H, Kp, T, None, None, 0, ptr(gts[0]), ptr(gts[1]),
+                 H, H, 128, stream())
+            for i, (param, gt) in enumerate(((w1, gts[0]), (w2, gts[1]))):
+                if not ctx.needs_input_grad[1 + 2 * i]:
+                    continue
+                target = _grad_target(param)
+                if target is not None and _SINK.folded is not None:
+                    _SINK.folded(param, gt, n)
+                elif target is not None:
+                    call("mdnvae_tri_unfold", ptr(gt), H, n, H, 1, ptr(target), 1, stream())
+                    _grad_added(param)
+                else:
+                    gws[i] = torch.empty(H, n * n, dtype=torch.float32, device=dev)
+                    call("mdnvae_tri_unfold", ptr(gt), H, n, H, 1, ptr(gws[i]), 0, stream())
+        gb1 = _bias_grad(gpre[0], b1) if ctx.needs_input_grad[2] else None
+        gb2 = _bias_grad(gpre[1], b2) if ctx.needs_input_grad[4] else None
+        return None, gws[0], gb1, gws[1], gb2, None
+
+
+def sym_linear_pair(x_tri, w1, b1, w2, b2, n_nodes):
+    return _SymLinearPair.apply(x_tri, w1, b1, w2, b2, n_nodes)
+
+
 class _AddAct(torch.autograd.Function):
     """act(a + b) with one kernel each way (residual joins)."""
 

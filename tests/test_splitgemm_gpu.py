@@ -1,0 +1,108 @@
+"""The split-bf16 product of the two symmetric-input first layers (self.fc11 / self.fc12 of
+function/MM_Gate.py:157-158): three bf16 parts per fp32 operand, six part products accumulated in fp32
+on the bf16 matrix cores.  It must be as good as fp32 arithmetic: checked against float64 at the fp32
+bars (values 1e-5, gradients 1e-4, relative to the largest entry) and, entry by entry, against the
+error an fp32 accumulation is allowed (a few 1e-7 of sum |a b|)."""
+import pytest
+import torch
+
+import mdnvae_amd as M
+from mdnvae_amd import ops, _lib
+from mdnvae_amd._lib import call, ptr, stream
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _operand(rows, k):
+    return torch.empty(int(_lib.load().mdnvae_split_operand_bytes(rows, k)), dtype=torch.uint8, device=DEV)
+
+
+def _up(v, m):
+    return (v + m - 1) // m * m
+
+
+@pytest.mark.parametrize("Mrows,N,K,tile", [(300, 512, 64, 256), (1000, 2048, 2368, 256), (257, 256, 16, 128),
+                                            (3840, 512, 1000, 128)])
+def test_split_product_against_float64(Mrows, N, K, tile):
+    """out = a . b^T through mdnvae_split_rows / mdnvae_split_cols / mdnvae_split_gemm, with ragged row
+    counts and k extents; entry-wise error against float64 relative to sum |a b|."""
+    g = torch.Generator().manual_seed(Mrows + K)
+    a = torch.randn(Mrows, K, generator=g) * torch.where(torch.rand(Mrows, K, generator=g) < 0.1, 30.0, 1.0)
+    b = torch.randn(N, K, generator=g) * 0.02
+    bias = torch.randn(N, generator=g) * 0.1
+    Kp, Mp = _up(K, 16), _up(Mrows, tile)
+    want = a.double() @ b.double().t()
+    mag = a.double().abs() @ b.double().abs().t()
+    ad, bd = a.to(DEV), b.to(DEV)
+    # row-split operands need k a multiple of 16: pad the sources; the column-split form pads by itself
+    a_pad = torch.zeros(Mrows, Kp, device=DEV)
+    a_pad[:, :K] = ad
+    b_pad = torch.zeros(N, Kp, device=DEV)
+    b_pad[:, :K] = bd
+    for how in ("rows", "cols"):
+        oa, ob = _operand(Mp, Kp), _operand(N, Kp)
+        if how == "rows":
+            call("mdnvae_split_rows", ptr(a_pad), Mrows, Kp, Kp, 0, oa.data_ptr(), stream())
+            call("mdnvae_split_rows", ptr(b_pad), N, Kp, Kp, 0, ob.data_ptr(), stream())
+        else:                                     # from the transposed tensors [K][rows]
+            at, bt = ad.t().contiguous(), bd.t().contiguous()
+            ld_a, ld_b = _up(Mrows, 4), _up(N, 4)
+            at_p = torch.zeros(K, ld_a, device=DEV)
+            at_p[:, :Mrows] = at
+            call("mdnvae_split_cols", ptr(at_p), K, Mrows, ld_a, 0, oa.data_ptr(), stream())
+            call("mdnvae_split_cols", ptr(bt), K, N, ld_b, 0, ob.data_ptr(), stream())
+        half = N // 2 if (N // 2) % 256 == 0 else N
+        out0 = torch.full((Mrows, half), float("nan"), device=DEV)
+        out1 = torch.full((Mrows, N - half), float("nan"), device=DEV) if half < N else None
+        call("mdnvae_split_gemm", oa.data_ptr(), ob.data_ptr(), Mp, N, Kp, Mrows, None, None, 0, ptr(out0), ptr(out1), half,
+             half, tile, stream())
+        got = torch.cat([out0] + ([out1] if out1 is not None else []), dim=1).double().cpu()
+        assert torch.isfinite(got).all()
+        assert float(((got - want).abs() / mag).max()) <= 1e-6, how        # fp32-accumulation level, entry by entry
+        assert float((got - want).abs().max() / want.abs().max()) <= 1e-5
+    # bias + ReLU epilogue
+    bd_ = bias.to(DEV)
+    out0 = torch.empty(Mrows, half, device=DEV)
+    out1 = torch.empty(Mrows, N - half, device=DEV) if half < N else None
+    call("mdnvae_split_gemm", oa.data_ptr(), ob.data_ptr(), Mp, N, Kp, Mrows, ptr(bd_[:half].contiguous()),
+         ptr(bd_[half:].contiguous()) if half < N else None, 1, ptr(out0), ptr(out1), half, half, tile, stream())
+    got = torch.cat([out0] + ([out1] if out1 is not None else []), dim=1).double().cpu()
+    want_r = torch.relu(want + bias.double())
+    assert float((got - want_r).abs().max() / want_r.abs().max()) <= 1e-5
+
+
+@pytest.mark.parametrize("B,n", [(1024, 68), (1500, 87)])
+def test_first_layer_pair_against_float64_and_the_library_path(B, n):
+    """ops.sym_linear_pair (one split product for both layers, forward and weight gradients) against
+    float64 on the full N*N inputs and against ops.sym_linear_act (library fp32 GEMMs)."""
+    torch.manual_seed(B)
+    H, D = 1024, n * n
+    x = M.data.synthetic_sc(B, n, seed=3, device=DEV)
+    w = [(torch.randn(H, D) / D ** 0.5).to(DEV).requires_grad_(True) for _ in range(2)]
+    b = [(torch.randn(H) * 0.05).to(DEV).requires_grad_(True) for _ in range(2)]
+    up = [torch.randn(B, H, device=DEV) * (torch.rand(B, H, device=DEV) < 0.5) for _ in range(2)]
+    asym = torch.zeros(1, dtype=torch.int32, device=DEV)
+    xt = ops.tri_pack(x, n, asym)
+    y = ops.sym_linear_pair(xt, w[0], b[0], w[1], b[1], n)
+    torch.autograd.backward(list(y), up)
+    assert int(asym.item()) == 0
+    got = [t.detach().clone() for t in y] + [t.grad.clone() for t in w + b]
+    for t in w + b:
+        t.grad = None
+    y_lib = [ops.sym_linear_act(xt, w[i], b[i], "relu", n) for i in range(2)]
+    torch.autograd.backward(y_lib, up)
+    lib = [t.detach() for t in y_lib] + [t.grad for t in w + b]
+    x64 = x.double().cpu()
+    w64 = [t.detach().double().cpu().requires_grad_(True) for t in w]
+    b64 = [t.detach().double().cpu().requires_grad_(True) for t in b]
+    y64 = [torch.relu(x64 @ w64[i].t() + b64[i]) for i in range(2)]
+    torch.autograd.backward(y64, [u.double().cpu() for u in up])
+    want = [t.detach() for t in y64] + [t.grad for t in w64 + b64]
+    names = ["y1", "y2", "gw1", "gw2", "gb1", "gb2"]
+    for name, g_, l_, w_ in zip(names, got, lib, want):
+        bar = 1e-5 if name.startswith("y") else 1e-4
+        err = float((g_.double().cpu() - w_).abs().max() / w_.abs().max())
+        err_lib = float((l_.double().cpu() - w_).abs().max() / w_.abs().max())
+        assert err <= bar, (name, err)
+        assert err <= max(4 * err_lib, 1e-6), (name, err, err_lib)      # no worse than the fp32 library GEMM
