@@ -162,6 +162,18 @@ __global__ __launch_bounds__(512) void split_gemm_kernel(const char* __restrict_
         }
     };
 
+    // output columns of this wave, and their biases (loaded now, long landed by the epilogue)
+    const int n_tile0 = tn * 256 + wn * 64;
+    const bool second = n_tile0 >= n_split;
+    float* out = second ? out1 : out0;
+    const int n_base = n_tile0 - (second ? n_split : 0);
+    float bv[2] = {0.0f, 0.0f};
+    if (EPI == SG_EPI_BIAS_RELU) {
+        const float* bias = second ? bias1 : bias0;
+        bv[0] = bias[n_base + (lane & 31)];
+        bv[1] = bias[n_base + 32 + (lane & 31)];
+    }
+
     sg_acc acc[WM][2];
 #pragma unroll
     for (int i = 0; i < WM; ++i)
@@ -177,41 +189,44 @@ __global__ __launch_bounds__(512) void split_gemm_kernel(const char* __restrict_
         if (ks + 1 < KS) stage(buf ^ 1, ks + 1);
         const char* sa = smem + buf * STAGE + (wm * WM) * SG_STEP + lane * 16;
         const char* sb = smem + buf * STAGE + (TA + wn * 2) * SG_STEP + lane * 16;
-        sg_frag a[WM][3], b[2][3];
-#pragma unroll
-        for (int i = 0; i < WM; ++i)
-#pragma unroll
-            for (int s = 0; s < 3; ++s) a[i][s] = *reinterpret_cast<const sg_frag*>(sa + i * SG_STEP + s * SG_FRAG);
+        // B fragments and the first A row tile, then A row tile i + 1 is fetched while the twelve
+        // MFMAs of row tile i run: only the first block of a step waits on LDS
+        sg_frag a[2][3], b[2][3];
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int s = 0; s < 3; ++s) b[j][s] = *reinterpret_cast<const sg_frag*>(sb + j * SG_STEP + s * SG_FRAG);
 #pragma unroll
-        for (int i = 0; i < WM; ++i)
+        for (int s = 0; s < 3; ++s) a[0][s] = *reinterpret_cast<const sg_frag*>(sa + s * SG_FRAG);
+#pragma unroll
+        for (int i = 0; i < WM; ++i) {
+            if (i + 1 < WM) {
+#pragma unroll
+                for (int s = 0; s < 3; ++s)
+                    a[(i + 1) & 1][s] = *reinterpret_cast<const sg_frag*>(sa + (i + 1) * SG_STEP + s * SG_FRAG);
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 // smallest terms first
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i & 1][0], b[j][2], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i & 1][1], b[j][1], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i & 1][2], b[j][0], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i & 1][0], b[j][1], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i & 1][1], b[j][0], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i & 1][0], b[j][0], acc[i][j], 0, 0, 0);
             }
+            __builtin_amdgcn_sched_barrier(0);
+        }
         __syncthreads();
     }
 
     // epilogue: accumulator register e of a 32 x 32 tile is row (e & 3) + 8 (e >> 2) + 4 (lane >> 5),
-    // column lane & 31
-    const int n_tile0 = tn * 256 + wn * 64;
-    const bool second = n_tile0 >= n_split;
-    float* out = second ? out1 : out0;
-    const float* bias = second ? bias1 : bias0;
-    const int n_base = n_tile0 - (second ? n_split : 0);
+    // column lane & 31.  A tile that lies wholly inside the valid rows stores without per-row tests.
+    const bool whole = (tm * TA + wm * WM + WM) * 32 <= m_valid;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        const int n = n_base + j * 32 + (lane & 31);
-        const float bv = EPI == SG_EPI_BIAS_RELU ? bias[n] : 0.0f;
+        float* col = out + n_base + j * 32 + (lane & 31);
 #pragma unroll
         for (int i = 0; i < WM; ++i) {
             const int m0 = (tm * TA + wm * WM + i) * 32 + 4 * (lane >> 5);
@@ -219,8 +234,9 @@ __global__ __launch_bounds__(512) void split_gemm_kernel(const char* __restrict_
             for (int e = 0; e < 16; ++e) {
                 const int m = m0 + (e & 3) + 8 * (e >> 2);
                 float v = acc[i][j][e];
-                if (EPI == SG_EPI_BIAS_RELU) v = fmaxf(v + bv, 0.0f);
-                if (m < m_valid) out[(long)m * ld_out + n] = v;
+                if (EPI == SG_EPI_BIAS_RELU) v = fmaxf(v + bv[j], 0.0f);
+                if (whole) col[(long)m * ld_out] = v;
+                else if (m < m_valid) col[(long)m * ld_out] = v;
             }
         }
     }

@@ -31,3 +31,23 @@ def fixture_params(fix, dtype=None):
 @pytest.fixture(scope="session")
 def golden():
     return load_fixture
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """Achieved errors next to the bars in force, for every gradient check that went through
+    recipe.check_grad / recipe.record in this session (gpurun_out/parity_report.md)."""
+    import recipe
+    if not recipe.REPORT:
+        return
+    out = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    groups = {}
+    for tag, what, name, achieved, bar, note, noise in recipe.REPORT:
+        groups.setdefault((tag, what, note), []).append((name, achieved, bar, noise))
+    with open(os.path.join(out, "parity_report.md"), "w") as f:
+        f.write("| fixture / case | path | checks | worst quantity (by achieved / bar) | achieved | bar in force | "
+                "reference's own fp32 run | measure |\n|---|---|---|---|---|---|---|---|\n")
+        for (tag, what, note), rows in sorted(groups.items()):
+            name, achieved, bar, noise = max(rows, key=lambda r: r[1] / max(r[2], 1e-300))
+            f.write(f"| {tag} | {what} | {len(rows)} | {name} | {achieved:.2e} | {bar:.2e} | "
+                    f"{'' if noise is None else format(noise, '.2e')} | {note} |\n")

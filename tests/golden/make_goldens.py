@@ -451,7 +451,23 @@ def make_prep():
          rows_fisher=rows_fz)
 
 
-ALL = dict(cnn_nn_sc=make_cnn_nn_sc, cnn_gcn_sc=make_cnn_gcn_sc, cnn_gcn_fc=make_cnn_gcn_fc,
+def make_traits():
+    """The reference's own conditioning data for the trait-gated mixture model: data/trait.pt (a plain
+    [100,4] fp32 tensor, read with a loader that executes nothing from the file) next to the 100
+    structural connectomes of data/HCP_samples.mat prepared as function/VAE_CNN_NN.py:32-39 does,
+    and the k-NN adjacency of function/MM_Gate.py:55-65 on their group mean.  Data only: the mixture
+    head is build-defined, so its expected values come from the build's own float64 statement at
+    test time."""
+    traits = torch.load(os.path.join(REF, "data/trait.pt"), weights_only=True)
+    assert isinstance(traits, torch.Tensor) and tuple(traits.shape) == (100, 4)
+    x, A_mat, _, _ = sc_inputs()
+    ns = load_defs("function/MM_Gate.py")
+    adjacency = [list(map(int, a)) for a in ns["build_knn_adjacency"](A_mat, k=32)]
+    save("traits", traits=traits.numpy().astype(np.float32), x=x.astype(np.float32),
+         adjacency=np.array(adjacency, dtype=np.int64))
+
+
+ALL = dict(traits=make_traits, cnn_nn_sc=make_cnn_nn_sc, cnn_gcn_sc=make_cnn_gcn_sc, cnn_gcn_fc=make_cnn_gcn_fc,
            cnn_nn_fc=make_cnn_nn_fc, mm_gate=make_mm_gate, fnn_gcn_fc=make_fnn_gcn_fc, cvae=make_cvae, ec87=make_ec87,
            losses=make_losses, fid=make_fid, prep=make_prep, graphs=make_graphs, resnet_fc=make_resnet_fc)
 

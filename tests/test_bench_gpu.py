@@ -29,5 +29,7 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     assert roof["bound"] in ("hbm", "mfma") and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9
     assert d["script_batch"]["graph"]["value"] > 0 and d["n68"]["value"] > 0
     # the same workload without the symmetric-input promise is reported next to the headline
-    assert d["full_first_layer"]["value"] > 0 and "packed upper triangle" not in d["full_first_layer"]["workload"]
-    assert "packed upper triangle" in d["config"]["workload"]
+    assert d["full_first_layer"]["value"] > 0
+    assert d["config"]["symmetric_first_layer"] is True and len(d["config"]["workload"]) <= 128
+    assert d["config"]["full_first_layer_value"] == d["full_first_layer"]["value"]
+    assert not d["roofline"]["kernel"].startswith("library_")          # a hand-written kernel

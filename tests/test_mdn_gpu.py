@@ -268,3 +268,53 @@ def test_mdn_trainer_streams_a_target_that_is_the_verified_symmetric_input(monke
     assert seen == [True, False]
     assert abs(got[0][0] - got[1][0]) <= 1e-6 * abs(got[1][0])
     assert _rel(got[0][1], got[1][1]) <= 1e-5
+
+
+def test_mixture_model_on_the_reference_traits_and_subjects():
+    """BASELINE config 2 on the reference's own data: the 100 structural connectomes of
+    data/HCP_samples.mat conditioned on data/trait.pt (tests/golden/traits.npz).  The mixture head is
+    build-defined (the reference never loads trait.pt), so the expected values are the build's own
+    float64 statement: loss 1e-5, gradients 1e-4, for the plain and the symmetric-input model; then
+    one epoch of training lowers the loss."""
+    fix = load_fixture("traits")
+    params = fixture_params(load_fixture("mm_gate"))
+    x = torch.from_numpy(fix["x"])
+    traits = torch.from_numpy(fix["traits"])
+    adjacency = [list(map(int, r)) for r in fix["adjacency"]]
+    eps = torch.randn(x.shape[0], 68, generator=torch.Generator().manual_seed(11))
+    want = {}
+    for sym in (False, True):
+        torch.manual_seed(5)
+        model = M.MDNGateVAE(R=5, n_nodes=68, k=32, n_layers=3, latent_dim=68, n_traits=4, symmetric_input=sym)
+        model.load_state_dict(params, strict=False)
+        with torch.no_grad():
+            model.log_sigma.fill_(3.0)           # broad components: responsibilities stay mixed on these heavy-tailed targets
+        if not want:                                  # float64 statement of the same model
+            p = {k: v.detach().double().clone().requires_grad_(True) for k, v in model.state_dict().items()
+                 if not k.startswith("_")}
+            mu, lv = R.fnn_encode(p, x.double())
+            z = R.reparameterize(mu, lv, eps.double())
+            comp = R.gcn_components(p, z, adjacency)
+            logits = R.mdn_gate_logits(traits.double(), p["gate.weight"], p["gate.bias"])
+            total = R.mdn_nll(comp, p["log_sigma"], logits, x.double()) + R.kl_term(mu, lv)
+            total.backward()
+            want = {"loss": total.item(), "grads": {k: v.grad for k, v in p.items()}}
+        trainer = M.Trainer(model.to(DEV), "mdn", folded_adam=False)
+        xd = x.to(DEV)
+        loss = trainer.forward_backward((xd, adjacency, traits.to(DEV)), xd, eps=eps.to(DEV))
+        model.check_inputs()
+        assert abs(loss.item() - want["loss"]) <= 1e-5 * abs(want["loss"])
+        for name, prm in model.named_parameters():
+            assert _rel(prm.grad, want["grads"][name]) <= 1e-4, (sym, name)
+    # the trait gate matters on this data and training moves: an epoch lowers the loss
+    torch.manual_seed(5)
+    model = M.MDNGateVAE(R=5, n_nodes=68, k=32, n_layers=3, latent_dim=68, n_traits=4, symmetric_input=True)
+    trainer = M.Trainer(model.to(DEV), "mdn")
+    gen = torch.Generator(device=DEV).manual_seed(1)
+    tr = traits.to(DEV)
+    first = trainer.train_epoch(x.to(DEV), batch_size=32, extra=lambda idx: (adjacency, tr.index_select(0, idx)),
+                                generator=gen, eps_generator=torch.Generator(device=DEV).manual_seed(2))
+    for _ in range(3):
+        last = trainer.train_epoch(x.to(DEV), batch_size=32, extra=lambda idx: (adjacency, tr.index_select(0, idx)),
+                                   generator=gen, eps_generator=torch.Generator(device=DEV).manual_seed(2))
+    assert last < first
