@@ -398,10 +398,30 @@ int mdnvae_fid_finalize(const double* gram, const double* sum, const float* shif
                         double* cov, void* stream);
 /* Elementwise steps of the coupled Newton-Schulz square root (float64; the products are library
  * GEMMs issued by the host): t = 1.5 I - 0.5 zy;  out = scale * (a + a^T)/2;
- * out2 = {trace(a), ||a||_F^2}. */
+ * out2 = {trace(a), ||a||_F^2} (above 256 rows summed with float64 atomics: the last bits depend on the
+ * order of arrival). */
 int mdnvae_ns_residual(const double* zy, int d, double* t, void* stream);
 int mdnvae_symmetrize(const double* a, int d, double scale, double* out, void* stream);
 int mdnvae_trace_norm(const double* a, int d, double* out2, void* stream);
+/* out[0] = max_i sum_j |a_ij|: with the Frobenius norm, the two bounds of the largest eigenvalue the
+ * iteration scales by (it needs the spectrum inside (0, 1]; the tighter bound saves iterations). */
+int mdnvae_inf_norm(const double* a, int d, double* out, void* stream);
+/* The step of the iteration that yields a square-root FACTOR (Y with Y Y^T = A; no counterpart in the
+ * reference, which calls scipy's sqrtm at function/VAE_CNN_NN.py:313): w = Z Y is symmetric up to rounding,
+ * t = 1.5 I - 0.25 (w + w^T), and gap[0] = ||I - w||_F^2 (cleared by the call, summed with float64
+ * atomics, so its last bits depend on the order of arrival).  mdnvae_trace: out[0] = trace(a). */
+int mdnvae_ns_residual_gap(const double* w, int d, double* t, double* gap, void* stream);
+int mdnvae_trace(const double* a, int d, double* out, void* stream);
+
+/* The same steps in fp32 on padded matrices [d][ld] (ld a multiple of 32; columns d..ld-1 of every output
+ * are zero), for the part of the iteration that runs as split-bf16 products (mdnvae_split_gemm) before a
+ * few float64 steps finish it: t = 1.5 I - 0.5 zy;  out = scale (a + a^T)/2;  out[0] = trace(a) in
+ * float64;  and the conversions between a float64 [d][d] matrix and its padded fp32 copy. */
+int mdnvae_ns_residual_f32(const float* zy, int d, long ld, float* t, void* stream);
+int mdnvae_symmetrize_f32(const float* a, int d, long ld, float scale, float* out, void* stream);
+int mdnvae_trace_f32(const float* a, int d, long ld, double* out, void* stream);
+int mdnvae_f64_to_f32_padded(const double* a, int d, long ld, float* out, void* stream);
+int mdnvae_f32_padded_to_f64(const float* a, int d, long ld, double* out, void* stream);
 
 /* ---- evaluation loop ------------------------------------------------------------------------
  * function/VAE_CNN_NN.py:268-271: max_value = real.max(); real/max_value; max(generated/max_value, 0);

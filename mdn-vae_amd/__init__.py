@@ -8,7 +8,7 @@ from . import _lib  # noqa: F401
 from .ops import reparameterize, vae_loss, vae_loss_terms, vae_loss_and_grads, mdn_loss, mdn_loss_terms  # noqa: F401
 
 from . import ops, data, fid, evaluate  # noqa: F401
-from .fid import calculate_fid, FeatureStats, feature_stats, fid_from_stats, sqrtm_psd  # noqa: F401
+from .fid import calculate_fid, FeatureStats, feature_stats, fid_from_stats, sqrtm_psd, sqrt_factor  # noqa: F401
 from .trainer import Trainer, FlatBuffers, allreduce_sum  # noqa: F401
 from .modules import (ConvVAE, GCNVAE, MDNGateVAE, cVAE, GraphCNN, Linear, GCNLayer, ChannelGCN, MultiChannelGCNDecoder,  # noqa: F401
                       DiagonalIntercept, loss_function_poisson_rate, loss_function_poisson_log, loss_function_mse,

@@ -245,21 +245,130 @@ __global__ __launch_bounds__(256) void symmetrize_kernel(const double* __restric
     out[idx] = 0.5 * (a[idx] + a[(long)j * d + i]) * scale;
 }
 
-// out[0] = trace(a), out[1] = sum of squares (Frobenius norm^2); one workgroup, fixed order
+// out[0] += trace(a), out[1] += sum of squares (Frobenius norm^2) over this workgroup's share of the rows;
+// the caller zeroes out[0..1]
 __global__ __launch_bounds__(256) void trace_norm_kernel(const double* __restrict__ a, int d, double* __restrict__ out) {
     __shared__ double red[4];
     double tr = 0.0, sq = 0.0;
-    for (long idx = threadIdx.x; idx < (long)d * d; idx += 256) {
-        const double v = a[idx];
-        sq += v * v;
-        if (idx / d == idx % d) tr += v;
+    for (int i = blockIdx.x; i < d; i += gridDim.x) {
+        const double* row = a + (long)i * d;
+        for (int j = threadIdx.x; j < d; j += 256) {
+            const double v = row[j];
+            sq += v * v;
+            if (j == i) tr += v;
+        }
     }
     tr = block_sum<256, double>(tr, red);
     sq = block_sum<256, double>(sq, red);
     if (threadIdx.x == 0) {
-        out[0] = tr;
-        out[1] = sq;
+        atomicAdd(out, tr);
+        atomicAdd(out + 1, sq);
     }
+}
+
+// out[0] = max over rows of sum |a_ij| (the infinity norm, an upper bound of the largest eigenvalue of a symmetric
+// matrix); non-negative doubles order like their bit patterns, so the maximum is an integer atomic.  The caller
+// zeroes out[0].
+__global__ __launch_bounds__(256) void inf_norm_kernel(const double* __restrict__ a, int d, double* __restrict__ out) {
+    __shared__ double red[4];
+    double best = 0.0;
+    for (int i = blockIdx.x; i < d; i += gridDim.x) {
+        const double* row = a + (long)i * d;
+        double s = 0.0;
+        for (int j = threadIdx.x; j < d; j += 256) s += fabs(row[j]);
+        s = block_sum<256, double>(s, red);
+        best = s > best ? s : best;                    // NaN rows: s > best is false; the Frobenius norm catches them
+    }
+    if (threadIdx.x == 0)
+        atomicMax(reinterpret_cast<unsigned long long*>(out), (unsigned long long)__double_as_longlong(best));
+}
+
+// t = 1.5 I - 0.25 (w + w^T), and gap[0] += sum of (I - w)^2 over this tile (the caller zeroes gap[0]).  One
+// workgroup per 32 x 32 tile, the mirror tile through LDS.
+__global__ __launch_bounds__(256) void ns_residual_gap_kernel(const double* __restrict__ w, int d, double* __restrict__ t,
+                                                              double* __restrict__ gap) {
+    __shared__ double tr[32][33];
+    __shared__ double red[4];
+    const int bi = blockIdx.y, bj = blockIdx.x;
+    const int c = threadIdx.x & 31, r0 = threadIdx.x >> 5;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int r = r0 + 8 * p, i = bj * 32 + r, j = bi * 32 + c;
+        tr[r][c] = (i < d && j < d) ? w[(long)i * d + j] : 0.0;
+    }
+    __syncthreads();
+    double acc = 0.0;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int r = r0 + 8 * p, i = bi * 32 + r, j = bj * 32 + c;
+        if (i < d && j < d) {
+            const double x = w[(long)i * d + j], eye = i == j ? 1.0 : 0.0;
+            t[(long)i * d + j] = 1.5 * eye - 0.25 * (x + tr[c][r]);
+            acc += (eye - x) * (eye - x);
+        }
+    }
+    acc = block_sum<256, double>(acc, red);
+    if (threadIdx.x == 0) atomicAdd(gap, acc);
+}
+
+// out[0] = trace(a) of a [d][d] float64 matrix
+__global__ __launch_bounds__(256) void trace_f64_kernel(const double* __restrict__ a, int d, double* __restrict__ out) {
+    __shared__ double red[4];
+    double t = 0.0;
+    for (int i = threadIdx.x; i < d; i += 256) t += a[(long)i * d + i];
+    t = block_sum<256, double>(t, red);
+    if (threadIdx.x == 0) out[0] = t;
+}
+
+// ---- fp32 steps of the coupled Newton-Schulz iteration on padded matrices [d][ld] (ld a multiple of 32;
+// columns d .. ld-1 are kept zero: they are the k padding of the split-bf16 products that form Z Y, Y T, T Z) ----
+// kind 0: out = 1.5 I - 0.5 a;  kind 1: out = scale (a + a^T) / 2.  One workgroup per 32 x 32 tile; the
+// transposed tile comes through LDS so both reads move whole cache lines.
+template <int KIND>
+__global__ __launch_bounds__(256) void ns_tile_kernel(const float* __restrict__ a, int d, long ld, float scale,
+                                                      float* __restrict__ out) {
+    __shared__ float tr[32][33];
+    const int bi = blockIdx.y, bj = blockIdx.x;
+    const int c = threadIdx.x & 31, r0 = threadIdx.x >> 5;
+    if (KIND == 1) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int r = r0 + 8 * p, i = bj * 32 + r, j = bi * 32 + c;      // the mirror tile (bj, bi)
+            tr[r][c] = (i < d && j < d) ? a[(long)i * ld + j] : 0.0f;
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int r = r0 + 8 * p, i = bi * 32 + r, j = bj * 32 + c;
+        if (i >= d) continue;
+        float v = 0.0f;
+        if (j < d) {
+            const float x = a[(long)i * ld + j];
+            v = KIND == 0 ? (i == j ? 1.5f : 0.0f) - 0.5f * x : 0.5f * scale * (x + tr[c][r]);
+        }
+        out[(long)i * ld + j] = v;
+    }
+}
+__global__ __launch_bounds__(256) void trace_f32_kernel(const float* __restrict__ a, int d, long ld, double* __restrict__ out) {
+    __shared__ double red[4];
+    double t = 0.0;
+    for (int i = threadIdx.x; i < d; i += 256) t += (double)a[(long)i * ld + i];
+    t = block_sum<256, double>(t, red);
+    if (threadIdx.x == 0) out[0] = t;
+}
+// out [d][ld] fp32 = a [d][d] float64 (padding columns zero), and back
+__global__ __launch_bounds__(256) void narrow_pad_kernel(const double* __restrict__ a, int d, long ld, float* __restrict__ out) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)d * ld) return;
+    const int i = (int)(idx / ld), j = (int)(idx % ld);
+    out[idx] = j < d ? (float)a[(long)i * d + j] : 0.0f;
+}
+__global__ __launch_bounds__(256) void widen_unpad_kernel(const float* __restrict__ a, int d, long ld, double* __restrict__ out) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)d * d) return;
+    const int i = (int)(idx / d), j = (int)(idx % d);
+    out[idx] = (double)a[(long)i * ld + j];
 }
 
 }  // namespace mdnvae
@@ -368,8 +477,83 @@ int mdnvae_symmetrize(const double* a, int d, double scale, double* out, void* s
 
 int mdnvae_trace_norm(const double* a, int d, double* out2, void* stream) {
     MV_REQUIRE(d >= 1 && a && out2, E_ARG, "mdnvae_trace_norm: bad argument");
-    hipLaunchKernelGGL(trace_norm_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, a, d, out2);
+    hipStream_t st = (hipStream_t)stream;
+    const hipError_t e = hipMemsetAsync(out2, 0, 2 * sizeof(double), st);
+    MV_REQUIRE(e == hipSuccess, (int)e, "mdnvae_trace_norm: clearing the result failed: %s", hipGetErrorString(e));
+    // one workgroup up to 256 rows: small matrices keep a fixed summation order
+    hipLaunchKernelGGL(trace_norm_kernel, dim3(d <= 256 ? 1u : 512u), dim3(256), 0, st, a, d, out2);
     MV_LAUNCH_CHECK("trace_norm_kernel");
+    return 0;
+}
+
+int mdnvae_inf_norm(const double* a, int d, double* out, void* stream) {
+    MV_REQUIRE(d >= 1 && a && out, E_ARG, "mdnvae_inf_norm: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    const hipError_t e = hipMemsetAsync(out, 0, sizeof(double), st);
+    MV_REQUIRE(e == hipSuccess, (int)e, "mdnvae_inf_norm: clearing the result failed: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(inf_norm_kernel, dim3(d < 512 ? (unsigned)d : 512u), dim3(256), 0, st, a, d, out);
+    MV_LAUNCH_CHECK("inf_norm_kernel");
+    return 0;
+}
+
+int mdnvae_ns_residual_gap(const double* w, int d, double* t, double* gap, void* stream) {
+    MV_REQUIRE(d >= 1 && w && t && gap && w != t, E_ARG, "mdnvae_ns_residual_gap: bad argument (in-place is not supported)");
+    hipStream_t st = (hipStream_t)stream;
+    const hipError_t e = hipMemsetAsync(gap, 0, sizeof(double), st);
+    MV_REQUIRE(e == hipSuccess, (int)e, "mdnvae_ns_residual_gap: clearing gap failed: %s", hipGetErrorString(e));
+    const unsigned tiles = (unsigned)((d + 31) / 32);
+    hipLaunchKernelGGL(ns_residual_gap_kernel, dim3(tiles, tiles), dim3(256), 0, st, w, d, t, gap);
+    MV_LAUNCH_CHECK("ns_residual_gap_kernel");
+    return 0;
+}
+
+int mdnvae_trace(const double* a, int d, double* out, void* stream) {
+    MV_REQUIRE(d >= 1 && a && out, E_ARG, "mdnvae_trace: bad argument");
+    hipLaunchKernelGGL(trace_f64_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, a, d, out);
+    MV_LAUNCH_CHECK("trace_f64_kernel");
+    return 0;
+}
+
+static int ns_f32_args(const char* fn, const void* a, int d, long ld, const void* out) {
+    MV_REQUIRE(d >= 1 && ld >= d && ld % 32 == 0, E_ARG, "%s: d = %d, ld = %ld (ld a multiple of 32, at least d)", fn, d, ld);
+    MV_REQUIRE(a && out && a != out, E_ARG, "%s: null pointer, or in-place", fn);
+    return 0;
+}
+
+int mdnvae_ns_residual_f32(const float* zy, int d, long ld, float* t, void* stream) {
+    if (int rc = ns_f32_args("mdnvae_ns_residual_f32", zy, d, ld, t)) return rc;
+    hipLaunchKernelGGL(ns_tile_kernel<0>, dim3((unsigned)(ld / 32), (unsigned)((d + 31) / 32)), dim3(256), 0,
+                       (hipStream_t)stream, zy, d, ld, 1.0f, t);
+    MV_LAUNCH_CHECK("ns_tile_kernel");
+    return 0;
+}
+
+int mdnvae_symmetrize_f32(const float* a, int d, long ld, float scale, float* out, void* stream) {
+    if (int rc = ns_f32_args("mdnvae_symmetrize_f32", a, d, ld, out)) return rc;
+    hipLaunchKernelGGL(ns_tile_kernel<1>, dim3((unsigned)(ld / 32), (unsigned)((d + 31) / 32)), dim3(256), 0,
+                       (hipStream_t)stream, a, d, ld, scale, out);
+    MV_LAUNCH_CHECK("ns_tile_kernel");
+    return 0;
+}
+
+int mdnvae_trace_f32(const float* a, int d, long ld, double* out, void* stream) {
+    if (int rc = ns_f32_args("mdnvae_trace_f32", a, d, ld, out)) return rc;
+    hipLaunchKernelGGL(trace_f32_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, a, d, ld, out);
+    MV_LAUNCH_CHECK("trace_f32_kernel");
+    return 0;
+}
+
+int mdnvae_f64_to_f32_padded(const double* a, int d, long ld, float* out, void* stream) {
+    if (int rc = ns_f32_args("mdnvae_f64_to_f32_padded", a, d, ld, out)) return rc;
+    hipLaunchKernelGGL(narrow_pad_kernel, dim3(grid_for((long)d * ld)), dim3(256), 0, (hipStream_t)stream, a, d, ld, out);
+    MV_LAUNCH_CHECK("narrow_pad_kernel");
+    return 0;
+}
+
+int mdnvae_f32_padded_to_f64(const float* a, int d, long ld, double* out, void* stream) {
+    if (int rc = ns_f32_args("mdnvae_f32_padded_to_f64", a, d, ld, out)) return rc;
+    hipLaunchKernelGGL(widen_unpad_kernel, dim3(grid_for((long)d * d)), dim3(256), 0, (hipStream_t)stream, a, d, ld, out);
+    MV_LAUNCH_CHECK("widen_unpad_kernel");
     return 0;
 }
 

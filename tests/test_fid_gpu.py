@@ -8,6 +8,7 @@ import pytest
 import torch
 
 from conftest import load_fixture
+from recipe import record
 
 pytestmark = pytest.mark.gpu
 
@@ -67,6 +68,110 @@ def test_sqrtm_psd_properties(M):
     assert float((root @ root - a).norm() / a.norm()) < 1e-9
     mu = torch.zeros(d, dtype=torch.float64)
     assert abs(M.calculate_fid(mu, a, mu, a)) < 1e-6 * float(torch.trace(a))
+
+
+def _psd(d, floor, rng):
+    if floor > 0:
+        q, _ = np.linalg.qr(rng.standard_normal((d, d)))
+        a = (q * np.exp(rng.uniform(np.log(floor), 0.0, d))) @ q.T
+    else:
+        q = rng.standard_normal((d, 300))        # rank 300, like a covariance of fewer samples than features
+        a = q @ q.T / 300.0
+    return (a + a.T) / 2
+
+
+@pytest.mark.parametrize("d,floor", [(640, 1e-6), (1000, 1e-3), (1024, 0.0)])
+def test_large_principal_root_against_float64_eigendecomposition(M, d, floor):
+    """sqrtm_psd against numpy's eigh on spectra that span 1/floor (floor 0: singular): root^2 against A at
+    1e-9 of the Frobenius norm, the trace against the sum of root eigenvalues at 1e-10; on the singular
+    matrix 1e-6 (the ridge that keeps the iteration bounded moves it by up to 1e-7 per null direction)."""
+    a = _psd(d, floor, np.random.default_rng(d))
+    want_tr = np.sqrt(np.clip(np.linalg.eigvalsh(a), 0, None)).sum()
+    root, iters = M.sqrtm_psd(torch.from_numpy(a).cuda())
+    got = root.cpu().numpy()
+    err = np.linalg.norm(got @ got - a) / np.linalg.norm(a)
+    tr_err = abs(np.trace(got) - want_tr) / want_tr
+    tr_bar = 1e-10 if floor > 0 else 1e-6
+    record("fid", "sqrtm_psd: root^2 vs A", f"d={d} spectrum floor {floor:g}", err, 1e-9, note=f"{iters} iterations")
+    record("fid", "sqrtm_psd: trace vs sum of root eigenvalues", f"d={d} spectrum floor {floor:g}", tr_err, tr_bar)
+    assert err < 1e-9 and tr_err < tr_bar
+
+
+@pytest.mark.parametrize("d,floor,tr_bar", [(640, 0.05, 1e-9), (1000, 1e-3, 1e-5)])
+def test_mixed_precision_root_factor(M, d, floor, tr_bar):
+    """sqrt_factor (first iterations in split-bf16 products, float64 finish): F F^T is A to float64 rounding
+    at any condition it accepts; the trace is off in second order of the fp32 phase's error, which grows
+    with the condition number: 1e-9 at condition 20, 1e-5 at condition 1000."""
+    a = _psd(d, floor, np.random.default_rng(d))
+    want_tr = np.sqrt(np.clip(np.linalg.eigvalsh(a), 0, None)).sum()
+    f, iters = M.sqrt_factor(torch.from_numpy(a).cuda())
+    got = f.cpu().numpy()
+    err = np.linalg.norm(got @ got.T - a) / np.linalg.norm(a)
+    tr_err = abs(np.trace(got) - want_tr) / want_tr
+    record("fid", "sqrt_factor: F F^T vs A", f"d={d} condition {1 / floor:g}", err, 1e-9, note=f"{iters} iterations")
+    record("fid", "sqrt_factor: trace vs sum of root eigenvalues", f"d={d} condition {1 / floor:g}", tr_err, tr_bar)
+    assert err < 1e-9 and tr_err < tr_bar
+
+
+def test_fid_at_the_validation_size(M):
+    """The conv scripts' validation at full size: two sets of 100 000 flattened 68 x 68 networks
+    (4624 features).  Size-independent properties: moments accumulated in chunks, and summed over two
+    halves as two data-parallel ranks would, equal the one-call moments; FID(A, A) = 0; FID(A, B) is
+    symmetric; and on features with independent columns of known variance it sits just above the closed form
+    |mu1 - mu2|^2 + sum (s1 - s2)^2 of the diagonal case (finite-sample bias)."""
+    import time
+    n, d = 100_000, 4624
+    g = torch.Generator(device="cuda").manual_seed(11)
+    a = torch.randn(n, d, device="cuda", generator=g)
+    b = torch.randn(n, d, device="cuda", generator=g) * 1.5 + 0.02
+    shift = a[0].clone()
+    whole = M.FeatureStats(d, shift).update(a)
+    parts = [M.FeatureStats(d, shift), M.FeatureStats(d, shift)]
+    half = n // 2 + 7
+    for lo in range(0, half, 16384):
+        parts[0].update(a[lo:min(lo + 16384, half)])
+    parts[1].update(a[half:])
+    parts[0].sum += parts[1].sum                 # what the all-reduce does
+    parts[0].gram += parts[1].gram
+    parts[0].n += parts[1].n
+    m1, c1 = whole.finalize()
+    m1p, c1p = parts[0].finalize()
+    assert parts[0].n == n
+    # the Gram kernel sums 1024-row chunks in fp32 before the float64 accumulator; other chunk boundaries
+    # round differently: unit-variance features, so the bar is that of the moments test (2e-5)
+    cov_err = float((c1 - c1p).abs().max())
+    record("fid", "moments summed over chunks and ranks vs one call", "100000 x 4624", cov_err, 2e-5)
+    assert cov_err < 2e-5 and float((m1 - m1p).abs().max()) < 1e-9
+    del whole, parts
+    m2, c2 = M.feature_stats(b)
+    M.fid_from_stats(m1, c1, m1, c1)             # first call pays library start-up
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    same = M.fid_from_stats(m1, c1, m1, c1)
+    torch.cuda.synchronize()
+    t_same = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    ab = M.fid_from_stats(m1, c1, m2, c2)
+    torch.cuda.synchronize()
+    t_ab = time.perf_counter() - t0
+    ba = M.fid_from_stats(m2, c2, m1, c1)
+    t0 = time.perf_counter()
+    ab_mixed = M.fid_from_stats(m1, c1, m2, c2, mixed=True)
+    torch.cuda.synchronize()
+    t_mixed = time.perf_counter() - t0
+    record("fid", "FID(A, B), mixed-precision roots vs float64 roots", "d=4624", abs(ab_mixed - ab) / ab, 1e-9,
+           note=f"{t_mixed:.3f} s per call")
+    assert abs(ab_mixed - ab) < 1e-9 * ab
+    tr = float(torch.trace(c1))
+    record("fid", "FID(A, A) / trace", "d=4624", abs(same) / tr, 1e-9, note=f"{t_same:.3f} s per call")
+    assert abs(same) < 1e-9 * tr
+    record("fid", "FID(A, B) vs FID(B, A)", "d=4624", abs(ab - ba) / ab, 1e-9, note=f"{t_ab:.3f} s per call")
+    assert abs(ab - ba) < 1e-9 * ab
+    # independent columns: the population FID is d * (0.02^2 + (1.5 - 1)^2); sample covariances of d / n = 0.05
+    # spread their eigenvalues, which lowers tr sqrt(S1 S2) and biases the FID upward (by 14 % here)
+    closed = d * (0.02 ** 2 + 0.25)
+    assert closed < ab < 1.25 * closed
+    assert t_ab < 1.0                            # two matrix square roots at d = 4624
 
 
 def test_fid_rejects_bad_input(M):

@@ -112,12 +112,18 @@ def bench_fid(n, d):
     m1, c1 = M.feature_stats(a)
     m2, c2 = M.feature_stats(b)
     import time
-    torch.cuda.synchronize()
+    for tag, mixed in (("first call", False), ("second call", False), ("mixed, first call", True), ("mixed, second call", True)):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        val = M.fid_from_stats(m1, c1, m2, c2, mixed=mixed)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        out.append(dict(kernel="fid_from_stats (2 Newton-Schulz square roots), " + tag, d=d, s=dt, fid=val))
     t0 = time.perf_counter()
-    val = M.fid_from_stats(m1, c1, m2, c2)
+    root, iters = M.sqrtm_psd(c1)
     torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    out.append(dict(kernel="fid_from_stats(2 Newton-Schulz sqrtm, fp64 library GEMMs)", d=d, s=dt, fid=val))
+    out.append(dict(kernel="sqrtm_psd", d=d, s=time.perf_counter() - t0, iterations=iters,
+                    residual=float((root @ root - c1).norm() / c1.norm())))
     return out
 
 
