@@ -349,6 +349,233 @@ __global__ __launch_bounds__(256, (SI > 8 ? 2 : 3)) void conv_mfma_kernel(ConvGe
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// forward / data-gradient kernel on the bf16 matrix cores (operands rounded to bf16, fp32 accumulation)
+// ---------------------------------------------------------------------------------------
+// Same tiling as conv_mfma_kernel (256 flattened (sample, pixel) rows x 96 output channels per
+// workgroup), with the K dimension of one v_mfma_f32_32x32x16_bf16 running over 16 input channels.
+// Per chunk of 16 channels a thread stages whole slab positions: it loads the 16 channel values of a
+// position (consecutive lanes = consecutive positions, so every load is coalesced along the plane),
+// applies the producer's instance norm + ReLU if asked, rounds to bf16 and writes two 16-byte pieces,
+// slab[k half][position][8 channels] - which is exactly the A operand fragment of a lane, read back
+// with one ds_read_b128 per (32-row tile, tap).  Weights arrive pre-packed as whole B fragments
+// ([tap][chunk][32-channel tile][lane][8 bf16], 1 KiB each) by 16-byte LDS-DMA.  LDS is single
+// buffered: a second and third resident workgroup cover the staging of the first.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int BF_CK = 16;
+
+template <int IT, int TAPS, bool PLAIN>
+__global__ __launch_bounds__(256, 2) void conv_bf16_kernel(ConvGeom g, const float* __restrict__ x,
+                                                            const float* __restrict__ stats,
+                                                            const char* __restrict__ wp,
+                                                            const float* __restrict__ bias, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char smem_b[];
+    constexpr int WM = 2, WN = 3, WAVES = 4;
+    constexpr int NT = WAVES * 64;
+    constexpr int PT = WAVES * WM * 32;
+    constexpr int NTILE = WN * 32;
+    char* wl = smem_b;                                    // [ntaps][WN][1 KiB]
+    char* slab = smem_b + MAX_TAPS * WN * 1024;           // [2 k halves][slab_stride][16 B]
+    const int half = g.slab_stride * 16;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, l32 = lane & 31;
+    const int P = g.SH * g.SW;
+    const long Q = (long)g.B * P;
+    const long q0 = (long)blockIdx.x * PT;
+    const int n0 = blockIdx.y * NTILE;
+    const long qlast = min(Q - 1, q0 + PT - 1);
+    const int s0 = (int)(q0 / P);
+    const int pa0 = (int)(q0 - (long)s0 * P);
+    const bool two = qlast >= (long)(s0 + 1) * P;
+    const int pe0 = two ? P - 1 : (int)(qlast - (long)s0 * P);
+    const int a00 = fdiv(pa0, g.m_sw);
+    const int seg0 = ((fdiv(pe0, g.m_sw) - a00) * g.S + g.KHe) * g.IWp;
+    const int pe1 = two ? (int)(qlast - (long)(s0 + 1) * P) : 0;
+    const int seg1 = two ? (fdiv(pe1, g.m_sw) * g.S + g.KHe) * g.IWp : 0;
+    const int slab_elems = seg0 + seg1;                   // <= slab_stride
+    const int in_plane = g.H * g.W;
+    const bool norm = !PLAIN && stats != nullptr;
+    const int seg_off = g.Cin * in_plane;                 // source offset of sample s0 + 1 relative to s0
+
+    // source offset of slab position it*256 + tid relative to channel 0 of sample s0
+    // (-1 = padding, -2 = past the slab); the same for every chunk
+    int soff[IT];
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+        const int rem = i * NT + tid;
+        soff[i] = -2;
+        if (rem < slab_elems) {
+            const int sg = rem >= seg0;
+            const int rr = sg ? rem - seg0 : rem;
+            const int r = fdiv(rr, g.m_iwp), col = rr - r * g.IWp;
+            int vy = (sg ? 0 : a00 * g.S) + r - g.pad, vx = col - g.pad;
+            bool ok = true;
+            if (g.reflect) {
+                vy = vy < 0 ? -vy : (vy >= g.H ? 2 * (g.H - 1) - vy : vy);
+                vx = vx < 0 ? -vx : (vx >= g.W ? 2 * (g.W - 1) - vx : vx);
+            } else {
+                ok = vy >= 0 && vy < g.H && vx >= 0 && vx < g.W;
+            }
+            soff[i] = ok ? sg * seg_off + vy * g.W + vx : -1;
+        }
+    }
+    int lane_pos[WM];
+#pragma unroll
+    for (int m = 0; m < WM; ++m) {
+        const long q = min(Q - 1, q0 + (wave * WM + m) * 32 + l32);
+        const int sg = q >= (long)(s0 + 1) * P;
+        const int pp = (int)(q - (long)(s0 + sg) * P);
+        const int a = fdiv(pp, g.m_sw), bb = pp - a * g.SW;
+        lane_pos[m] = (sg ? seg0 + a * g.S * g.IWp : (a - a00) * g.S * g.IWp) + bb * g.S;
+    }
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int m = 0; m < WM; ++m)
+#pragma unroll
+        for (int n = 0; n < WN; ++n)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[m][n][j] = 0.0f;
+
+    const int ntaps = TAPS > 0 ? TAPS : g.ntaps;
+    const int wcount = ntaps * WN * 64;                   // 16-byte pieces of one chunk's weights
+    const int nchunk = g.Cin / BF_CK, ntile_all = g.CoutP / 32;
+    const float* xs0 = x + (long)s0 * g.Cin * in_plane;
+    const int s1 = min(s0 + 1, g.B - 1);
+
+    for (int ck = 0; ck < nchunk; ++ck) {
+        const int c0 = ck * BF_CK;
+        __syncthreads();                                  // the previous chunk's operand reads are done
+        for (int base = 0; base < wcount; base += NT) {
+            const int i = base + tid;
+            if (i < wcount) {
+                const int t = i / (WN * 64), r = i - t * (WN * 64), j = r >> 6;
+                const long frag = ((long)g.tap_w[t] * nchunk + ck) * ntile_all + (n0 >> 5) + j;
+                __builtin_amdgcn_global_load_lds(MV_GLOBAL_PTR(wp + frag * 1024 + (r & 63) * 16),
+                                                 MV_LDS_PTR(wl + (base + wave * 64) * 16), 16, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int i0 = 0; i0 < IT; i0 += 2) {
+            float v[2][BF_CK];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if (i0 + u >= IT) continue;
+                const int so = soff[i0 + u];
+                const float* src = xs0 + (long)c0 * in_plane + (so >= 0 ? so : 0);
+#pragma unroll
+                for (int c = 0; c < BF_CK; ++c) v[u][c] = so >= 0 ? src[(long)c * in_plane] : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if (i0 + u >= IT) continue;
+                const int so = soff[i0 + u];
+                if (so == -2) continue;
+                if (!PLAIN && so >= 0) {
+                    if (norm) {
+                        const float* stp = stats + 2 * ((long)(so >= seg_off ? s1 : s0) * g.Cin + c0);
+#pragma unroll
+                        for (int c = 0; c < BF_CK; ++c) v[u][c] = (v[u][c] - stp[2 * c]) * stp[2 * c + 1];
+                    }
+                    if (g.relu_in) {
+#pragma unroll
+                        for (int c = 0; c < BF_CK; ++c) v[u][c] = fmaxf(v[u][c], 0.0f);
+                    }
+                }
+                bf16x8 lo, hi;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    lo[c] = (__bf16)v[u][c];
+                    hi[c] = (__bf16)v[u][8 + c];
+                }
+                const int pos = (i0 + u) * NT + tid;
+                *reinterpret_cast<bf16x8*>(slab + pos * 16) = lo;
+                *reinterpret_cast<bf16x8*>(slab + half + pos * 16) = hi;
+            }
+        }
+        __syncthreads();                                  // weights (the barrier drains the DMA) and slab are in place
+        const char* sl = slab + h * half;
+#pragma unroll
+        for (int t = 0; t < (TAPS > 0 ? TAPS : g.ntaps); ++t) {
+            bf16x8 A[WM], Bv[WN];
+#pragma unroll
+            for (int m = 0; m < WM; ++m) A[m] = *reinterpret_cast<const bf16x8*>(sl + (lane_pos[m] + g.tap_off[t]) * 16);
+#pragma unroll
+            for (int n = 0; n < WN; ++n) Bv[n] = *reinterpret_cast<const bf16x8*>(wl + (t * WN + n) * 1024 + lane * 16);
+#pragma unroll
+            for (int m = 0; m < WM; ++m)
+#pragma unroll
+                for (int n = 0; n < WN; ++n)
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[m], Bv[n], acc[m][n], 0, 0, 0);
+        }
+    }
+    // epilogue: as conv_mfma_kernel (the accumulator layout of the two MFMA shapes is the same)
+    const long oplane_sz = (long)g.OHf * g.OWf;
+    const bool linear = g.osx == 1 && g.osy == 1 && g.SW == g.OWf;
+#pragma unroll
+    for (int n = 0; n < WN; ++n) {
+        const int ch = n0 + n * 32 + l32;
+        if (ch < g.Cout) {
+            const float bv = bias ? bias[ch] : 0.0f;
+#pragma unroll
+            for (int m = 0; m < WM; ++m) {
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    const long q = q0 + (wave * WM + m) * 32 + 8 * gq + 4 * h;
+                    if (q >= Q) continue;
+                    const int sg = q >= (long)(s0 + 1) * P;
+                    const int pp = (int)(q - (long)(s0 + sg) * P);
+                    float* oplane = out + ((long)(s0 + sg) * g.Cout + ch) * oplane_sz;
+                    if (linear && pp + 3 < P) {
+                        f32x4_a4 o;
+                        o.x = acc[m][n][4 * gq] + bv;
+                        o.y = acc[m][n][4 * gq + 1] + bv;
+                        o.z = acc[m][n][4 * gq + 2] + bv;
+                        o.w = acc[m][n][4 * gq + 3] + bv;
+                        *reinterpret_cast<f32x4_a4*>(oplane + pp) = o;
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const long qk = q + k;
+                            if (qk < Q) {
+                                const int sk = qk >= (long)(s0 + 1) * P;
+                                const int pk = (int)(qk - (long)(s0 + sk) * P);
+                                const int a = fdiv(pk, g.m_sw), bb = pk - a * g.SW;
+                                float* op = out + ((long)(s0 + sk) * g.Cout + ch) * oplane_sz;
+                                op[(a * g.osy + g.oy0) * g.OWf + bb * g.osx + g.ox0] = acc[m][n][4 * gq + k] + bv;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// w [Cout,Cin,3,3] fp32 -> B fragments of the bf16 kernel: fwd[tap][Cin/16][CoutP/32][lane][8] with
+// lane = (k half, output channel in the tile), entry j = input channel 16*chunk + 8*half + j; bwd the
+// same with the roles of the channel counts exchanged and the taps flipped (the data gradient).
+__global__ void conv_pack_bf16_kernel(const float* __restrict__ w, int Cout, int Cin, int CoutP, int CinP,
+                                      __bf16* __restrict__ fwd, __bf16* __restrict__ bwd) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long nf = 9L * Cin * CoutP, nb = 9L * Cout * CinP;
+    if (idx < nf) {
+        const int j = (int)(idx & 7), ln = (int)((idx >> 3) & 63);
+        long r = idx >> 9;
+        const int nt = (int)(r % (CoutP / 32)); r /= (CoutP / 32);
+        const int ck = (int)(r % (Cin / 16)), tap = (int)(r / (Cin / 16));
+        const int n = nt * 32 + (ln & 31), c = ck * 16 + 8 * (ln >> 5) + j;
+        fwd[idx] = (__bf16)((n < Cout) ? w[((long)n * Cin + c) * 9 + tap] : 0.0f);
+    }
+    if (bwd && idx < nb) {
+        const int j = (int)(idx & 7), ln = (int)((idx >> 3) & 63);
+        long r = idx >> 9;
+        const int ct = (int)(r % (CinP / 32)); r /= (CinP / 32);
+        const int ck = (int)(r % (Cout / 16)), tap = (int)(r / (Cout / 16));
+        const int c = ct * 32 + (ln & 31), n = ck * 16 + 8 * (ln >> 5) + j;
+        bwd[idx] = (__bf16)((c < Cin) ? w[((long)n * Cin + c) * 9 + (8 - tap)] : 0.0f);
+    }
+}
+
 // Stem: one input channel, so the MFMA K dimension runs over the taps (49 -> 50, the last with
 // zero weight).  wp is [50][CoutP].
 template <int WAVES, int WM, int WN>
@@ -796,6 +1023,136 @@ __global__ __launch_bounds__(WG_NT, 2) void conv_wgrad_flat_kernel(int B, int Ci
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// weight gradient on the bf16 matrix cores
+// ---------------------------------------------------------------------------------------
+// D[n][c] per tap accumulates over output pixels, 16 per v_mfma_f32_32x32x16_bf16: a lane's 8 k values
+// are 8 consecutive pixels of one output row.  A = grad_out[n][pixels] is that run as it lies in memory.
+// B = input[c][pixel*S + tap] is the same run shifted by the tap; so that every B fragment is one aligned
+// 16-byte LDS read, the input rows a chunk needs are staged three times, once per tap column dx, already
+// subsampled by the stride: slab[dx][c][input row][ow] = pad(act(x))[c][row][ow*S + dx].  Rows are padded
+// to a multiple of 8 pixels with zeros in grad_out.  Both tiles are rounded to bf16 while staged
+// (through registers: padding, reflection and the producer's instance norm + ReLU are applied there).
+// Channel strides in LDS are an odd number of 16-byte units, which keeps the fragment reads conflict-free.
+// Workgroup tile: 64 output x 64 input channels x 9 taps; 4 waves as 2 (n) x 2 (c); chunk = nr output
+// rows of one sample; LDS is single buffered, a second resident workgroup covers the staging.
+// partial [G][9][Cout][Cin], summed by conv_wgrad_reduce_kernel.
+struct WgradBf16 {
+    int B, Cin, Cout, H, W, OH, OW, S, pad, reflect, relu_in;
+    int nr;        // output rows per chunk
+    int G8;        // 8-pixel groups per output row (OW padded)
+    int rows;      // input rows per chunk = (nr - 1) * S + 3
+    int gunits;    // 16-byte units per grad_out channel in LDS (odd)
+    int sunits;    // 16-byte units per input channel and dx copy in LDS (odd)
+    int spg;       // samples per z group
+};
+
+template <int S>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(WgradBf16 p, const float* __restrict__ x,
+                                                                  const float* __restrict__ stats,
+                                                                  const float* __restrict__ gout,
+                                                                  float* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) char smem_w[];
+    char* gl = smem_w;                                   // [64 n][gunits][16 B]
+    char* slab = smem_w + 64 * p.gunits * 16;            // [3 dx][64 c][sunits][16 B]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, l32 = lane & 31;
+    const int wn = wave >> 1, wc = wave & 1;
+    const int n0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+    const int b_begin = blockIdx.z * p.spg, b_end = min(p.B, b_begin + p.spg);
+    const int npc = (p.OH + p.nr - 1) / p.nr;
+    const int nchunks = (b_end - b_begin) * npc;
+    const long in_plane = (long)p.H * p.W, out_plane = (long)p.OH * p.OW;
+    const unsigned m_g8 = magic_of(p.G8), m_gch = magic_of(p.nr * p.G8), m_sch = magic_of(p.rows * p.G8);
+    constexpr int NV = 8 * S + 2;                        // source columns behind one group of 8 pixels, all dx
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[t][j] = 0.0f;
+
+    const int gitems = 64 * p.nr * p.G8, sitems = 64 * p.rows * p.G8;
+    for (int ci = 0; ci < nchunks; ++ci) {
+        const int b = b_begin + ci / npc, a0 = (ci % npc) * p.nr;
+        __syncthreads();                                 // the previous chunk's operand reads are done
+        for (int it = tid; it < gitems; it += 256) {     // grad_out: (n, row, group)
+            const int n = fdiv(it, m_gch), rg = it - n * p.nr * p.G8;
+            const int r = fdiv(rg, m_g8), g8 = rg - r * p.G8;
+            bf16x8 o;
+            const bool ok = n0 + n < p.Cout && a0 + r < p.OH;
+            const float* src = gout + ((long)b * p.Cout + n0 + n) * out_plane + (long)(a0 + r) * p.OW + 8 * g8;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (__bf16)((ok && 8 * g8 + j < p.OW) ? src[j] : 0.0f);
+            *reinterpret_cast<bf16x8*>(gl + (n * p.gunits + rg) * 16) = o;
+        }
+        for (int it = tid; it < sitems; it += 256) {     // input: (c, input row, group) -> three shifted copies
+            const int c = fdiv(it, m_sch), rg = it - c * p.rows * p.G8;
+            const int r = fdiv(rg, m_g8), g8 = rg - r * p.G8;
+            int vy = a0 * S + r - p.pad;
+            bool rok = c0 + c < p.Cin;
+            if (p.reflect) vy = vy < 0 ? -vy : (vy >= p.H ? 2 * (p.H - 1) - vy : vy);
+            else rok = rok && vy >= 0 && vy < p.H;
+            rok = rok && vy >= 0 && vy < p.H;             // rows past the plane (a short last chunk)
+            const long pl = (long)b * p.Cin + c0 + c;
+            const float* src = x + pl * in_plane + (long)vy * p.W;
+            float mean = 0.0f, rstd = 1.0f;
+            if (stats && rok) {
+                mean = stats[2 * pl];
+                rstd = stats[2 * pl + 1];
+            }
+            float v[NV];
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                int vx = 8 * g8 * S + j - p.pad;
+                bool ok = rok;
+                if (p.reflect) vx = vx < 0 ? -vx : (vx >= p.W ? 2 * (p.W - 1) - vx : vx);
+                ok = ok && vx >= 0 && vx < p.W;
+                float t = ok ? src[vx] : 0.0f;
+                if (ok && stats) t = (t - mean) * rstd;
+                if (p.relu_in) t = fmaxf(t, 0.0f);
+                v[j] = t;
+            }
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                bf16x8 o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = (__bf16)v[j * S + dx];
+                *reinterpret_cast<bf16x8*>(slab + (((dx * 64 + c) * p.sunits) + rg) * 16) = o;
+            }
+        }
+        __syncthreads();
+        const char* ga = gl + (wn * 32 + l32) * p.gunits * 16;
+        const char* sb = slab + (wc * 32 + l32) * p.sunits * 16;
+        const int dxs = 64 * p.sunits * 16;              // bytes between dx copies
+        const int nsteps = (p.nr * p.G8) >> 1;
+        int r = fdiv(h, m_g8), g8 = h - r * p.G8;         // this lane's group 2*ks + h
+        for (int ks = 0; ks < nsteps; ++ks) {
+            const bf16x8 A = *reinterpret_cast<const bf16x8*>(ga + (2 * ks + h) * 16);
+            const char* bb = sb + ((r * S) * p.G8 + g8) * 16;
+            bf16x8 Bv[9];
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+                Bv[t] = *reinterpret_cast<const bf16x8*>(bb + (t % 3) * dxs + (t / 3) * p.G8 * 16);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, Bv[t], acc[t], 0, 0, 0);
+            g8 += 2;
+            if (g8 >= p.G8) { g8 -= p.G8; ++r; }
+            if (g8 >= p.G8) { g8 -= p.G8; ++r; }
+        }
+    }
+    float* dst = partial + (long)blockIdx.z * 9 * p.Cout * p.Cin;
+    const int c = c0 + wc * 32 + l32;
+    if (c < p.Cin) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int n = n0 + wn * 32 + (j & 3) + 8 * (j >> 2) + 4 * h;
+                if (n < p.Cout) dst[((long)t * p.Cout + n) * p.Cin + c] = acc[t][j];
+            }
+    }
+}
+
 // dW[n][c][tap] = sum_z partial[z][tap][n][c]
 __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __restrict__ partial, int G, int KK,
                                                                 int Cout, int Cin, float* __restrict__ dw) {
@@ -1005,6 +1362,45 @@ static int launch_conv(ConvGeom g, const float* x, const float* stats, const flo
     return 0;
 }
 
+template <int IT, int TAPS, bool PLAIN>
+static void launch_conv_bf16_t(const ConvGeom& g, size_t lds, const float* x, const float* stats, const char* wp,
+                               const float* bias, float* out, hipStream_t st) {
+    constexpr int PT = 256, NTILE = 96;
+    static bool once = false;
+    if (!once) { set_attr_once(reinterpret_cast<const void*>(conv_bf16_kernel<IT, TAPS, PLAIN>)); once = true; }
+    const long Q = (long)g.B * g.SH * g.SW;
+    dim3 grid((unsigned)((Q + PT - 1) / PT), g.CoutP / NTILE, 1);
+    hipLaunchKernelGGL((conv_bf16_kernel<IT, TAPS, PLAIN>), grid, dim3(256), lds, st, g, x, stats, wp, bias, out);
+}
+
+static int launch_conv_bf16(ConvGeom g, const float* x, const float* stats, const char* wp, const float* bias,
+                            float* out, hipStream_t st) {
+    const int P = g.SH * g.SW;
+    constexpr int PT = 256;
+    MV_REQUIRE(P >= PT, E_SHAPE, "mdnvae_conv2d_bf16: plane of %d pixels is smaller than the %d-pixel tile", P, PT);
+    MV_REQUIRE(g.Cin % BF_CK == 0, E_SHAPE, "mdnvae_conv2d_bf16: Cin %d must be a multiple of 16", g.Cin);
+    const int one = ((PT + g.SW - 2) / g.SW) * g.S + g.KHe;
+    const int two = (PT / g.SW) * g.S + 2 * g.KHe;
+    const int rows = one > two ? one : two;
+    g.slab_stride = rows * g.IWp;
+    MV_REQUIRE(g.slab_stride <= 6 * 256, E_SHAPE, "mdnvae_conv2d_bf16: slab of %d positions is too large", g.slab_stride);
+    const size_t lds = (size_t)MAX_TAPS * 3 * 1024 + (size_t)2 * g.slab_stride * 16;
+    const bool plain = stats == nullptr && !g.relu_in;
+    if (g.slab_stride <= 2 * 256) {
+        if (g.ntaps == 9 && plain) launch_conv_bf16_t<2, 9, true>(g, lds, x, stats, wp, bias, out, st);
+        else if (g.ntaps == 9) launch_conv_bf16_t<2, 9, false>(g, lds, x, stats, wp, bias, out, st);
+        else if (plain) launch_conv_bf16_t<2, 0, true>(g, lds, x, stats, wp, bias, out, st);
+        else launch_conv_bf16_t<2, 0, false>(g, lds, x, stats, wp, bias, out, st);
+    } else {
+        if (g.ntaps == 9 && plain) launch_conv_bf16_t<6, 9, true>(g, lds, x, stats, wp, bias, out, st);
+        else if (g.ntaps == 9) launch_conv_bf16_t<6, 9, false>(g, lds, x, stats, wp, bias, out, st);
+        else if (plain) launch_conv_bf16_t<6, 0, true>(g, lds, x, stats, wp, bias, out, st);
+        else launch_conv_bf16_t<6, 0, false>(g, lds, x, stats, wp, bias, out, st);
+    }
+    MV_LAUNCH_CHECK("conv_bf16_kernel");
+    return 0;
+}
+
 static int wgrad_groups(int B, int ntiles) {
     int G = 512 / ntiles;
     if (G < 1) G = 1;
@@ -1045,10 +1441,18 @@ int mdnvae_conv_pack_weights(const float* w, int Cout, int Cin, int KS, float* p
     return 0;
 }
 
-// Forward convolution (transposed = 0) or data gradient (transposed = 1).
-int mdnvae_conv2d(const float* x, const float* in_stats, int relu_in, const float* packed_w, const float* bias,
-                  float* out, int B, int Cin, int H, int W, int Cout, int OH, int OW, int KS, int stride, int pad,
-                  int reflect, int transposed, void* stream) {
+}  // extern "C"
+
+// Forward convolution (transposed = 0) or data gradient (transposed = 1); bf16: packed_w holds bf16 fragments
+static int conv2d_run(const float* x, const float* in_stats, int relu_in, const void* packed_w_, const float* bias,
+                      float* out, int B, int Cin, int H, int W, int Cout, int OH, int OW, int KS, int stride, int pad,
+                      int reflect, int transposed, void* stream, bool bf16) {
+    const float* packed_w = static_cast<const float*>(packed_w_);
+    auto launch = [&](const ConvGeom& gg, const float* bb) {
+        return bf16 ? launch_conv_bf16(gg, x, in_stats, static_cast<const char*>(packed_w_), bb, out, (hipStream_t)stream)
+                    : launch_conv(gg, x, in_stats, packed_w, bb, out, (hipStream_t)stream);
+    };
+    MV_REQUIRE(!(bf16 && Cin == 1), E_SHAPE, "mdnvae_conv2d_bf16: the single-channel stem runs in fp32 (mdnvae_conv2d)");
     MV_REQUIRE(B >= 0, E_ARG, "mdnvae_conv2d: negative batch");
     if (B == 0) return 0;
     MV_REQUIRE(x && packed_w && out, E_ARG, "mdnvae_conv2d: null pointer");
@@ -1091,7 +1495,7 @@ int mdnvae_conv2d(const float* x, const float* in_stats, int relu_in, const floa
             g.tap_off[t] = (t / 3) * g.IWp + (t % 3);
             g.tap_w[t] = t;
         }
-        return launch_conv(g, x, in_stats, packed_w, bias, out, st);
+        return launch(g, bias);
     }
     // ---- data gradient: x = gradient w.r.t. the conv output [B,Cin,H,W], out = gradient w.r.t. its input
     MV_REQUIRE(pad >= 0 && pad <= KS - 1, E_SHAPE, "mdnvae_conv2d: transposed padding %d", pad);
@@ -1109,7 +1513,7 @@ int mdnvae_conv2d(const float* x, const float* in_stats, int relu_in, const floa
             g.tap_off[t] = (t / 3) * g.IWp + (t % 3);
             g.tap_w[t] = t;                       // the packed copy is already flipped
         }
-        return launch_conv(g, x, in_stats, packed_w, nullptr, out, st);
+        return launch(g, nullptr);
     }
     // stride 2, 3x3, pad 1: input pixel (2a+py, 2b+px) receives kernel rows ky with (py+1-ky) even
     MV_REQUIRE(KS == 3 && pad == 1, E_SHAPE, "mdnvae_conv2d: stride-2 data gradient supports k3 p1");
@@ -1131,9 +1535,45 @@ int mdnvae_conv2d(const float* x, const float* in_stats, int relu_in, const floa
                     q.tap_w[q.ntaps] = (2 - ky) * 3 + (2 - kx);      // index in the flipped packed copy
                     ++q.ntaps;
                 }
-            if (int rc = launch_conv(q, x, in_stats, packed_w, nullptr, out, st)) return rc;
+            if (int rc = launch(q, nullptr)) return rc;
         }
     return 0;
+}
+
+extern "C" {
+
+int mdnvae_conv2d(const float* x, const float* in_stats, int relu_in, const float* packed_w, const float* bias,
+                  float* out, int B, int Cin, int H, int W, int Cout, int OH, int OW, int KS, int stride, int pad,
+                  int reflect, int transposed, void* stream) {
+    return conv2d_run(x, in_stats, relu_in, packed_w, bias, out, B, Cin, H, W, Cout, OH, OW, KS, stride, pad, reflect,
+                      transposed, stream, false);
+}
+
+size_t mdnvae_conv_packed_bytes_bf16(int Cout, int Cin, int KS, int transposed) {
+    if (KS != 3 || Cin % 16 || Cout % 16) return 0;
+    return (size_t)9 * 2 * (transposed ? (size_t)Cout * round_up(Cin, 96) : (size_t)Cin * round_up(Cout, 96));
+}
+
+int mdnvae_conv_pack_weights_bf16(const float* w, int Cout, int Cin, int KS, void* packed_fwd, void* packed_bwd,
+                                  void* stream) {
+    MV_REQUIRE(w && packed_fwd, E_ARG, "mdnvae_conv_pack_weights_bf16: null pointer");
+    MV_REQUIRE(KS == 3 && Cin >= 16 && Cin % 16 == 0 && Cout % 16 == 0, E_SHAPE,
+               "mdnvae_conv_pack_weights_bf16: 3x3 kernels with channel counts that are multiples of 16 (got k%d, %d -> %d)",
+               KS, Cin, Cout);
+    const int CoutP = round_up(Cout, 96), CinP = round_up(Cin, 96);
+    const long nf = 9L * Cin * CoutP, nb = packed_bwd ? 9L * Cout * CinP : 0;
+    const long n = nf > nb ? nf : nb;
+    hipLaunchKernelGGL(conv_pack_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, Cout,
+                       Cin, CoutP, CinP, static_cast<__bf16*>(packed_fwd), static_cast<__bf16*>(packed_bwd));
+    MV_LAUNCH_CHECK("conv_pack_bf16_kernel");
+    return 0;
+}
+
+int mdnvae_conv2d_bf16(const float* x, const float* in_stats, int relu_in, const void* packed_w, const float* bias,
+                       float* out, int B, int Cin, int H, int W, int Cout, int OH, int OW, int KS, int stride, int pad,
+                       int reflect, int transposed, void* stream) {
+    return conv2d_run(x, in_stats, relu_in, packed_w, bias, out, B, Cin, H, W, Cout, OH, OW, KS, stride, pad, reflect,
+                      transposed, stream, true);
 }
 
 size_t mdnvae_conv_wgrad_workspace_floats(int B, int Cout, int Cin, int KS) {
@@ -1247,6 +1687,60 @@ int mdnvae_conv2d_wgrad(const float* x, const float* in_stats, int relu_in, cons
     MV_LAUNCH_CHECK("conv_wgrad_kernel");
     hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, workspace, Gz,
                        KK, Cout, Cin, grad_w);
+    MV_LAUNCH_CHECK("conv_wgrad_reduce_kernel");
+    return 0;
+}
+
+int mdnvae_conv2d_wgrad_bf16(const float* x, const float* in_stats, int relu_in, const float* grad_out, float* workspace,
+                             float* grad_w, int B, int Cin, int H, int W, int Cout, int OH, int OW, int KS, int stride,
+                             int pad, int reflect, void* stream) {
+    MV_REQUIRE(B >= 1, E_ARG, "mdnvae_conv2d_wgrad_bf16: empty batch");
+    MV_REQUIRE(x && grad_out && workspace && grad_w, E_ARG, "mdnvae_conv2d_wgrad_bf16: null pointer");
+    MV_REQUIRE(KS == 3 && Cin > 1 && pad == 1 && (stride == 1 || stride == 2), E_SHAPE,
+               "mdnvae_conv2d_wgrad_bf16: 3x3, pad 1, stride 1 or 2, more than one input channel (got k%d p%d s%d Cin %d)", KS,
+               pad, stride, Cin);
+    MV_REQUIRE(OH == (H + 2 * pad - KS) / stride + 1 && OW == (W + 2 * pad - KS) / stride + 1, E_SHAPE,
+               "mdnvae_conv2d_wgrad_bf16: output size mismatch");
+    MV_REQUIRE(!reflect || (H >= 2 && W >= 2), E_SHAPE, "mdnvae_conv2d_wgrad_bf16: reflection needs a plane of 2x2 or more");
+    WgradBf16 p{};
+    p.B = B; p.Cin = Cin; p.Cout = Cout; p.H = H; p.W = W; p.OH = OH; p.OW = OW; p.S = stride; p.pad = pad;
+    p.reflect = reflect; p.relu_in = relu_in;
+    p.G8 = (OW + 7) / 8;
+    // the largest chunk of output rows (an even number of 8-pixel groups) whose tiles leave room for two workgroups
+    int best = 0;
+    for (size_t cap : {(size_t)78 * 1024, (size_t)156 * 1024}) {      // room for two workgroups per CU, else for one
+        for (int nr = 1; nr <= OH + 1 && nr <= 16; ++nr) {
+            if ((nr * p.G8) & 1) continue;
+            const int rows = (nr - 1) * stride + 3;
+            const size_t lds = ((size_t)64 * ((nr * p.G8) | 1) + (size_t)3 * 64 * ((rows * p.G8) | 1)) * 16;
+            if (lds <= cap) best = nr;
+        }
+        if (best) break;
+    }
+    MV_REQUIRE(best > 0, E_SHAPE, "mdnvae_conv2d_wgrad_bf16: no chunk of output rows fits in LDS (OW = %d)", OW);
+    p.nr = best;
+    p.rows = (best - 1) * stride + 3;
+    p.gunits = (best * p.G8) | 1;
+    p.sunits = (p.rows * p.G8) | 1;
+    const size_t lds = ((size_t)64 * p.gunits + (size_t)3 * 64 * p.sunits) * 16;
+    const int ntiles = ((Cout + 63) / 64) * ((Cin + 63) / 64);
+    const int Gz0 = wgrad_groups(B, ntiles);
+    p.spg = (B + Gz0 - 1) / Gz0;
+    const int Gz = (B + p.spg - 1) / p.spg;
+    hipStream_t st = (hipStream_t)stream;
+    static bool once = false;
+    if (!once) {
+        set_attr_once(reinterpret_cast<const void*>(conv_wgrad_bf16_kernel<1>));
+        set_attr_once(reinterpret_cast<const void*>(conv_wgrad_bf16_kernel<2>));
+        once = true;
+    }
+    dim3 grid((Cout + 63) / 64, (Cin + 63) / 64, Gz);
+    if (stride == 1) hipLaunchKernelGGL(conv_wgrad_bf16_kernel<1>, grid, dim3(256), lds, st, p, x, in_stats, grad_out, workspace);
+    else hipLaunchKernelGGL(conv_wgrad_bf16_kernel<2>, grid, dim3(256), lds, st, p, x, in_stats, grad_out, workspace);
+    MV_LAUNCH_CHECK("conv_wgrad_bf16_kernel");
+    const long total = 9L * Cout * Cin;
+    hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, workspace, Gz, 9,
+                       Cout, Cin, grad_w);
     MV_LAUNCH_CHECK("conv_wgrad_reduce_kernel");
     return 0;
 }

@@ -783,8 +783,17 @@ class _ConvLayer:
         self.h = h
         self.oh = _conv_out(h, ks, stride, pad)
 
-    def pack(self, w, dev, need_bwd):
+    def pack(self, w, dev, need_bwd, bf16=False):
         lib = _lib.load()
+        if bf16 and self.cin > 1:
+            wf = torch.empty(lib.mdnvae_conv_packed_bytes_bf16(self.cout, self.cin, self.ks, 0), dtype=torch.uint8, device=dev)
+            wb = None
+            if need_bwd:
+                wb = torch.empty(lib.mdnvae_conv_packed_bytes_bf16(self.cout, self.cin, self.ks, 1), dtype=torch.uint8,
+                                 device=dev)
+            call("mdnvae_conv_pack_weights_bf16", ptr(_c(w), "conv weight"), self.cout, self.cin, self.ks, wf.data_ptr(),
+                 None if wb is None else wb.data_ptr(), stream())
+            return wf, wb
         wf = torch.empty(lib.mdnvae_conv_packed_floats(self.cout, self.cin, self.ks, 0), dtype=torch.float32, device=dev)
         wb = None
         if need_bwd and self.cin > 1:
@@ -793,8 +802,11 @@ class _ConvLayer:
         return wf, wb
 
     def fwd(self, x, stats, relu_in, wf, bias, B):
+        """wf from pack(); a uint8 buffer (bf16 fragments) selects the bf16 kernel."""
         out = torch.empty(B, self.cout, self.oh, self.oh, dtype=torch.float32, device=x.device)
-        call("mdnvae_conv2d", ptr(x), ptr(stats), int(relu_in), ptr(wf), ptr(bias, "conv bias"), ptr(out), B, self.cin,
+        bf16 = wf.dtype == torch.uint8
+        call("mdnvae_conv2d_bf16" if bf16 else "mdnvae_conv2d", ptr(x), ptr(stats), int(relu_in),
+             wf.data_ptr() if bf16 else ptr(wf), ptr(bias, "conv bias"), ptr(out), B, self.cin,
              self.h, self.h, self.cout, self.oh, self.oh, self.ks, self.stride, self.pad, int(self.reflect), 0, stream())
         return out
 
@@ -805,16 +817,18 @@ class _ConvLayer:
         else:
             oh, pad = self.h, self.pad
         gin = torch.empty(B, self.cin, oh, oh, dtype=torch.float32, device=gout.device)
-        call("mdnvae_conv2d", ptr(gout), None, 0, ptr(wb), None, ptr(gin), B, self.cout, self.oh, self.oh, self.cin, oh,
-             oh, self.ks, self.stride, pad, 0, 1, stream())
+        bf16 = wb.dtype == torch.uint8
+        call("mdnvae_conv2d_bf16" if bf16 else "mdnvae_conv2d", ptr(gout), None, 0, wb.data_ptr() if bf16 else ptr(wb), None,
+             ptr(gin), B, self.cout, self.oh, self.oh, self.cin, oh, oh, self.ks, self.stride, pad, 0, 1, stream())
         return gin
 
-    def wgrad(self, x, stats, relu_in, gout, B):
+    def wgrad(self, x, stats, relu_in, gout, B, bf16=False):
         lib = _lib.load()
         ws = torch.empty(lib.mdnvae_conv_wgrad_workspace_floats(B, self.cout, self.cin, self.ks), dtype=torch.float32,
                          device=x.device)
         gw = torch.empty(self.cout, self.cin, self.ks, self.ks, dtype=torch.float32, device=x.device)
-        call("mdnvae_conv2d_wgrad", ptr(x), ptr(stats), int(relu_in), ptr(gout), ptr(ws), ptr(gw), B, self.cin, self.h,
+        call("mdnvae_conv2d_wgrad_bf16" if bf16 and self.cin > 1 else "mdnvae_conv2d_wgrad", ptr(x), ptr(stats),
+             int(relu_in), ptr(gout), ptr(ws), ptr(gw), B, self.cin, self.h,
              self.h, self.cout, self.oh, self.oh, self.ks, self.stride, self.pad, int(self.reflect), stream())
         return gw
 

@@ -69,6 +69,54 @@ def test_conv_forward_dgrad_wgrad(cin, cout, ks, stride, pad, reflect, h, B):
         assert _rel(gin, act.grad) <= 1e-5
 
 
+def _bf16(t):
+    return t.to(torch.bfloat16).double()
+
+
+@pytest.mark.parametrize("cin,cout,ks,stride,pad,reflect,h", [g for g in GEOMS if g[0] > 1])
+@pytest.mark.parametrize("B", [1, 3])
+def test_bf16_conv_forward_dgrad(cin, cout, ks, stride, pad, reflect, h, B):
+    """The bf16 kernels round both operands to bf16 and accumulate in fp32.  Against a float64 convolution
+    of the SAME rounded operands (the activation normalised in fp32 with the kernel's own statistics, as
+    the kernel does before rounding) only the fp32 accumulation differs: bar 1e-5 of the output's
+    largest entry, as for the fp32 kernels.  The distance to the unrounded convolution is recorded."""
+    g = torch.Generator().manual_seed(cin * 7 + h + B)
+    x = torch.randn(B, cin, h, h, generator=g)
+    w = torch.randn(cout, cin, ks, ks, generator=g) / (cin * ks * ks) ** 0.5
+    b = torch.randn(cout, generator=g)
+    ly = ops._ConvLayer(cin, cout, ks, stride, pad, reflect, h)
+    xg = x.to(DEV)
+    st = ops._plane_stats(xg)
+    stc = st.cpu().reshape(B, cin, 2)
+    act32 = F.relu((x - stc[:, :, 0, None, None]) * stc[:, :, 1, None, None])
+    want = _ref_conv(_bf16(act32), _bf16(w), b.double(), ks, stride, pad, reflect)
+    exact = _ref_conv(act32.double(), w.double(), b.double(), ks, stride, pad, reflect)
+    wf, wb = ly.pack(w.to(DEV), DEV, True, bf16=True)
+    out = ly.fwd(xg, st, True, wf, b.to(DEV), B)
+    recipe.record("conv bf16", "forward vs float64 on the rounded operands", f"{cin}->{cout} s{stride} h{h} B{B}",
+                  _rel(out, want), 1e-5, note=f"{_rel(out, exact):.1e} from the unrounded convolution")
+    assert _rel(out, want) <= 1e-5
+    assert _rel(out, exact) <= 2e-2
+    cot = torch.randn(want.shape, generator=g)
+    cd = _bf16(cot).requires_grad_(False)
+    xin = torch.zeros(B, cin, h, h, dtype=torch.float64, requires_grad=True)
+    (_ref_conv(xin, _bf16(w), None, ks, stride, pad, reflect) * cd).sum().backward()
+    gin = ly.dgrad(cot.to(DEV), wb, B)
+    if reflect:
+        folded = torch.empty(B, cin, h, h, device=DEV)
+        ops.call("mdnvae_fold_add", None, ops.ptr(gin), B * cin, h, h, ops.ptr(folded), ops.stream())
+        gin = folded
+    recipe.record("conv bf16", "data gradient vs float64 on the rounded operands", f"{cin}->{cout} s{stride} h{h} B{B}",
+                  _rel(gin, xin.grad), 1e-5)
+    assert _rel(gin, xin.grad) <= 1e-5
+    wd = torch.zeros(cout, cin, ks, ks, dtype=torch.float64, requires_grad=True)
+    (_ref_conv(_bf16(act32), wd, None, ks, stride, pad, reflect) * cd).sum().backward()
+    gw = ly.wgrad(xg, st, True, cot.to(DEV), B, bf16=True)
+    recipe.record("conv bf16", "weight gradient vs float64 on the rounded operands", f"{cin}->{cout} s{stride} h{h} B{B}",
+                  _rel(gw, wd.grad), 1e-5)
+    assert _rel(gw, wd.grad) <= 1e-5
+
+
 @pytest.mark.parametrize("C,H,relu,folded", [(5, 17, True, True), (3, 22, False, False), (2, 44, True, False),
                                              (2, 87, True, False), (4, 22, True, True), (3, 3, True, True)])
 def test_instance_norm_kernels(C, H, relu, folded):
