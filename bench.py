@@ -48,7 +48,7 @@ MODELS = {
 }
 
 
-def build(model_name, n_nodes, device, symmetric=True):
+def build(model_name, n_nodes, device, symmetric=True, precision="fp32"):
     """`symmetric`: the synthetic connectomes are symmetric like the prepared data of the scripts,
     so the FNN-encoder models run their first layers on the packed triangle (same sums, half the
     GEMM work; the symmetry is verified on the device every step and checked after the run)."""
@@ -60,7 +60,7 @@ def build(model_name, n_nodes, device, symmetric=True):
         model = M.MDNGateVAE(R=5, n_nodes=n_nodes, k=32, n_layers=3, latent_dim=68, n_traits=4,
                              symmetric_input=symmetric)
     else:
-        model = M.ConvVAE(n_nodes=n_nodes, latent_dim=68, **kw)
+        model = M.ConvVAE(n_nodes=n_nodes, latent_dim=68, precision=precision, **kw)
     return model.to(device), mode, kind
 
 
@@ -220,7 +220,10 @@ ABI_TAGS.update({
 })
 HBM_TAGS |= {"split_rows_kernel", "split_cols_kernel", "act_bwd_kernel", "tri_pack_kernel<fold>"}
 # bf16 matrix-core work: (a, b, M, N, K, m_valid, ...) executes six bf16 MFMA products per fp32 multiply-add
-BF16_TAGS = {"split_gemm_kernel"}
+BF16_TAGS = {"split_gemm_kernel", "conv_bf16_kernel", "conv_wgrad_bf16_kernel"}
+# kernels that reach fp32 accuracy with several bf16 products per multiply: rated in fp32-equivalent
+# flops against the bf16 peak divided by their number of products
+SPLIT_PRODUCTS = {"conv_bf16x2_kernel": 3, "conv_bf16x3_kernel": 6, "conv_wgrad_bf16x2_kernel": 3, "conv_wgrad_bf16x3_kernel": 6}
 ABI_TAGS["mdnvae_split_gemm"] = ("split_gemm_kernel", lambda a: 12.0 * a[5] * a[3] * a[4])
 # matrix-core entry points with a fixed tag (work in flops; kept out of HBM_TAGS)
 ABI_TAGS.update({
@@ -241,16 +244,20 @@ def install_clock(clock):
     def flops(ly, B):
         return 2.0 * ly.ks * ly.ks * ly.cin * ly.cout * ly.oh * ly.oh * B
 
-    def fwd(self, x, stats, relu_in, wf, bias, B):
-        tag = "conv_stem_kernel" if self.cin == 1 else "conv_mfma_kernel"
-        return clock.bracket(tag, flops(self, B), lambda: orig_fwd(self, x, stats, relu_in, wf, bias, B))
+    split_tag = {1: "conv_bf16_kernel", 2: "conv_bf16x2_kernel", 3: "conv_bf16x3_kernel"}
+    wgrad_tag = {1: "conv_wgrad_bf16_kernel", 2: "conv_wgrad_bf16x2_kernel", 3: "conv_wgrad_bf16x3_kernel"}
 
-    def dgrad(self, gout, wb, B):
-        return clock.bracket("conv_mfma_kernel", flops(self, B), lambda: orig_dgrad(self, gout, wb, B))
+    def fwd(self, x, stats, relu_in, wf, bias, B, parts=0):
+        tag = "conv_stem_kernel" if self.cin == 1 else split_tag.get(parts, "conv_mfma_kernel")
+        return clock.bracket(tag, flops(self, B), lambda: orig_fwd(self, x, stats, relu_in, wf, bias, B, parts))
 
-    def wgrad(self, x, stats, relu_in, gout, B):
-        tag = "conv_stem_wgrad_kernel" if self.cin == 1 else "conv_wgrad_kernel"
-        return clock.bracket(tag, flops(self, B), lambda: orig_wgrad(self, x, stats, relu_in, gout, B))
+    def dgrad(self, gout, wb, B, parts=0):
+        return clock.bracket(split_tag.get(parts, "conv_mfma_kernel"), flops(self, B),
+                             lambda: orig_dgrad(self, gout, wb, B, parts))
+
+    def wgrad(self, x, stats, relu_in, gout, B, parts=0):
+        tag = "conv_stem_wgrad_kernel" if self.cin == 1 else wgrad_tag.get(parts, "conv_wgrad_kernel")
+        return clock.bracket(tag, flops(self, B), lambda: orig_wgrad(self, x, stats, relu_in, gout, B, parts))
 
     L.fwd, L.dgrad, L.wgrad = fwd, dgrad, wgrad
 
@@ -307,6 +314,8 @@ def kernel_table(clock, elapsed):
         hbm = tag in HBM_TAGS
         rate = r["work"] / r["seconds"] / (1e9 if hbm else 1e12)
         peak = PEAK_HBM_GBPS if hbm else (PEAK_BF16_MATRIX_TFLOPS if tag in BF16_TAGS else PEAK_FP32_MATRIX_TFLOPS)
+        if tag in SPLIT_PRODUCTS:
+            peak = PEAK_BF16_MATRIX_TFLOPS / SPLIT_PRODUCTS[tag]
         kernels[tag] = dict(bound="hbm" if hbm else "mfma", achieved=rate, peak=peak, unit="GB/s" if hbm else "TFLOP/s",
                             frac=rate / peak, launches=r["launches"], avg_ms=per_launch * 1e3,
                             share_of_step=r["seconds"] / elapsed,
@@ -347,11 +356,11 @@ def mixture_stream_rates(batch, nodes, device, reps=5):
 
 
 def run_workload(model_name, batch, nodes, steps, warmup, pool_batches, device, rank, world, use_clock,
-                 overlap=True, symmetric=True, graph=False):
+                 overlap=True, symmetric=True, graph=False, precision="fp32"):
     """Warm up, then time exactly `steps` steps between barrier + synchronize pairs; returns
     (elapsed seconds: max over ranks, final loss, kernel clock, wall time of the instrumented pass
     or None, workload description)."""
-    model, mode, kind = build(model_name, nodes, device, symmetric)
+    model, mode, kind = build(model_name, nodes, device, symmetric, precision)
     gen = M.data.synthetic_sc if kind == "sc" else M.data.synthetic_fc
     # each rank owns its shard of the synthetic subjects (seed differs per rank)
     pool = gen(batch * pool_batches, nodes, seed=1234 + rank, device=device)
@@ -440,6 +449,8 @@ def main():
     ap.add_argument("--no-overlap", action="store_true", help="all-reduce every gradient after backward")
     ap.add_argument("--full-first-layer", action="store_true",
                     help="FNN-encoder models: run the first layers on all N*N entries instead of the packed triangle")
+    ap.add_argument("--precision", default="fp32", choices=sorted(M.modules.CONV_PRECISIONS),
+                    help="conv-encoder models: how the 3x3 convolutions multiply (see ConvVAE)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend (nccl = RCCL over xGMI).  gloo is a rehearsal path (ranks may share "
                          "a GPU): the trainer stages device buffers through pinned host memory for it, because gloo's "
@@ -476,7 +487,7 @@ def main():
                                                              args.pool, device, rank, world,
                                                              not args.no_kernel_clock and not args.graph,
                                                              not args.no_overlap, not args.full_first_layer,
-                                                             graph=args.graph and world == 1)
+                                                             graph=args.graph and world == 1, precision=args.precision)
     if rank == 0:
         line = {
             "metric": "train samples/sec (fwd+bwd, 87x87 connectome)" if args.nodes == 87 else
@@ -517,7 +528,7 @@ def main():
         # the reference-parity shape (68 x 68 crop) next to the 87 x 87 headline shape
         steps68 = max(2, min(args.steps, 4))
         el68, loss68, _, _, what68 = run_workload(args.model, batch, 68, steps68, 2, args.pool, device, rank, world, False,
-                                                  not args.no_overlap, not args.full_first_layer)
+                                                  not args.no_overlap, not args.full_first_layer, precision=args.precision)
         line["n68"] = {"workload": what68, "value": batch * steps68 / el68, "unit": "samples/s", "per_gpu_batch": batch,
                        "steps": steps68, "warmup": 2, "ms_per_step": el68 / steps68 * 1e3,
                        "final_loss_per_sample": loss68 / batch}
@@ -556,6 +567,17 @@ def main():
         if not args.no_cpu_baseline:
             also["cpu_baseline"] = cpu_baseline(args.also, args.nodes, seconds_budget=12.0)
         line["also"] = also
+        # the conv-encoder VAE of function_FC/VAE_CNN_GCN.py with its 3x3 convolutions on the bf16 matrix cores
+        el3, loss3, clock3, clocked3, what3 = run_workload("cnn_gcn_fc", ab, args.nodes, steps, 2, args.pool, device, rank,
+                                                           world, not args.no_kernel_clock, precision="bf16")
+        k3 = kernel_table(clock3, clocked3) if clocked3 else {}
+        bf = {"workload": what3, "value": ab * steps / el3, "unit": "samples/s", "per_gpu_batch": ab, "steps": steps,
+              "warmup": 2, "ms_per_step": el3 / steps * 1e3, "dtype": "bf16 operands, f32 accumulation (3x3 convolutions); f32 elsewhere",
+              "final_loss_per_sample": loss3 / ab, "kernels": k3}
+        if k3:
+            dom3 = max(k3, key=lambda k: k3[k]["share_of_step"])
+            bf["roofline"] = dict(k3[dom3], kernel=dom3)
+        line["also_bf16"] = bf
     if rank == 0:
         print(json.dumps(line))
     if world > 1 or REHEARSE_EXCHANGE:

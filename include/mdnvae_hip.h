@@ -281,24 +281,27 @@ int mdnvae_conv_pack_weights(const float* w, int Cout, int Cin, int KS, float* p
 int mdnvae_conv2d(const float* x, const float* in_stats, int relu_in, const float* packed_w, const float* bias,
                   float* out, int B, int Cin, int H, int W, int Cout, int OH, int OW, int KS, int stride, int pad,
                   int reflect, int transposed, void* stream);
-/* The same convolution / data gradient with both operands rounded to bf16 and fp32 accumulation
- * (v_mfma_f32_32x32x16_bf16), for the encoder of function_FC/VAE_CNN_GCN.py:97-137 when it is run in
- * its reduced-precision mode; results differ from mdnvae_conv2d by bf16 rounding of the inputs (2^-9
- * relative per operand).  3x3 kernels, Cin and Cout multiples of 16; the 7x7 stem stays in fp32.
- * packed_w comes from mdnvae_conv_pack_weights_bf16 (whole MFMA operand fragments,
- * [tap][16-channel chunk][32-channel tile][lane][8 bf16]); mdnvae_conv_packed_bytes_bf16 is its size
- * in bytes (0 for an unsupported shape). */
-size_t mdnvae_conv_packed_bytes_bf16(int Cout, int Cin, int KS, int transposed);
-int mdnvae_conv_pack_weights_bf16(const float* w, int Cout, int Cin, int KS, void* packed_fwd, void* packed_bwd,
-                                  void* stream);
+/* The same convolution / data gradient on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16, fp32
+ * accumulation).  parts = 1: both operands rounded to bf16 - the reduced-precision mode of the encoder of
+ * function_FC/VAE_CNN_GCN.py:97-137; results differ from mdnvae_conv2d by the rounding of the inputs (2^-9
+ * relative per operand).  parts = 3: each operand is split into three bf16 numbers whose sum is the fp32
+ * value and the six part products of relative size >= 2^-16 are accumulated: fp32 accuracy (the same
+ * 1e-5 bar as mdnvae_conv2d) at 6/16 of the cost of the fp32 matrix instruction.  parts = 2: three part
+ * products, 2^-16 relative per product.  3x3 kernels, Cin and Cout multiples of 16; the 7x7 stem stays
+ * with mdnvae_conv2d.  packed_w comes from mdnvae_conv_pack_weights_bf16 with the same parts (whole MFMA
+ * operand fragments, [part][tap][16-channel chunk][32-channel tile][lane][8 bf16]);
+ * mdnvae_conv_packed_bytes_bf16 is its size in bytes (0 for an unsupported shape). */
+size_t mdnvae_conv_packed_bytes_bf16(int Cout, int Cin, int KS, int transposed, int parts);
+int mdnvae_conv_pack_weights_bf16(const float* w, int Cout, int Cin, int KS, int parts, void* packed_fwd,
+                                  void* packed_bwd, void* stream);
 int mdnvae_conv2d_bf16(const float* x, const float* in_stats, int relu_in, const void* packed_w, const float* bias,
                        float* out, int B, int Cin, int H, int W, int Cout, int OH, int OW, int KS, int stride, int pad,
-                       int reflect, int transposed, void* stream);
-/* Weight gradient with both operands rounded to bf16 (fp32 accumulation): same arguments, conventions and
- * workspace as mdnvae_conv2d_wgrad; 3x3, pad 1, stride 1 or 2, Cin > 1. */
+                       int reflect, int transposed, int parts, void* stream);
+/* Weight gradient on the bf16 matrix cores with the operands in `parts` bf16 parts (as mdnvae_conv2d_bf16):
+ * same arguments, conventions and workspace as mdnvae_conv2d_wgrad; 3x3, pad 1, stride 1 or 2, Cin > 1. */
 int mdnvae_conv2d_wgrad_bf16(const float* x, const float* in_stats, int relu_in, const float* grad_out,
                              float* workspace, float* grad_w, int B, int Cin, int H, int W, int Cout, int OH, int OW,
-                             int KS, int stride, int pad, int reflect, void* stream);
+                             int KS, int stride, int pad, int reflect, int parts, void* stream);
 size_t mdnvae_conv_wgrad_workspace_floats(int B, int Cout, int Cin, int KS);
 /* grad_w [Cout,Cin,KS,KS] = sum_{b,pixels} grad_out x pad(act(x)); same x / in_stats / relu_in
  * / padding conventions as the forward call.  3x3 multi-channel or the 7x7 single-channel stem. */

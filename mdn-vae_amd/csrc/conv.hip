@@ -19,6 +19,7 @@
 // second kernel adds in a fixed order.
 #include "common.h"
 #include "../../include/mdnvae_hip.h"
+#include <algorithm>
 #include <cstdlib>
 
 namespace mdnvae {
@@ -350,32 +351,54 @@ __global__ __launch_bounds__(256, (SI > 8 ? 2 : 3)) void conv_mfma_kernel(ConvGe
 }
 
 // ---------------------------------------------------------------------------------------
-// forward / data-gradient kernel on the bf16 matrix cores (operands rounded to bf16, fp32 accumulation)
+// forward / data-gradient kernel on the bf16 matrix cores
 // ---------------------------------------------------------------------------------------
-// Same tiling as conv_mfma_kernel (256 flattened (sample, pixel) rows x 96 output channels per
-// workgroup), with the K dimension of one v_mfma_f32_32x32x16_bf16 running over 16 input channels.
-// Per chunk of 16 channels a thread stages whole slab positions: it loads the 16 channel values of a
-// position (consecutive lanes = consecutive positions, so every load is coalesced along the plane),
-// applies the producer's instance norm + ReLU if asked, rounds to bf16 and writes two 16-byte pieces,
-// slab[k half][position][8 channels] - which is exactly the A operand fragment of a lane, read back
-// with one ds_read_b128 per (32-row tile, tap).  Weights arrive pre-packed as whole B fragments
-// ([tap][chunk][32-channel tile][lane][8 bf16], 1 KiB each) by 16-byte LDS-DMA.  LDS is single
-// buffered: a second and third resident workgroup cover the staging of the first.
+// PARTS = 1: both operands rounded to bf16, fp32 accumulation (one v_mfma_f32_32x32x16_bf16 per tile pair).
+// PARTS = 3: every fp32 operand is the exact sum of three bf16 numbers, x = x1 + x2 + x3; the product keeps
+// the six part products of relative size >= 2^-16 (x1 w1, x1 w2, x2 w1, x1 w3, x2 w2, x3 w1), accumulated
+// smallest first - what is left out is below one fp32 rounding, so the result has fp32 accuracy at 6/16 of
+// the cost of the fp32 matrix instruction.  PARTS = 2 keeps x1 w1 + x1 w2 + x2 w1 (2^-16 relative per
+// product).
+//
+// Same row tiling as conv_mfma_kernel (flattened (sample, pixel) rows), with the K dimension of one MFMA
+// running over 16 input channels.  Per chunk of 16 channels a thread stages whole slab positions: it
+// loads the 16 channel values of a position (consecutive lanes = consecutive positions, so every load is
+// coalesced along the plane), applies the producer's instance norm + ReLU if asked, splits / rounds to
+// bf16 and writes 16-byte pieces, slab[part][k half][position][8 channels] - which is exactly the A operand
+// fragment of a lane, read back with one ds_read_b128 per (32-row tile, tap, part).  Weights arrive
+// pre-packed as whole B fragments ([part][tap][chunk][32-channel tile][lane][8 bf16], 1 KiB each) by
+// 16-byte LDS-DMA.  LDS is single buffered: a second resident workgroup covers the staging of the first.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int BF_CK = 16;
 
-template <int IT, int TAPS, bool PLAIN>
+template <int PARTS>
+__device__ __forceinline__ void bf_split(float x, __bf16 (&b)[PARTS]) {
+    b[0] = (__bf16)x;
+    if (PARTS > 1) {
+        const float r1 = x - (float)b[0];
+        b[PARTS > 1 ? 1 : 0] = (__bf16)r1;
+        if (PARTS > 2) b[PARTS > 2 ? 2 : 0] = (__bf16)(r1 - (float)b[1]);
+    }
+}
+
+template <int PARTS, int WM, int WN, int IT, int TAPS, bool PLAIN>
 __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(ConvGeom g, const float* __restrict__ x,
                                                             const float* __restrict__ stats,
                                                             const char* __restrict__ wp,
                                                             const float* __restrict__ bias, float* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) char smem_b[];
-    constexpr int WM = 2, WN = 3, WAVES = 4;
+    constexpr int WAVES = 4;
     constexpr int NT = WAVES * 64;
     constexpr int PT = WAVES * WM * 32;
     constexpr int NTILE = WN * 32;
-    char* wl = smem_b;                                    // [ntaps][WN][1 KiB]
-    char* slab = smem_b + MAX_TAPS * WN * 1024;           // [2 k halves][slab_stride][16 B]
+    constexpr int NTERM = PARTS == 1 ? 1 : PARTS == 2 ? 3 : 6;
+    // part pairs (a, b) of the products kept, smallest first; the last NTERM entries are used:
+    // PARTS = 3: (2,0) (1,1) (0,2) (1,0) (0,1) (0,0);  PARTS = 2: (1,0) (0,1) (0,0);  PARTS = 1: (0,0)
+    constexpr int TA[6] = {2, 1, 0, PARTS >= 2 ? 1 : 0, 0, 0};
+    constexpr int TB[6] = {0, 1, 2, 0, PARTS >= 2 ? 1 : 0, 0};
+    const int wpart = MAX_TAPS * WN * 1024;               // bytes of one part of the weight tile
+    char* wl = smem_b;                                    // [PARTS][ntaps][WN][1 KiB]
+    char* slab = smem_b + PARTS * wpart;                  // [PARTS][2 k halves][slab_stride][16 B]
     const int half = g.slab_stride * 16;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, l32 = lane & 31;
@@ -428,85 +451,134 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(ConvGeom g, const flo
         const int a = fdiv(pp, g.m_sw), bb = pp - a * g.SW;
         lane_pos[m] = (sg ? seg0 + a * g.S * g.IWp : (a - a00) * g.S * g.IWp) + bb * g.S;
     }
-    f32x16 acc[WM][WN];
+    // the leading products and the small cross terms accumulate apart and meet once at the end: added
+    // one by one to a sum thousands of times their size, the cross terms would lose most of their bits
+    f32x16 acc[WM][WN], lo[PARTS > 1 ? WM : 1][PARTS > 1 ? WN : 1];
 #pragma unroll
     for (int m = 0; m < WM; ++m)
 #pragma unroll
         for (int n = 0; n < WN; ++n)
 #pragma unroll
-            for (int j = 0; j < 16; ++j) acc[m][n][j] = 0.0f;
+            for (int j = 0; j < 16; ++j) {
+                acc[m][n][j] = 0.0f;
+                if (PARTS > 1) lo[m][n][j] = 0.0f;
+            }
 
     const int ntaps = TAPS > 0 ? TAPS : g.ntaps;
-    const int wcount = ntaps * WN * 64;                   // 16-byte pieces of one chunk's weights
+    const int wcount = ntaps * WN * 64;                   // 16-byte pieces of one part of one chunk's weights
     const int nchunk = g.Cin / BF_CK, ntile_all = g.CoutP / 32;
+    const long wpart_g = 9L * nchunk * ntile_all * 1024;  // bytes of one part of the packed weights
     const float* xs0 = x + (long)s0 * g.Cin * in_plane;
     const int s1 = min(s0 + 1, g.B - 1);
+
+    // raw values of the first PF slab positions of a chunk: loaded while the previous chunk's MFMAs run
+    constexpr int PF = IT < 2 ? IT : 2;
+    float pre[PF][BF_CK];
+    auto load_item = [&](int i, int c0, float (&v)[BF_CK]) {
+        // every load is issued whatever the position is (padding reads position 0 and drops the value):
+        // a load under a condition becomes a branch and a wait of its own
+        const int so = soff[i];
+        const float* src = xs0 + (long)c0 * in_plane + (so >= 0 ? so : 0);
+#pragma unroll
+        for (int c = 0; c < BF_CK; ++c) v[c] = src[(long)c * in_plane];
+    };
+    auto store_item = [&](int i, int c0, float (&v)[BF_CK]) {
+        const int so = soff[i];
+        if (so == -2) return;
+        if (!PLAIN && norm) {
+            const float* stp = stats + 2 * ((long)(so >= seg_off ? s1 : s0) * g.Cin + c0);
+#pragma unroll
+            for (int c = 0; c < BF_CK; ++c) v[c] = (v[c] - stp[2 * c]) * stp[2 * c + 1];
+        }
+#pragma unroll
+        for (int c = 0; c < BF_CK; ++c) {
+            if (!PLAIN && g.relu_in) v[c] = fmaxf(v[c], 0.0f);
+            v[c] = so >= 0 ? v[c] : 0.0f;
+        }
+        bf16x8 lo[PARTS], hi[PARTS];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            __bf16 bl[PARTS], bh[PARTS];
+            bf_split<PARTS>(v[c], bl);
+            bf_split<PARTS>(v[8 + c], bh);
+#pragma unroll
+            for (int pt = 0; pt < PARTS; ++pt) {
+                lo[pt][c] = bl[pt];
+                hi[pt][c] = bh[pt];
+            }
+        }
+        const int pos = i * NT + tid;
+#pragma unroll
+        for (int pt = 0; pt < PARTS; ++pt) {
+            *reinterpret_cast<bf16x8*>(slab + (2 * pt) * half + pos * 16) = lo[pt];
+            *reinterpret_cast<bf16x8*>(slab + (2 * pt + 1) * half + pos * 16) = hi[pt];
+        }
+    };
+#pragma unroll
+    for (int u = 0; u < PF; ++u) load_item(u, 0, pre[u]);
 
     for (int ck = 0; ck < nchunk; ++ck) {
         const int c0 = ck * BF_CK;
         __syncthreads();                                  // the previous chunk's operand reads are done
-        for (int base = 0; base < wcount; base += NT) {
-            const int i = base + tid;
-            if (i < wcount) {
-                const int t = i / (WN * 64), r = i - t * (WN * 64), j = r >> 6;
-                const long frag = ((long)g.tap_w[t] * nchunk + ck) * ntile_all + (n0 >> 5) + j;
-                __builtin_amdgcn_global_load_lds(MV_GLOBAL_PTR(wp + frag * 1024 + (r & 63) * 16),
-                                                 MV_LDS_PTR(wl + (base + wave * 64) * 16), 16, 0, 0);
-            }
-        }
 #pragma unroll
-        for (int i0 = 0; i0 < IT; i0 += 2) {
+        for (int pt = 0; pt < PARTS; ++pt)
+            for (int base = 0; base < wcount; base += NT) {
+                const int i = base + tid;
+                if (i < wcount) {
+                    const int t = i / (WN * 64), r = i - t * (WN * 64), j = r >> 6;
+                    const long frag = ((long)g.tap_w[t] * nchunk + ck) * ntile_all + (n0 >> 5) + j;
+                    __builtin_amdgcn_global_load_lds(MV_GLOBAL_PTR(wp + pt * wpart_g + frag * 1024 + (r & 63) * 16),
+                                                     MV_LDS_PTR(wl + pt * wpart + (base + wave * 64) * 16), 16, 0, 0);
+                }
+            }
+#pragma unroll
+        for (int u = 0; u < PF; ++u) store_item(u, c0, pre[u]);
+#pragma unroll
+        for (int i0 = PF; i0 < IT; i0 += 2) {             // large slabs: the rest is loaded here, two positions at a time
             float v[2][BF_CK];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                if (i0 + u >= IT) continue;
-                const int so = soff[i0 + u];
-                const float* src = xs0 + (long)c0 * in_plane + (so >= 0 ? so : 0);
+            for (int u = 0; u < 2; ++u)
+                if (i0 + u < IT) load_item(i0 + u, c0, v[u]);
 #pragma unroll
-                for (int c = 0; c < BF_CK; ++c) v[u][c] = so >= 0 ? src[(long)c * in_plane] : 0.0f;
-            }
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                if (i0 + u >= IT) continue;
-                const int so = soff[i0 + u];
-                if (so == -2) continue;
-                if (!PLAIN && so >= 0) {
-                    if (norm) {
-                        const float* stp = stats + 2 * ((long)(so >= seg_off ? s1 : s0) * g.Cin + c0);
-#pragma unroll
-                        for (int c = 0; c < BF_CK; ++c) v[u][c] = (v[u][c] - stp[2 * c]) * stp[2 * c + 1];
-                    }
-                    if (g.relu_in) {
-#pragma unroll
-                        for (int c = 0; c < BF_CK; ++c) v[u][c] = fmaxf(v[u][c], 0.0f);
-                    }
-                }
-                bf16x8 lo, hi;
-#pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    lo[c] = (__bf16)v[u][c];
-                    hi[c] = (__bf16)v[u][8 + c];
-                }
-                const int pos = (i0 + u) * NT + tid;
-                *reinterpret_cast<bf16x8*>(slab + pos * 16) = lo;
-                *reinterpret_cast<bf16x8*>(slab + half + pos * 16) = hi;
-            }
+            for (int u = 0; u < 2; ++u)
+                if (i0 + u < IT) store_item(i0 + u, c0, v[u]);
         }
         __syncthreads();                                  // weights (the barrier drains the DMA) and slab are in place
+        if (ck + 1 < nchunk) {
+#pragma unroll
+            for (int u = 0; u < PF; ++u) load_item(u, c0 + BF_CK, pre[u]);
+        }
         const char* sl = slab + h * half;
 #pragma unroll
         for (int t = 0; t < (TAPS > 0 ? TAPS : g.ntaps); ++t) {
-            bf16x8 A[WM], Bv[WN];
+            bf16x8 A[PARTS][WM], Bv[PARTS][WN];
 #pragma unroll
-            for (int m = 0; m < WM; ++m) A[m] = *reinterpret_cast<const bf16x8*>(sl + (lane_pos[m] + g.tap_off[t]) * 16);
+            for (int pt = 0; pt < PARTS; ++pt) {
 #pragma unroll
-            for (int n = 0; n < WN; ++n) Bv[n] = *reinterpret_cast<const bf16x8*>(wl + (t * WN + n) * 1024 + lane * 16);
+                for (int m = 0; m < WM; ++m)
+                    A[pt][m] = *reinterpret_cast<const bf16x8*>(sl + 2 * pt * half + (lane_pos[m] + g.tap_off[t]) * 16);
+#pragma unroll
+                for (int n = 0; n < WN; ++n)
+                    Bv[pt][n] = *reinterpret_cast<const bf16x8*>(wl + pt * wpart + (t * WN + n) * 1024 + lane * 16);
+            }
 #pragma unroll
             for (int m = 0; m < WM; ++m)
 #pragma unroll
                 for (int n = 0; n < WN; ++n)
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[m], Bv[n], acc[m][n], 0, 0, 0);
+                {
+#pragma unroll
+                    for (int e = 6 - NTERM; e < 5; ++e)
+                        lo[PARTS > 1 ? m : 0][PARTS > 1 ? n : 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                            A[TA[e]][m], Bv[TB[e]][n], lo[PARTS > 1 ? m : 0][PARTS > 1 ? n : 0], 0, 0, 0);
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0][m], Bv[0][n], acc[m][n], 0, 0, 0);
+                }
         }
+    }
+    if (PARTS > 1) {
+#pragma unroll
+        for (int m = 0; m < WM; ++m)
+#pragma unroll
+            for (int n = 0; n < WN; ++n) acc[m][n] += lo[PARTS > 1 ? m : 0][PARTS > 1 ? n : 0];
     }
     // epilogue: as conv_mfma_kernel (the accumulator layout of the two MFMA shapes is the same)
     const long oplane_sz = (long)g.OHf * g.OWf;
@@ -551,20 +623,21 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(ConvGeom g, const flo
     }
 }
 
-// w [Cout,Cin,3,3] fp32 -> B fragments of the bf16 kernel: fwd[tap][Cin/16][CoutP/32][lane][8] with
+// w [Cout,Cin,3,3] fp32 -> B fragments of the bf16 kernel: fwd[part][tap][Cin/16][CoutP/32][lane][8] with
 // lane = (k half, output channel in the tile), entry j = input channel 16*chunk + 8*half + j; bwd the
 // same with the roles of the channel counts exchanged and the taps flipped (the data gradient).
-__global__ void conv_pack_bf16_kernel(const float* __restrict__ w, int Cout, int Cin, int CoutP, int CinP,
+__global__ void conv_pack_bf16_kernel(const float* __restrict__ w, int Cout, int Cin, int CoutP, int CinP, int parts,
                                       __bf16* __restrict__ fwd, __bf16* __restrict__ bwd) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long nf = 9L * Cin * CoutP, nb = 9L * Cout * CinP;
+    float vf = 0.0f, vb = 0.0f;
     if (idx < nf) {
         const int j = (int)(idx & 7), ln = (int)((idx >> 3) & 63);
         long r = idx >> 9;
         const int nt = (int)(r % (CoutP / 32)); r /= (CoutP / 32);
         const int ck = (int)(r % (Cin / 16)), tap = (int)(r / (Cin / 16));
         const int n = nt * 32 + (ln & 31), c = ck * 16 + 8 * (ln >> 5) + j;
-        fwd[idx] = (__bf16)((n < Cout) ? w[((long)n * Cin + c) * 9 + tap] : 0.0f);
+        vf = (n < Cout) ? w[((long)n * Cin + c) * 9 + tap] : 0.0f;
     }
     if (bwd && idx < nb) {
         const int j = (int)(idx & 7), ln = (int)((idx >> 3) & 63);
@@ -572,7 +645,14 @@ __global__ void conv_pack_bf16_kernel(const float* __restrict__ w, int Cout, int
         const int ct = (int)(r % (CinP / 32)); r /= (CinP / 32);
         const int ck = (int)(r % (Cout / 16)), tap = (int)(r / (Cout / 16));
         const int c = ct * 32 + (ln & 31), n = ck * 16 + 8 * (ln >> 5) + j;
-        bwd[idx] = (__bf16)((c < Cin) ? w[((long)n * Cin + c) * 9 + (8 - tap)] : 0.0f);
+        vb = (c < Cin) ? w[((long)n * Cin + c) * 9 + (8 - tap)] : 0.0f;
+    }
+    for (int pt = 0; pt < parts; ++pt) {
+        const __bf16 bf = (__bf16)vf, bb = (__bf16)vb;
+        if (idx < nf) fwd[pt * nf + idx] = bf;
+        if (bwd && idx < nb) bwd[pt * nb + idx] = bb;
+        vf -= (float)bf;
+        vb -= (float)bb;
     }
 }
 
@@ -895,9 +975,10 @@ __global__ __launch_bounds__(WG_NT, 2) void conv_wgrad_kernel(ConvGeom g, const 
 #ifndef WGRAD_FLAT_LDS
 #define WGRAD_FLAT_LDS (80 * 1024)
 #endif
-template <int DUMMY>
+template <bool NORM>
 __global__ __launch_bounds__(WG_NT, 2) void conv_wgrad_flat_kernel(int B, int Cin, int Cout, int H, int W,
                                                                    const float* __restrict__ x,
+                                                                   const float* __restrict__ stats, int relu_in,
                                                                    const float* __restrict__ gout, int nr, int GS,
                                                                    int SS, int samples_per_group,
                                                                    float* __restrict__ partial) {
@@ -971,6 +1052,11 @@ __global__ __launch_bounds__(WG_NT, 2) void conv_wgrad_flat_kernel(int B, int Ci
         const float* ga = gl0 + (ci & 1) * gbuf + nrow * GS + phA + h;
         const float* sb = slab0 + (ci & 1) * sbuf + crow * SS + phB - r_lo * W;   // sb[iy*W + ix]
         const int npairs = (count + 1) >> 1;
+        float mean = 0.0f, rstd = 1.0f;                  // the producer's instance norm (+ ReLU) of this lane's channel
+        if (NORM && stats) {
+            mean = stats[2 * ((long)b * Cin + c0 + crow)];
+            rstd = stats[2 * ((long)b * Cin + c0 + crow) + 1];
+        }
         // grid pixel p0 + 2k + h walks the chunk two pixels per step
         int oy = a0 + fdiv(min(h, count - 1), m_w), ox = min(h, count - 1) - (oy - a0) * W;
         float av0, bv0[KKT], av1, bv1[KKT];
@@ -992,6 +1078,13 @@ __global__ __launch_bounds__(WG_NT, 2) void conv_wgrad_flat_kernel(int B, int Ci
         };
         auto mma_k = [&](int k, float av, float (&bv)[KKT]) {
             av = (2 * k + h < count) ? av : 0.0f;          // past the end of the chunk: zero gradient
+            if (NORM) {
+#pragma unroll
+                for (int t = 0; t < KKT; ++t) {
+                    const float v = (bv[t] - mean) * rstd;
+                    bv[t] = relu_in ? fmaxf(v, 0.0f) : v;
+                }
+            }
             if (2 * k + h >= count) {
 #pragma unroll
                 for (int t = 0; t < KKT; ++t) bv[t] = 0.0f;    // (whatever was read there may be NaN)
@@ -1028,33 +1121,57 @@ __global__ __launch_bounds__(WG_NT, 2) void conv_wgrad_flat_kernel(int B, int Ci
 // ---------------------------------------------------------------------------------------
 // D[n][c] per tap accumulates over output pixels, 16 per v_mfma_f32_32x32x16_bf16: a lane's 8 k values
 // are 8 consecutive pixels of one output row.  A = grad_out[n][pixels] is that run as it lies in memory.
-// B = input[c][pixel*S + tap] is the same run shifted by the tap; so that every B fragment is one aligned
-// 16-byte LDS read, the input rows a chunk needs are staged three times, once per tap column dx, already
-// subsampled by the stride: slab[dx][c][input row][ow] = pad(act(x))[c][row][ow*S + dx].  Rows are padded
-// to a multiple of 8 pixels with zeros in grad_out.  Both tiles are rounded to bf16 while staged
-// (through registers: padding, reflection and the producer's instance norm + ReLU are applied there).
+// B = input[c][pixel*S + tap] is the same run shifted by the tap column dx.  Input rows are staged as S
+// planes per row (column phase = column mod S, so a stride-2 layer keeps even and odd columns apart):
+// tap dx reads plane dx mod S shifted by dx / S elements, and a shifted fragment is built in registers
+// from the aligned 16-byte piece and the first dword of the next one (v_alignbit for an odd shift, plain
+// register renaming for a shift of two), so every LDS read is aligned and the input is staged once.
+// Rows are padded to a multiple of 8 pixels with zeros in grad_out.  Both tiles are split / rounded to
+// PARTS bf16 parts while staged (through registers: padding, reflection and the producer's instance
+// norm + ReLU are applied there); the part products kept are those of conv_bf16_kernel.
 // Channel strides in LDS are an odd number of 16-byte units, which keeps the fragment reads conflict-free.
 // Workgroup tile: 64 output x 64 input channels x 9 taps; 4 waves as 2 (n) x 2 (c); chunk = nr output
 // rows of one sample; LDS is single buffered, a second resident workgroup covers the staging.
 // partial [G][9][Cout][Cin], summed by conv_wgrad_reduce_kernel.
 struct WgradBf16 {
-    int B, Cin, Cout, H, W, OH, OW, S, pad, reflect, relu_in;
+    int B, Cin, Cout, H, W, OH, OW, pad, reflect, relu_in;
     int nr;        // output rows per chunk
     int G8;        // 8-pixel groups per output row (OW padded)
     int rows;      // input rows per chunk = (nr - 1) * S + 3
     int gunits;    // 16-byte units per grad_out channel in LDS (odd)
-    int sunits;    // 16-byte units per input channel and dx copy in LDS (odd)
+    int sunits;    // 16-byte units per input channel in LDS (odd): rows x S planes x (G8 + 1)
     int spg;       // samples per z group
 };
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-template <int S>
+// the fragment that starts `shift` bf16 elements into (p0, next dword)
+template <int SHIFT>
+__device__ __forceinline__ bf16x8 frag_shift(u32x4 p0, unsigned nxt) {
+    u32x4 o;
+    if (SHIFT == 0) o = p0;
+    else if (SHIFT == 1) {
+        o.x = __builtin_amdgcn_alignbit(p0.y, p0.x, 16);
+        o.y = __builtin_amdgcn_alignbit(p0.z, p0.y, 16);
+        o.z = __builtin_amdgcn_alignbit(p0.w, p0.z, 16);
+        o.w = __builtin_amdgcn_alignbit(nxt, p0.w, 16);
+    } else {
+        o.x = p0.y; o.y = p0.z; o.z = p0.w; o.w = nxt;
+    }
+    return __builtin_bit_cast(bf16x8, o);
+}
+
+template <int S, int PARTS>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(WgradBf16 p, const float* __restrict__ x,
                                                                   const float* __restrict__ stats,
                                                                   const float* __restrict__ gout,
                                                                   float* __restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) char smem_w[];
-    char* gl = smem_w;                                   // [64 n][gunits][16 B]
-    char* slab = smem_w + 64 * p.gunits * 16;            // [3 dx][64 c][sunits][16 B]
+    constexpr int NTERM = PARTS == 1 ? 1 : PARTS == 2 ? 3 : 6;
+    constexpr int TA[6] = {2, 1, 0, PARTS >= 2 ? 1 : 0, 0, 0};
+    constexpr int TB[6] = {0, 1, 2, 0, PARTS >= 2 ? 1 : 0, 0};
+    const int gpart = 64 * p.gunits * 16, spart = 64 * p.sunits * 16;
+    char* gl = smem_w;                                   // [PARTS][64 n][gunits][16 B]
+    char* slab = smem_w + PARTS * gpart;                 // [PARTS][64 c][rows][S planes][G8 + 1][16 B]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, l32 = lane & 31;
     const int wn = wave >> 1, wc = wave & 1;
     const int n0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
@@ -1062,8 +1179,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(WgradBf16 p, co
     const int npc = (p.OH + p.nr - 1) / p.nr;
     const int nchunks = (b_end - b_begin) * npc;
     const long in_plane = (long)p.H * p.W, out_plane = (long)p.OH * p.OW;
-    const unsigned m_g8 = magic_of(p.G8), m_gch = magic_of(p.nr * p.G8), m_sch = magic_of(p.rows * p.G8);
-    constexpr int NV = 8 * S + 2;                        // source columns behind one group of 8 pixels, all dx
+    const int RU = S * (p.G8 + 1);                       // units per staged input row
+    const unsigned m_g8 = magic_of(p.G8), m_gch = magic_of(p.nr * p.G8), m_sch = magic_of(p.rows * RU), m_ru = magic_of(RU),
+                   m_g9 = magic_of(p.G8 + 1);
 
     f32x16 acc[9];
 #pragma unroll
@@ -1071,70 +1189,134 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(WgradBf16 p, co
 #pragma unroll
         for (int j = 0; j < 16; ++j) acc[t][j] = 0.0f;
 
-    const int gitems = 64 * p.nr * p.G8, sitems = 64 * p.rows * p.G8;
+    const int gitems = 64 * p.nr * p.G8, sitems = 64 * p.rows * RU;
     for (int ci = 0; ci < nchunks; ++ci) {
         const int b = b_begin + ci / npc, a0 = (ci % npc) * p.nr;
         __syncthreads();                                 // the previous chunk's operand reads are done
-        for (int it = tid; it < gitems; it += 256) {     // grad_out: (n, row, group)
-            const int n = fdiv(it, m_gch), rg = it - n * p.nr * p.G8;
-            const int r = fdiv(rg, m_g8), g8 = rg - r * p.G8;
-            bf16x8 o;
-            const bool ok = n0 + n < p.Cout && a0 + r < p.OH;
-            const float* src = gout + ((long)b * p.Cout + n0 + n) * out_plane + (long)(a0 + r) * p.OW + 8 * g8;
+        // Staging runs U items at a time: their 8 loads each are all issued (unconditionally, clamped into the
+        // plane, the value dropped where there is no pixel) before the first is converted.
+        constexpr int U = 4;
+        for (int it0 = tid; it0 < gitems; it0 += 256 * U) {     // grad_out: (n, row, group)
+            float v[U][8];
+            int dst[U];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = (__bf16)((ok && 8 * g8 + j < p.OW) ? src[j] : 0.0f);
-            *reinterpret_cast<bf16x8*>(gl + (n * p.gunits + rg) * 16) = o;
+            for (int u = 0; u < U; ++u) {
+                const int it = min(it0 + u * 256, gitems - 1);
+                const int n = fdiv(it, m_gch), rg = it - n * p.nr * p.G8;
+                const int r = fdiv(rg, m_g8), g8 = rg - r * p.G8;
+                const bool ok = n0 + n < p.Cout && a0 + r < p.OH;
+                const float* src = gout + ((long)b * p.Cout + (ok ? n0 + n : 0)) * out_plane + (long)(ok ? a0 + r : 0) * p.OW;
+                dst[u] = it0 + u * 256 < gitems ? (n * p.gunits + rg) * 16 : -1;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int ow = 8 * g8 + j;
+                    const float t = src[min(ow, p.OW - 1)];
+                    v[u][j] = (ok && ow < p.OW) ? t : 0.0f;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (dst[u] < 0) continue;
+                bf16x8 o[PARTS];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    __bf16 bp[PARTS];
+                    bf_split<PARTS>(v[u][j], bp);
+#pragma unroll
+                    for (int pt = 0; pt < PARTS; ++pt) o[pt][j] = bp[pt];
+                }
+#pragma unroll
+                for (int pt = 0; pt < PARTS; ++pt) *reinterpret_cast<bf16x8*>(gl + pt * gpart + dst[u]) = o[pt];
+            }
         }
-        for (int it = tid; it < sitems; it += 256) {     // input: (c, input row, group) -> three shifted copies
-            const int c = fdiv(it, m_sch), rg = it - c * p.rows * p.G8;
-            const int r = fdiv(rg, m_g8), g8 = rg - r * p.G8;
-            int vy = a0 * S + r - p.pad;
-            bool rok = c0 + c < p.Cin;
-            if (p.reflect) vy = vy < 0 ? -vy : (vy >= p.H ? 2 * (p.H - 1) - vy : vy);
-            else rok = rok && vy >= 0 && vy < p.H;
-            rok = rok && vy >= 0 && vy < p.H;             // rows past the plane (a short last chunk)
-            const long pl = (long)b * p.Cin + c0 + c;
-            const float* src = x + pl * in_plane + (long)vy * p.W;
-            float mean = 0.0f, rstd = 1.0f;
-            if (stats && rok) {
-                mean = stats[2 * pl];
-                rstd = stats[2 * pl + 1];
+        for (int it0 = tid; it0 < sitems; it0 += 256 * U) {     // input: (c, input row, plane, unit)
+            float v[U][8];
+            int dst[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int it = min(it0 + u * 256, sitems - 1);
+                const int c = fdiv(it, m_sch), ru = it - c * p.rows * RU;
+                const int r = fdiv(ru, m_ru), uu = ru - r * RU;
+                const int ph = fdiv(uu, m_g9), gu = uu - ph * (p.G8 + 1);
+                int vy = a0 * S + r - p.pad;
+                bool rok = c0 + c < p.Cin;
+                if (p.reflect) vy = vy < 0 ? -vy : (vy >= p.H ? 2 * (p.H - 1) - vy : vy);
+                rok = rok && vy >= 0 && vy < p.H;         // zero padding, and rows past the plane (a short last chunk)
+                const long pl = (long)b * p.Cin + (rok ? c0 + c : 0);
+                const float* src = x + pl * in_plane + (long)(rok ? vy : 0) * p.W;
+                float mean = 0.0f, rstd = 1.0f;
+                if (stats) {
+                    mean = stats[2 * pl];
+                    rstd = stats[2 * pl + 1];
+                }
+                dst[u] = it0 + u * 256 < sitems ? (c * p.sunits + ru) * 16 : -1;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    int vx = (8 * gu + j) * S + ph - p.pad;
+                    if (p.reflect) vx = vx < 0 ? -vx : (vx >= p.W ? 2 * (p.W - 1) - vx : vx);
+                    const bool ok = rok && vx >= 0 && vx < p.W;
+                    float t = src[min(max(vx, 0), p.W - 1)];
+                    if (stats) t = (t - mean) * rstd;
+                    if (p.relu_in) t = fmaxf(t, 0.0f);
+                    v[u][j] = ok ? t : 0.0f;
+                }
             }
-            float v[NV];
 #pragma unroll
-            for (int j = 0; j < NV; ++j) {
-                int vx = 8 * g8 * S + j - p.pad;
-                bool ok = rok;
-                if (p.reflect) vx = vx < 0 ? -vx : (vx >= p.W ? 2 * (p.W - 1) - vx : vx);
-                ok = ok && vx >= 0 && vx < p.W;
-                float t = ok ? src[vx] : 0.0f;
-                if (ok && stats) t = (t - mean) * rstd;
-                if (p.relu_in) t = fmaxf(t, 0.0f);
-                v[j] = t;
-            }
+            for (int u = 0; u < U; ++u) {
+                if (dst[u] < 0) continue;
+                bf16x8 o[PARTS];
 #pragma unroll
-            for (int dx = 0; dx < 3; ++dx) {
-                bf16x8 o;
+                for (int j = 0; j < 8; ++j) {
+                    __bf16 bp[PARTS];
+                    bf_split<PARTS>(v[u][j], bp);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) o[j] = (__bf16)v[j * S + dx];
-                *reinterpret_cast<bf16x8*>(slab + (((dx * 64 + c) * p.sunits) + rg) * 16) = o;
+                    for (int pt = 0; pt < PARTS; ++pt) o[pt][j] = bp[pt];
+                }
+#pragma unroll
+                for (int pt = 0; pt < PARTS; ++pt) *reinterpret_cast<bf16x8*>(slab + pt * spart + dst[u]) = o[pt];
             }
         }
         __syncthreads();
         const char* ga = gl + (wn * 32 + l32) * p.gunits * 16;
         const char* sb = slab + (wc * 32 + l32) * p.sunits * 16;
-        const int dxs = 64 * p.sunits * 16;              // bytes between dx copies
-        const int nsteps = (p.nr * p.G8) >> 1;
+        const int ngroups = p.nr * p.G8, nsteps = (ngroups + 1) >> 1;
         int r = fdiv(h, m_g8), g8 = h - r * p.G8;         // this lane's group 2*ks + h
         for (int ks = 0; ks < nsteps; ++ks) {
-            const bf16x8 A = *reinterpret_cast<const bf16x8*>(ga + (2 * ks + h) * 16);
-            const char* bb = sb + ((r * S) * p.G8 + g8) * 16;
-            bf16x8 Bv[9];
+            // an odd number of groups: the last step's upper half has none - zero A, and B from group 0
+            const bool live = 2 * ks + h < ngroups;
+            if (!live) r = g8 = 0;
+            bf16x8 A[PARTS];
 #pragma unroll
-            for (int t = 0; t < 9; ++t)
-                Bv[t] = *reinterpret_cast<const bf16x8*>(bb + (t % 3) * dxs + (t / 3) * p.G8 * 16);
+            for (int pt = 0; pt < PARTS; ++pt) {
+                u32x4 a = *reinterpret_cast<const u32x4*>(ga + pt * gpart + (live ? 2 * ks + h : 0) * 16);
+                if (!live) a = u32x4{0u, 0u, 0u, 0u};
+                A[pt] = __builtin_bit_cast(bf16x8, a);
+            }
 #pragma unroll
-            for (int t = 0; t < 9; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, Bv[t], acc[t], 0, 0, 0);
+            for (int dy = 0; dy < 3; ++dy) {
+                const char* row = sb + ((r * S + dy) * RU + g8) * 16;
+                bf16x8 Bv[3][PARTS];
+#pragma unroll
+                for (int pt = 0; pt < PARTS; ++pt) {
+                    const char* rp = row + pt * spart;
+                    const u32x4 e0 = *reinterpret_cast<const u32x4*>(rp);
+                    const unsigned e1 = *reinterpret_cast<const unsigned*>(rp + 16);
+                    if (S == 1) {
+                        Bv[0][pt] = frag_shift<0>(e0, e1);
+                        Bv[1][pt] = frag_shift<1>(e0, e1);
+                        Bv[2][pt] = frag_shift<2>(e0, e1);
+                    } else {
+                        Bv[0][pt] = frag_shift<0>(e0, e1);
+                        Bv[1][pt] = *reinterpret_cast<const bf16x8*>(rp + (p.G8 + 1) * 16);
+                        Bv[2][pt] = frag_shift<1>(e0, e1);
+                    }
+                }
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+                    for (int e = 6 - NTERM; e < 6; ++e)
+                        acc[dy * 3 + dx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[TA[e]], Bv[dx][TB[e]], acc[dy * 3 + dx], 0, 0, 0);
+            }
             g8 += 2;
             if (g8 >= p.G8) { g8 -= p.G8; ++r; }
             if (g8 >= p.G8) { g8 -= p.G8; ++r; }
@@ -1362,43 +1544,62 @@ static int launch_conv(ConvGeom g, const float* x, const float* stats, const flo
     return 0;
 }
 
-template <int IT, int TAPS, bool PLAIN>
+template <int PARTS, int WM, int WN, int IT, int TAPS, bool PLAIN>
 static void launch_conv_bf16_t(const ConvGeom& g, size_t lds, const float* x, const float* stats, const char* wp,
                                const float* bias, float* out, hipStream_t st) {
-    constexpr int PT = 256, NTILE = 96;
+    constexpr int PT = 4 * WM * 32, NTILE = WN * 32;
     static bool once = false;
-    if (!once) { set_attr_once(reinterpret_cast<const void*>(conv_bf16_kernel<IT, TAPS, PLAIN>)); once = true; }
+    if (!once) { set_attr_once(reinterpret_cast<const void*>(conv_bf16_kernel<PARTS, WM, WN, IT, TAPS, PLAIN>)); once = true; }
     const long Q = (long)g.B * g.SH * g.SW;
-    dim3 grid((unsigned)((Q + PT - 1) / PT), g.CoutP / NTILE, 1);
-    hipLaunchKernelGGL((conv_bf16_kernel<IT, TAPS, PLAIN>), grid, dim3(256), lds, st, g, x, stats, wp, bias, out);
+    dim3 grid((unsigned)((Q + PT - 1) / PT), (g.Cout + NTILE - 1) / NTILE, 1);
+    hipLaunchKernelGGL((conv_bf16_kernel<PARTS, WM, WN, IT, TAPS, PLAIN>), grid, dim3(256), lds, st, g, x, stats, wp, bias,
+                       out);
 }
 
-static int launch_conv_bf16(ConvGeom g, const float* x, const float* stats, const char* wp, const float* bias,
-                            float* out, hipStream_t st) {
+// tile shapes per number of parts: (rows, output channels) per workgroup chosen so that two workgroups fit a CU
+template <int PARTS, int WM, int WN>
+static int launch_conv_bf16_p(ConvGeom g, const float* x, const float* stats, const char* wp, const float* bias,
+                              float* out, hipStream_t st) {
     const int P = g.SH * g.SW;
-    constexpr int PT = 256;
+    constexpr int PT = 4 * WM * 32;
     MV_REQUIRE(P >= PT, E_SHAPE, "mdnvae_conv2d_bf16: plane of %d pixels is smaller than the %d-pixel tile", P, PT);
-    MV_REQUIRE(g.Cin % BF_CK == 0, E_SHAPE, "mdnvae_conv2d_bf16: Cin %d must be a multiple of 16", g.Cin);
     const int one = ((PT + g.SW - 2) / g.SW) * g.S + g.KHe;
     const int two = (PT / g.SW) * g.S + 2 * g.KHe;
     const int rows = one > two ? one : two;
     g.slab_stride = rows * g.IWp;
     MV_REQUIRE(g.slab_stride <= 6 * 256, E_SHAPE, "mdnvae_conv2d_bf16: slab of %d positions is too large", g.slab_stride);
-    const size_t lds = (size_t)MAX_TAPS * 3 * 1024 + (size_t)2 * g.slab_stride * 16;
+    const size_t lds = (size_t)PARTS * ((size_t)MAX_TAPS * WN * 1024 + (size_t)2 * g.slab_stride * 16);
+    MV_REQUIRE(lds <= 160 * 1024, E_SHAPE, "mdnvae_conv2d_bf16: tile needs %zu bytes of LDS", lds);
     const bool plain = stats == nullptr && !g.relu_in;
     if (g.slab_stride <= 2 * 256) {
-        if (g.ntaps == 9 && plain) launch_conv_bf16_t<2, 9, true>(g, lds, x, stats, wp, bias, out, st);
-        else if (g.ntaps == 9) launch_conv_bf16_t<2, 9, false>(g, lds, x, stats, wp, bias, out, st);
-        else if (plain) launch_conv_bf16_t<2, 0, true>(g, lds, x, stats, wp, bias, out, st);
-        else launch_conv_bf16_t<2, 0, false>(g, lds, x, stats, wp, bias, out, st);
+        if (g.ntaps == 9 && plain) launch_conv_bf16_t<PARTS, WM, WN, 2, 9, true>(g, lds, x, stats, wp, bias, out, st);
+        else if (g.ntaps == 9) launch_conv_bf16_t<PARTS, WM, WN, 2, 9, false>(g, lds, x, stats, wp, bias, out, st);
+        else if (plain) launch_conv_bf16_t<PARTS, WM, WN, 2, 0, true>(g, lds, x, stats, wp, bias, out, st);
+        else launch_conv_bf16_t<PARTS, WM, WN, 2, 0, false>(g, lds, x, stats, wp, bias, out, st);
     } else {
-        if (g.ntaps == 9 && plain) launch_conv_bf16_t<6, 9, true>(g, lds, x, stats, wp, bias, out, st);
-        else if (g.ntaps == 9) launch_conv_bf16_t<6, 9, false>(g, lds, x, stats, wp, bias, out, st);
-        else if (plain) launch_conv_bf16_t<6, 0, true>(g, lds, x, stats, wp, bias, out, st);
-        else launch_conv_bf16_t<6, 0, false>(g, lds, x, stats, wp, bias, out, st);
+        if (g.ntaps == 9 && plain) launch_conv_bf16_t<PARTS, WM, WN, 6, 9, true>(g, lds, x, stats, wp, bias, out, st);
+        else if (g.ntaps == 9) launch_conv_bf16_t<PARTS, WM, WN, 6, 9, false>(g, lds, x, stats, wp, bias, out, st);
+        else if (plain) launch_conv_bf16_t<PARTS, WM, WN, 6, 0, true>(g, lds, x, stats, wp, bias, out, st);
+        else launch_conv_bf16_t<PARTS, WM, WN, 6, 0, false>(g, lds, x, stats, wp, bias, out, st);
     }
     MV_LAUNCH_CHECK("conv_bf16_kernel");
     return 0;
+}
+
+static int launch_conv_bf16(const ConvGeom& g, int parts, const float* x, const float* stats, const char* wp,
+                            const float* bias, float* out, hipStream_t st) {
+    MV_REQUIRE(g.Cin % BF_CK == 0, E_SHAPE, "mdnvae_conv2d_bf16: Cin %d must be a multiple of 16", g.Cin);
+    if (parts == 1) return launch_conv_bf16_p<1, 2, 3>(g, x, stats, wp, bias, out, st);
+    if (parts == 2) return launch_conv_bf16_p<2, 2, 2>(g, x, stats, wp, bias, out, st);
+    // three parts: 128-row tiles while two workgroups fit a CU (80 KiB each); else one workgroup with 256 rows,
+    // whose longer MFMA phase hides more of its own staging
+    const int rows128 = std::max(((128 + g.SW - 2) / g.SW) * g.S + g.KHe, (128 / g.SW) * g.S + 2 * g.KHe);
+    const size_t lds128 = (size_t)3 * ((size_t)MAX_TAPS * 2 * 1024 + (size_t)2 * rows128 * g.IWp * 16);
+    const int rows256 = std::max(((256 + g.SW - 2) / g.SW) * g.S + g.KHe, (256 / g.SW) * g.S + 2 * g.KHe);
+    const size_t lds256 = (size_t)3 * ((size_t)MAX_TAPS * 2 * 1024 + (size_t)2 * rows256 * g.IWp * 16);
+    if (lds128 <= 80 * 1024 || lds256 > 160 * 1024 || g.SH * g.SW < 256)
+        return launch_conv_bf16_p<3, 1, 2>(g, x, stats, wp, bias, out, st);
+    return launch_conv_bf16_p<3, 2, 2>(g, x, stats, wp, bias, out, st);
 }
 
 static int wgrad_groups(int B, int ntiles) {
@@ -1446,10 +1647,10 @@ int mdnvae_conv_pack_weights(const float* w, int Cout, int Cin, int KS, float* p
 // Forward convolution (transposed = 0) or data gradient (transposed = 1); bf16: packed_w holds bf16 fragments
 static int conv2d_run(const float* x, const float* in_stats, int relu_in, const void* packed_w_, const float* bias,
                       float* out, int B, int Cin, int H, int W, int Cout, int OH, int OW, int KS, int stride, int pad,
-                      int reflect, int transposed, void* stream, bool bf16) {
+                      int reflect, int transposed, void* stream, int bf16) {
     const float* packed_w = static_cast<const float*>(packed_w_);
     auto launch = [&](const ConvGeom& gg, const float* bb) {
-        return bf16 ? launch_conv_bf16(gg, x, in_stats, static_cast<const char*>(packed_w_), bb, out, (hipStream_t)stream)
+        return bf16 ? launch_conv_bf16(gg, bf16, x, in_stats, static_cast<const char*>(packed_w_), bb, out, (hipStream_t)stream)
                     : launch_conv(gg, x, in_stats, packed_w, bb, out, (hipStream_t)stream);
     };
     MV_REQUIRE(!(bf16 && Cin == 1), E_SHAPE, "mdnvae_conv2d_bf16: the single-channel stem runs in fp32 (mdnvae_conv2d)");
@@ -1489,7 +1690,7 @@ static int conv2d_run(const float* x, const float* in_stats, int relu_in, const 
             MV_LAUNCH_CHECK("conv_stem_kernel");
             return 0;
         }
-        g.CoutP = round_up(Cout, 96);
+        g.CoutP = round_up(Cout, bf16 ? 192 : 96);
         g.ntaps = 9;
         for (int t = 0; t < 9; ++t) {
             g.tap_off[t] = (t / 3) * g.IWp + (t % 3);
@@ -1502,7 +1703,7 @@ static int conv2d_run(const float* x, const float* in_stats, int relu_in, const 
     MV_REQUIRE(H == (OH + 2 * pad - KS) / stride + 1 && W == (OW + 2 * pad - KS) / stride + 1, E_SHAPE,
                "mdnvae_conv2d: gradient %dx%d is not the k%d s%d p%d image of a %dx%d plane", H, W, KS, stride, pad, OH,
                OW);
-    g.CoutP = round_up(Cout, 96);
+    g.CoutP = round_up(Cout, bf16 ? 192 : 96);
     g.reflect = 0;
     g.S = 1;
     if (stride == 1) {
@@ -1546,34 +1747,36 @@ int mdnvae_conv2d(const float* x, const float* in_stats, int relu_in, const floa
                   float* out, int B, int Cin, int H, int W, int Cout, int OH, int OW, int KS, int stride, int pad,
                   int reflect, int transposed, void* stream) {
     return conv2d_run(x, in_stats, relu_in, packed_w, bias, out, B, Cin, H, W, Cout, OH, OW, KS, stride, pad, reflect,
-                      transposed, stream, false);
+                      transposed, stream, 0);
 }
 
-size_t mdnvae_conv_packed_bytes_bf16(int Cout, int Cin, int KS, int transposed) {
-    if (KS != 3 || Cin % 16 || Cout % 16) return 0;
-    return (size_t)9 * 2 * (transposed ? (size_t)Cout * round_up(Cin, 96) : (size_t)Cin * round_up(Cout, 96));
+size_t mdnvae_conv_packed_bytes_bf16(int Cout, int Cin, int KS, int transposed, int parts) {
+    if (KS != 3 || Cin % 16 || Cout % 16 || parts < 1 || parts > 3) return 0;
+    return (size_t)parts * 9 * 2 * (transposed ? (size_t)Cout * round_up(Cin, 192) : (size_t)Cin * round_up(Cout, 192));
 }
 
-int mdnvae_conv_pack_weights_bf16(const float* w, int Cout, int Cin, int KS, void* packed_fwd, void* packed_bwd,
+int mdnvae_conv_pack_weights_bf16(const float* w, int Cout, int Cin, int KS, int parts, void* packed_fwd, void* packed_bwd,
                                   void* stream) {
     MV_REQUIRE(w && packed_fwd, E_ARG, "mdnvae_conv_pack_weights_bf16: null pointer");
+    MV_REQUIRE(parts >= 1 && parts <= 3, E_ARG, "mdnvae_conv_pack_weights_bf16: parts = %d (1, 2 or 3)", parts);
     MV_REQUIRE(KS == 3 && Cin >= 16 && Cin % 16 == 0 && Cout % 16 == 0, E_SHAPE,
                "mdnvae_conv_pack_weights_bf16: 3x3 kernels with channel counts that are multiples of 16 (got k%d, %d -> %d)",
                KS, Cin, Cout);
-    const int CoutP = round_up(Cout, 96), CinP = round_up(Cin, 96);
+    const int CoutP = round_up(Cout, 192), CinP = round_up(Cin, 192);
     const long nf = 9L * Cin * CoutP, nb = packed_bwd ? 9L * Cout * CinP : 0;
     const long n = nf > nb ? nf : nb;
     hipLaunchKernelGGL(conv_pack_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, Cout,
-                       Cin, CoutP, CinP, static_cast<__bf16*>(packed_fwd), static_cast<__bf16*>(packed_bwd));
+                       Cin, CoutP, CinP, parts, static_cast<__bf16*>(packed_fwd), static_cast<__bf16*>(packed_bwd));
     MV_LAUNCH_CHECK("conv_pack_bf16_kernel");
     return 0;
 }
 
 int mdnvae_conv2d_bf16(const float* x, const float* in_stats, int relu_in, const void* packed_w, const float* bias,
                        float* out, int B, int Cin, int H, int W, int Cout, int OH, int OW, int KS, int stride, int pad,
-                       int reflect, int transposed, void* stream) {
+                       int reflect, int transposed, int parts, void* stream) {
+    MV_REQUIRE(parts >= 1 && parts <= 3, E_ARG, "mdnvae_conv2d_bf16: parts = %d (1, 2 or 3)", parts);
     return conv2d_run(x, in_stats, relu_in, packed_w, bias, out, B, Cin, H, W, Cout, OH, OW, KS, stride, pad, reflect,
-                      transposed, stream, true);
+                      transposed, stream, parts);
 }
 
 size_t mdnvae_conv_wgrad_workspace_floats(int B, int Cout, int Cin, int KS) {
@@ -1625,7 +1828,7 @@ int mdnvae_conv2d_wgrad(const float* x, const float* in_stats, int relu_in, cons
     const int Gz0 = wgrad_groups(B, ntiles);
     const int spg = (B + Gz0 - 1) / Gz0, Gz = (B + spg - 1) / spg;
     const long total = (long)KK * Cout * Cin;
-    if (KS == 3 && stride == 1 && pad == 1 && reflect && !in_stats && !relu_in && H >= 3 && W >= 3 && W <= 64) {
+    if (KS == 3 && stride == 1 && pad == 1 && reflect && (in_stats || !relu_in) && H >= 3 && W >= 3 && W <= 64) {
         // flat 16-byte staging: whole grid rows per chunk, as many as leave room for two workgroups per CU
         int nr = 0, GS = 0, SS = 0;
         size_t lds = 0;
@@ -1636,10 +1839,18 @@ int mdnvae_conv2d_wgrad(const float* x, const float* in_stats, int relu_in, cons
         }
         if (nr > 0) {
             static bool once_flat = false;
-            if (!once_flat) { set_attr_once(reinterpret_cast<const void*>(conv_wgrad_flat_kernel<0>)); once_flat = true; }
+            if (!once_flat) {
+                set_attr_once(reinterpret_cast<const void*>(conv_wgrad_flat_kernel<false>));
+                set_attr_once(reinterpret_cast<const void*>(conv_wgrad_flat_kernel<true>));
+                once_flat = true;
+            }
             dim3 grid((Cout + 63) / 64, (Cin + 63) / 64, Gz);
-            hipLaunchKernelGGL(conv_wgrad_flat_kernel<0>, grid, dim3(WG_NT), lds, st, B, Cin, Cout, H, W, x, grad_out, nr,
-                               GS, SS, spg, workspace);
+            if (in_stats)
+                hipLaunchKernelGGL(conv_wgrad_flat_kernel<true>, grid, dim3(WG_NT), lds, st, B, Cin, Cout, H, W, x, in_stats,
+                                   relu_in, grad_out, nr, GS, SS, spg, workspace);
+            else
+                hipLaunchKernelGGL(conv_wgrad_flat_kernel<false>, grid, dim3(WG_NT), lds, st, B, Cin, Cout, H, W, x, in_stats,
+                                   relu_in, grad_out, nr, GS, SS, spg, workspace);
             MV_LAUNCH_CHECK("conv_wgrad_flat_kernel");
             hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
                                workspace, Gz, KK, Cout, Cin, grad_w);
@@ -1691,10 +1902,21 @@ int mdnvae_conv2d_wgrad(const float* x, const float* in_stats, int relu_in, cons
     return 0;
 }
 
-int mdnvae_conv2d_wgrad_bf16(const float* x, const float* in_stats, int relu_in, const float* grad_out, float* workspace,
-                             float* grad_w, int B, int Cin, int H, int W, int Cout, int OH, int OW, int KS, int stride,
-                             int pad, int reflect, void* stream) {
+}  // extern "C"
+
+template <int S, int PARTS>
+static void launch_wgrad_bf16(const WgradBf16& p, dim3 grid, size_t lds, const float* x, const float* stats,
+                              const float* grad_out, float* workspace, hipStream_t st) {
+    static bool once = false;
+    if (!once) { set_attr_once(reinterpret_cast<const void*>(conv_wgrad_bf16_kernel<S, PARTS>)); once = true; }
+    hipLaunchKernelGGL((conv_wgrad_bf16_kernel<S, PARTS>), grid, dim3(256), lds, st, p, x, stats, grad_out, workspace);
+}
+
+extern "C" int mdnvae_conv2d_wgrad_bf16(const float* x, const float* in_stats, int relu_in, const float* grad_out,
+                                        float* workspace, float* grad_w, int B, int Cin, int H, int W, int Cout, int OH,
+                                        int OW, int KS, int stride, int pad, int reflect, int parts, void* stream) {
     MV_REQUIRE(B >= 1, E_ARG, "mdnvae_conv2d_wgrad_bf16: empty batch");
+    MV_REQUIRE(parts >= 1 && parts <= 3, E_ARG, "mdnvae_conv2d_wgrad_bf16: parts = %d (1, 2 or 3)", parts);
     MV_REQUIRE(x && grad_out && workspace && grad_w, E_ARG, "mdnvae_conv2d_wgrad_bf16: null pointer");
     MV_REQUIRE(KS == 3 && Cin > 1 && pad == 1 && (stride == 1 || stride == 2), E_SHAPE,
                "mdnvae_conv2d_wgrad_bf16: 3x3, pad 1, stride 1 or 2, more than one input channel (got k%d p%d s%d Cin %d)", KS,
@@ -1703,40 +1925,41 @@ int mdnvae_conv2d_wgrad_bf16(const float* x, const float* in_stats, int relu_in,
                "mdnvae_conv2d_wgrad_bf16: output size mismatch");
     MV_REQUIRE(!reflect || (H >= 2 && W >= 2), E_SHAPE, "mdnvae_conv2d_wgrad_bf16: reflection needs a plane of 2x2 or more");
     WgradBf16 p{};
-    p.B = B; p.Cin = Cin; p.Cout = Cout; p.H = H; p.W = W; p.OH = OH; p.OW = OW; p.S = stride; p.pad = pad;
+    p.B = B; p.Cin = Cin; p.Cout = Cout; p.H = H; p.W = W; p.OH = OH; p.OW = OW; p.pad = pad;
     p.reflect = reflect; p.relu_in = relu_in;
     p.G8 = (OW + 7) / 8;
-    // the largest chunk of output rows (an even number of 8-pixel groups) whose tiles leave room for two workgroups
+    // the largest chunk of output rows whose tiles leave room for two workgroups
+    auto lds_of = [&](int nr) {
+        const int rows = (nr - 1) * stride + 3;
+        return (size_t)parts * 64 * (((nr * p.G8) | 1) + ((rows * stride * (p.G8 + 1)) | 1)) * 16;
+    };
     int best = 0;
     for (size_t cap : {(size_t)78 * 1024, (size_t)156 * 1024}) {      // room for two workgroups per CU, else for one
-        for (int nr = 1; nr <= OH + 1 && nr <= 16; ++nr) {
-            if ((nr * p.G8) & 1) continue;
-            const int rows = (nr - 1) * stride + 3;
-            const size_t lds = ((size_t)64 * ((nr * p.G8) | 1) + (size_t)3 * 64 * ((rows * p.G8) | 1)) * 16;
-            if (lds <= cap) best = nr;
-        }
+        for (int nr = 1; nr <= OH && nr <= 16; ++nr)
+            if (lds_of(nr) <= cap) best = nr;
         if (best) break;
     }
     MV_REQUIRE(best > 0, E_SHAPE, "mdnvae_conv2d_wgrad_bf16: no chunk of output rows fits in LDS (OW = %d)", OW);
     p.nr = best;
     p.rows = (best - 1) * stride + 3;
     p.gunits = (best * p.G8) | 1;
-    p.sunits = (p.rows * p.G8) | 1;
-    const size_t lds = ((size_t)64 * p.gunits + (size_t)3 * 64 * p.sunits) * 16;
+    p.sunits = (p.rows * stride * (p.G8 + 1)) | 1;
+    const size_t lds = lds_of(best);
     const int ntiles = ((Cout + 63) / 64) * ((Cin + 63) / 64);
     const int Gz0 = wgrad_groups(B, ntiles);
     p.spg = (B + Gz0 - 1) / Gz0;
     const int Gz = (B + p.spg - 1) / p.spg;
     hipStream_t st = (hipStream_t)stream;
-    static bool once = false;
-    if (!once) {
-        set_attr_once(reinterpret_cast<const void*>(conv_wgrad_bf16_kernel<1>));
-        set_attr_once(reinterpret_cast<const void*>(conv_wgrad_bf16_kernel<2>));
-        once = true;
-    }
     dim3 grid((Cout + 63) / 64, (Cin + 63) / 64, Gz);
-    if (stride == 1) hipLaunchKernelGGL(conv_wgrad_bf16_kernel<1>, grid, dim3(256), lds, st, p, x, in_stats, grad_out, workspace);
-    else hipLaunchKernelGGL(conv_wgrad_bf16_kernel<2>, grid, dim3(256), lds, st, p, x, in_stats, grad_out, workspace);
+    if (stride == 1) {
+        if (parts == 1) launch_wgrad_bf16<1, 1>(p, grid, lds, x, in_stats, grad_out, workspace, st);
+        else if (parts == 2) launch_wgrad_bf16<1, 2>(p, grid, lds, x, in_stats, grad_out, workspace, st);
+        else launch_wgrad_bf16<1, 3>(p, grid, lds, x, in_stats, grad_out, workspace, st);
+    } else {
+        if (parts == 1) launch_wgrad_bf16<2, 1>(p, grid, lds, x, in_stats, grad_out, workspace, st);
+        else if (parts == 2) launch_wgrad_bf16<2, 2>(p, grid, lds, x, in_stats, grad_out, workspace, st);
+        else launch_wgrad_bf16<2, 3>(p, grid, lds, x, in_stats, grad_out, workspace, st);
+    }
     MV_LAUNCH_CHECK("conv_wgrad_bf16_kernel");
     const long total = 9L * Cout * Cin;
     hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, workspace, Gz, 9,
@@ -1745,4 +1968,3 @@ int mdnvae_conv2d_wgrad_bf16(const float* x, const float* in_stats, int relu_in,
     return 0;
 }
 
-}  // extern "C"

@@ -117,18 +117,27 @@ def _dev_int(a, device):
 # ---------------------------------------------------------------------------------------
 # conv-encoder VAE family
 # ---------------------------------------------------------------------------------------
+CONV_PRECISIONS = {"fp32_mfma": 0, "bf16": 1, "bf16x2": 2, "fp32": 3}
+
+
 class ConvVAE(nn.Module):
     """Conv/ResNet encoder (or, with encoder='fnn', the two-tower FNN encoder of
     function_FC/MM_Gate_test.py) + five-branch rank-1 decoder.
 
+    precision: how the encoder's 3x3 convolutions multiply (CONV_PRECISIONS): 'fp32_mfma' the fp32 matrix
+              instruction; 'fp32' fp32 accuracy from three bf16 parts per operand on the bf16 matrix cores;
+              'bf16x2' two parts (2^-16 per product); 'bf16' operands rounded to bf16.  fp32 accumulation always.
     decoder:  'nn'   plain second layers                          (VAE_CNN_NN scripts)
               'gcn'  GraphCNN second layers + diagonal intercept  (VAE-CNN-GCN scripts)
     intercept: 'dense' | 'diag' | 'none';  final: 'exp' | 'none';  dropout: p or 0
     """
 
     def __init__(self, decoder="nn", intercept="dense", final="exp", dropout=0.0, n_nodes=68, latent_dim=68,
-                 act="sigmoid", encoder="conv"):
+                 act="sigmoid", encoder="conv", precision="fp32"):
         super().__init__()
+        if precision not in CONV_PRECISIONS:
+            raise ValueError(f"precision {precision!r}: one of {sorted(CONV_PRECISIONS)}")
+        self.precision = precision
         self.n_nodes, self.latent_dim = n_nodes, latent_dim
         self.decoder_kind, self.intercept_kind, self.final, self.act = decoder, intercept, final, act
         self.encoder_kind = encoder
@@ -185,7 +194,8 @@ class ConvVAE(nn.Module):
             h11 = self.fc111(self.fc11(x, act="relu"), act="relu")
             h12 = self.fc222(self.fc12(x, act="relu"), act="relu")
             return self.fc21(h11), self.fc22(h12)
-        feat = ops.conv_encoder(x, self.n_nodes, [(m.weight, m.bias) for m in self.conv_params()])
+        feat = ops.conv_encoder(x, self.n_nodes, [(m.weight, m.bias) for m in self.conv_params()],
+                                parts=CONV_PRECISIONS[self.precision])
         return self.fc_mean(feat), self.fc_log_var(feat)
 
     def reparameterize(self, mu, logvar, eps=None):

@@ -783,16 +783,19 @@ class _ConvLayer:
         self.h = h
         self.oh = _conv_out(h, ks, stride, pad)
 
-    def pack(self, w, dev, need_bwd, bf16=False):
+    def pack(self, w, dev, need_bwd, parts=0):
+        """parts = 0: weights for the fp32 matrix instruction; 1..3: bf16 fragments in that many split
+        parts (1 = plain bf16, 3 = fp32-accurate) for the bf16 matrix cores, as a uint8 buffer."""
         lib = _lib.load()
-        if bf16 and self.cin > 1:
-            wf = torch.empty(lib.mdnvae_conv_packed_bytes_bf16(self.cout, self.cin, self.ks, 0), dtype=torch.uint8, device=dev)
+        if parts and self.cin > 1:
+            wf = torch.empty(lib.mdnvae_conv_packed_bytes_bf16(self.cout, self.cin, self.ks, 0, parts), dtype=torch.uint8,
+                             device=dev)
             wb = None
             if need_bwd:
-                wb = torch.empty(lib.mdnvae_conv_packed_bytes_bf16(self.cout, self.cin, self.ks, 1), dtype=torch.uint8,
+                wb = torch.empty(lib.mdnvae_conv_packed_bytes_bf16(self.cout, self.cin, self.ks, 1, parts), dtype=torch.uint8,
                                  device=dev)
-            call("mdnvae_conv_pack_weights_bf16", ptr(_c(w), "conv weight"), self.cout, self.cin, self.ks, wf.data_ptr(),
-                 None if wb is None else wb.data_ptr(), stream())
+            call("mdnvae_conv_pack_weights_bf16", ptr(_c(w), "conv weight"), self.cout, self.cin, self.ks, parts,
+                 wf.data_ptr(), None if wb is None else wb.data_ptr(), stream())
             return wf, wb
         wf = torch.empty(lib.mdnvae_conv_packed_floats(self.cout, self.cin, self.ks, 0), dtype=torch.float32, device=dev)
         wb = None
@@ -801,35 +804,41 @@ class _ConvLayer:
         call("mdnvae_conv_pack_weights", ptr(_c(w), "conv weight"), self.cout, self.cin, self.ks, ptr(wf), ptr(wb), stream())
         return wf, wb
 
-    def fwd(self, x, stats, relu_in, wf, bias, B):
-        """wf from pack(); a uint8 buffer (bf16 fragments) selects the bf16 kernel."""
+    def fwd(self, x, stats, relu_in, wf, bias, B, parts=0):
+        """wf from pack() with the same parts."""
         out = torch.empty(B, self.cout, self.oh, self.oh, dtype=torch.float32, device=x.device)
-        bf16 = wf.dtype == torch.uint8
-        call("mdnvae_conv2d_bf16" if bf16 else "mdnvae_conv2d", ptr(x), ptr(stats), int(relu_in),
-             wf.data_ptr() if bf16 else ptr(wf), ptr(bias, "conv bias"), ptr(out), B, self.cin,
-             self.h, self.h, self.cout, self.oh, self.oh, self.ks, self.stride, self.pad, int(self.reflect), 0, stream())
+        geom = (B, self.cin, self.h, self.h, self.cout, self.oh, self.oh, self.ks, self.stride, self.pad, int(self.reflect), 0)
+        if parts and self.cin > 1:
+            call("mdnvae_conv2d_bf16", ptr(x), ptr(stats), int(relu_in), ptr(wf, "packed weights", torch.uint8),
+                 ptr(bias, "conv bias"), ptr(out), *geom, parts, stream())
+        else:
+            call("mdnvae_conv2d", ptr(x), ptr(stats), int(relu_in), ptr(wf), ptr(bias, "conv bias"), ptr(out), *geom, stream())
         return out
 
-    def dgrad(self, gout, wb, B):
+    def dgrad(self, gout, wb, B, parts=0):
         """Gradient w.r.t. the conv input; for reflection-padded layers on the padded plane."""
         if self.reflect:
             oh, pad = self.h + 2 * self.pad, 0
         else:
             oh, pad = self.h, self.pad
         gin = torch.empty(B, self.cin, oh, oh, dtype=torch.float32, device=gout.device)
-        bf16 = wb.dtype == torch.uint8
-        call("mdnvae_conv2d_bf16" if bf16 else "mdnvae_conv2d", ptr(gout), None, 0, wb.data_ptr() if bf16 else ptr(wb), None,
-             ptr(gin), B, self.cout, self.oh, self.oh, self.cin, oh, oh, self.ks, self.stride, pad, 0, 1, stream())
+        geom = (B, self.cout, self.oh, self.oh, self.cin, oh, oh, self.ks, self.stride, pad, 0, 1)
+        if parts:
+            call("mdnvae_conv2d_bf16", ptr(gout), None, 0, ptr(wb, "packed weights", torch.uint8), None, ptr(gin), *geom,
+                 parts, stream())
+        else:
+            call("mdnvae_conv2d", ptr(gout), None, 0, ptr(wb), None, ptr(gin), *geom, stream())
         return gin
 
-    def wgrad(self, x, stats, relu_in, gout, B, bf16=False):
+    def wgrad(self, x, stats, relu_in, gout, B, parts=0):
         lib = _lib.load()
         ws = torch.empty(lib.mdnvae_conv_wgrad_workspace_floats(B, self.cout, self.cin, self.ks), dtype=torch.float32,
                          device=x.device)
         gw = torch.empty(self.cout, self.cin, self.ks, self.ks, dtype=torch.float32, device=x.device)
-        call("mdnvae_conv2d_wgrad_bf16" if bf16 and self.cin > 1 else "mdnvae_conv2d_wgrad", ptr(x), ptr(stats),
+        split = (parts,) if parts and self.cin > 1 else ()
+        call("mdnvae_conv2d_wgrad_bf16" if split else "mdnvae_conv2d_wgrad", ptr(x), ptr(stats),
              int(relu_in), ptr(gout), ptr(ws), ptr(gw), B, self.cin, self.h,
-             self.h, self.cout, self.oh, self.oh, self.ks, self.stride, self.pad, int(self.reflect), stream())
+             self.h, self.cout, self.oh, self.oh, self.ks, self.stride, self.pad, int(self.reflect), *split, stream())
         return gw
 
 
@@ -873,37 +882,49 @@ def encoder_layers(n_nodes, n_res=5):
     return [l1, l2, l3] + res
 
 
+def _mul_parts(parts, layer):
+    """How a layer's forward and data-gradient products run under encoder mode `parts`: in the
+    fp32-accurate mode (3) the stride-2 layers stay on the fp32 matrix instruction, which is the faster
+    of two kernels held to the same bar there (their few-tap data-gradient launches and wide slabs
+    leave the bf16 kernel staging-bound); weight gradients use `parts` as given."""
+    if layer.cin == 1 or (parts == 3 and layer.stride != 1):
+        return 0
+    return parts
+
+
 class _ConvEncoder(torch.autograd.Function):
     """x [B, n*n] -> pooled features [B, 192*(h/8)^2]; every arithmetic step is a HIP kernel."""
 
     @staticmethod
-    def forward(ctx, x, n_nodes, *wb):
+    def forward(ctx, x, n_nodes, parts, *wb):
         x = _c(x)
         B = x.shape[0]
         dev = x.device
         ptr(x, "x")
         layers = encoder_layers(n_nodes, (len(wb) // 2 - 3) // 2)
-        need_bwd = any(ctx.needs_input_grad[2:])
+        need_bwd = any(ctx.needs_input_grad[3:])
         ws = [w for w in wb[0::2]]
         bs = [b for b in wb[1::2]]
-        packed = [ly.pack(w, dev, need_bwd) for ly, w in zip(layers, ws)]
-        # every normalised activation is materialised once (one extra write per layer, small next to
-        # the convolutions), so the convolution kernels stage plain tensors
-        raw1 = layers[0].fwd(x, None, 0, packed[0][0], bs[0], B)
-        act1, st1 = _inorm_fwd(raw1, None, 1)
-        raw2 = layers[1].fwd(act1, None, 0, packed[1][0], bs[1], B)
-        act2, st2 = _inorm_fwd(raw2, None, 1)
-        raw3 = layers[2].fwd(act2, None, 0, packed[2][0], bs[2], B)
+        mp = [_mul_parts(parts, ly) for ly in layers]
+        packed = [ly.pack(w, dev, need_bwd, m) for ly, w, m in zip(layers, ws, mp)]
+        # a normalised activation that only feeds the next convolution is never written: the convolution
+        # normalises the raw output of its producer while loading it (statistics from one read of the
+        # raw planes); only the residual stream x + block(x) is materialised
+        raw1 = layers[0].fwd(x, None, 0, packed[0][0], bs[0], B, mp[0])
+        st1 = _plane_stats(raw1)
+        raw2 = layers[1].fwd(raw1, st1, 1, packed[1][0], bs[1], B, mp[1])
+        st2 = _plane_stats(raw2)
+        raw3 = layers[2].fwd(raw2, st2, 1, packed[2][0], bs[2], B, mp[2])
         xk, st3 = _inorm_fwd(raw3, None, 1)
-        saved = [x, raw1, st1, act1, raw2, st2, act2, raw3, st3, xk]
+        saved = [x, raw1, st1, raw2, st2, raw3, st3, xk]
         nres = (len(layers) - 3) // 2
         for k in range(nres):
             la, lb = layers[3 + 2 * k], layers[4 + 2 * k]
-            ra = la.fwd(xk, None, 0, packed[3 + 2 * k][0], bs[3 + 2 * k], B)
-            aa, sa = _inorm_fwd(ra, None, 1)
-            rb = lb.fwd(aa, None, 0, packed[4 + 2 * k][0], bs[4 + 2 * k], B)
+            ra = la.fwd(xk, None, 0, packed[3 + 2 * k][0], bs[3 + 2 * k], B, mp[3 + 2 * k])
+            sa = _plane_stats(ra)
+            rb = lb.fwd(ra, sa, 1, packed[4 + 2 * k][0], bs[4 + 2 * k], B, mp[4 + 2 * k])
             xk, sb = _inorm_fwd(rb, xk, 0)
-            saved += [ra, sa, aa, rb, sb, xk]
+            saved += [ra, sa, rb, sb, xk]
         H = layers[-1].oh
         K = 8
         PH = H // K
@@ -912,18 +933,18 @@ class _ConvEncoder(torch.autograd.Function):
         call("mdnvae_maxpool_fwd", ptr(xk), B * 192, H, H, K, ptr(feat), ptr(argmax, "argmax", torch.int32), stream())
         if need_bwd:
             ctx.save_for_backward(*saved, argmax, *[p[1] for p in packed[1:]])
-            ctx.n_nodes, ctx.nres = n_nodes, nres
+            ctx.n_nodes, ctx.nres, ctx.parts = n_nodes, nres, parts
         return feat
 
     @staticmethod
     def backward(ctx, gfeat):
         sv = ctx.saved_tensors
-        nres = ctx.nres
+        nres, parts = ctx.nres, ctx.parts
         layers = encoder_layers(ctx.n_nodes, nres)
-        x, raw1, st1, act1, raw2, st2, act2, raw3, st3, x0 = sv[:10]
-        blocks = [sv[10 + 6 * k: 16 + 6 * k] for k in range(nres)]
-        argmax = sv[10 + 6 * nres]
-        wbwd = sv[11 + 6 * nres:]         # packed data-gradient weights of layers 1..
+        x, raw1, st1, raw2, st2, raw3, st3, x0 = sv[:8]
+        blocks = [sv[8 + 5 * k: 13 + 5 * k] for k in range(nres)]
+        argmax = sv[8 + 5 * nres]
+        wbwd = sv[9 + 5 * nres:]          # packed data-gradient weights of layers 1..
         B = x.shape[0]
         H = layers[-1].oh
         gfeat = _c(gfeat)
@@ -932,39 +953,41 @@ class _ConvEncoder(torch.autograd.Function):
         gw = [None] * len(layers)
         gb = [None] * len(layers)
         for k in range(nres - 1, -1, -1):
-            ra, sa, aa, rb, sb, _ = blocks[k]
-            xin = x0 if k == 0 else blocks[k - 1][5]
+            ra, sa, rb, sb, _ = blocks[k]
+            xin = x0 if k == 0 else blocks[k - 1][4]
             ia, ib = 3 + 2 * k, 4 + 2 * k
             g_rb, gb[ib] = _inorm_bwd(rb, sb, G, 0, 0)
-            gw[ib] = layers[ib].wgrad(aa, None, 0, g_rb, B)
-            gp_a = layers[ib].dgrad(g_rb, wbwd[ib - 1], B)
+            gw[ib] = layers[ib].wgrad(ra, sa, 1, g_rb, B, parts)
+            gp_a = layers[ib].dgrad(g_rb, wbwd[ib - 1], B, _mul_parts(parts, layers[ib]))
             g_ra, gb[ia] = _inorm_bwd(ra, sa, gp_a, 1, 1)
-            gw[ia] = layers[ia].wgrad(xin, None, 0, g_ra, B)
-            gp_x = layers[ia].dgrad(g_ra, wbwd[ia - 1], B)
+            gw[ia] = layers[ia].wgrad(xin, None, 0, g_ra, B, parts)
+            gp_x = layers[ia].dgrad(g_ra, wbwd[ia - 1], B, _mul_parts(parts, layers[ia]))
             Gn = torch.empty_like(G)
             call("mdnvae_fold_add", ptr(G), ptr(gp_x), B * 192, H, H, ptr(Gn), stream())
             G = Gn
         g_r3, gb[2] = _inorm_bwd(raw3, st3, G, 1, 0)
-        gw[2] = layers[2].wgrad(act2, None, 0, g_r3, B)
-        g_a2 = layers[2].dgrad(g_r3, wbwd[1], B)
+        gw[2] = layers[2].wgrad(raw2, st2, 1, g_r3, B, parts)
+        g_a2 = layers[2].dgrad(g_r3, wbwd[1], B, _mul_parts(parts, layers[2]))
         g_r2, gb[1] = _inorm_bwd(raw2, st2, g_a2, 1, 0)
-        gw[1] = layers[1].wgrad(act1, None, 0, g_r2, B)
-        g_a1 = layers[1].dgrad(g_r2, wbwd[0], B)
+        gw[1] = layers[1].wgrad(raw1, st1, 1, g_r2, B, parts)
+        g_a1 = layers[1].dgrad(g_r2, wbwd[0], B, _mul_parts(parts, layers[1]))
         g_r1, gb[0] = _inorm_bwd(raw1, st1, g_a1, 1, 0)
         gw[0] = layers[0].wgrad(x.view(B, 1, ctx.n_nodes, ctx.n_nodes), None, 0, g_r1, B)
         grads = []
         for w_, b_ in zip(gw, gb):
             grads += [w_, b_]
-        return (None, None, *grads)
+        return (None, None, None, *grads)
 
 
-def conv_encoder(x, n_nodes, weights_and_biases):
+def conv_encoder(x, n_nodes, weights_and_biases, parts=0):
     """weights_and_biases: [(weight, bias)] for the stem, the two stride-2 convs and the residual
-    block convs, in network order."""
+    block convs, in network order.  parts: 0 = the fp32 matrix instruction; 1..3 = the 3x3 convolutions on
+    the bf16 matrix cores with operands split into that many bf16 parts (1: operands rounded to bf16,
+    3: fp32 accuracy); the stem, the norms and the pool are fp32 in every mode."""
     flat = []
     for w, b in weights_and_biases:
         flat += [w, b]
-    return _ConvEncoder.apply(x, n_nodes, *flat)
+    return _ConvEncoder.apply(x, n_nodes, int(parts), *flat)
 
 
 # ---------------------------------------------------------------------------------------

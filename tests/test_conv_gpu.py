@@ -57,8 +57,11 @@ def test_conv_forward_dgrad_wgrad(cin, cout, ks, stride, pad, reflect, h, B):
     st = ops._plane_stats(xg) if norm else None
     out = ly.fwd(xg, st, norm, wf, b.to(DEV), B)
     assert out.shape == want.shape
+    tag = f"{cin}->{cout} s{stride} h{h} B{B}"
+    recipe.record("conv fp32 mfma", "forward vs float64", tag, _rel(out, want), 1e-5)
     assert _rel(out, want) <= 1e-5
     gw = ly.wgrad(xg, st, norm, cg, B)
+    recipe.record("conv fp32 mfma", "weight gradient vs float64", tag, _rel(gw, wd.grad), 1e-5)
     assert _rel(gw, wd.grad) <= 1e-5
     if cin > 1:
         gin = ly.dgrad(cg, wb, B)
@@ -66,11 +69,48 @@ def test_conv_forward_dgrad_wgrad(cin, cout, ks, stride, pad, reflect, h, B):
             folded = torch.empty(B, cin, h, h, device=DEV)
             ops.call("mdnvae_fold_add", None, ops.ptr(gin), B * cin, h, h, ops.ptr(folded), ops.stream())
             gin = folded
+        recipe.record("conv fp32 mfma", "data gradient vs float64", tag, _rel(gin, act.grad), 1e-5)
         assert _rel(gin, act.grad) <= 1e-5
 
 
 def _bf16(t):
     return t.to(torch.bfloat16).double()
+
+
+@pytest.mark.parametrize("cin,cout,ks,stride,pad,reflect,h", [g for g in GEOMS if g[0] > 1])
+@pytest.mark.parametrize("parts,bar", [(3, 1e-5), (2, 1e-4)])
+def test_split_conv_forward_dgrad(cin, cout, ks, stride, pad, reflect, h, parts, bar):
+    """The convolutions on the bf16 matrix cores with each operand split into bf16 parts, against the
+    float64 convolution of the unrounded operands: three parts must meet the bar of the fp32 kernels
+    (1e-5 of the largest entry), two parts 1e-4."""
+    B = 3
+    g = torch.Generator().manual_seed(cin * 7 + h + B)
+    x = torch.randn(B, cin, h, h, generator=g)
+    w = torch.randn(cout, cin, ks, ks, generator=g) / (cin * ks * ks) ** 0.5
+    b = torch.randn(cout, generator=g)
+    xd, wd, bd = x.double().requires_grad_(True), w.double().requires_grad_(True), b.double()
+    act = F.relu(F.instance_norm(xd, eps=1e-5))
+    act.retain_grad()
+    want = _ref_conv(act, wd, bd, ks, stride, pad, reflect)
+    cot = torch.randn(want.shape, generator=g)
+    (want * cot.double()).sum().backward()
+    ly = ops._ConvLayer(cin, cout, ks, stride, pad, reflect, h)
+    xg = x.to(DEV)
+    wf, wb = ly.pack(w.to(DEV), DEV, True, parts)
+    st = ops._plane_stats(xg)
+    out = ly.fwd(xg, st, True, wf, b.to(DEV), B, parts)
+    recipe.record(f"conv split x{parts}", "forward vs float64", f"{cin}->{cout} s{stride} h{h}", _rel(out, want), bar)
+    assert _rel(out, want) <= bar
+    gin = ly.dgrad(cot.to(DEV), wb, B, parts)
+    if reflect:
+        folded = torch.empty(B, cin, h, h, device=DEV)
+        ops.call("mdnvae_fold_add", None, ops.ptr(gin), B * cin, h, h, ops.ptr(folded), ops.stream())
+        gin = folded
+    recipe.record(f"conv split x{parts}", "data gradient vs float64", f"{cin}->{cout} s{stride} h{h}", _rel(gin, act.grad), bar)
+    assert _rel(gin, act.grad) <= bar
+    gw = ly.wgrad(xg, st, True, cot.to(DEV), B, parts)
+    recipe.record(f"conv split x{parts}", "weight gradient vs float64", f"{cin}->{cout} s{stride} h{h}", _rel(gw, wd.grad), bar)
+    assert _rel(gw, wd.grad) <= bar
 
 
 @pytest.mark.parametrize("cin,cout,ks,stride,pad,reflect,h", [g for g in GEOMS if g[0] > 1])
@@ -91,8 +131,8 @@ def test_bf16_conv_forward_dgrad(cin, cout, ks, stride, pad, reflect, h, B):
     act32 = F.relu((x - stc[:, :, 0, None, None]) * stc[:, :, 1, None, None])
     want = _ref_conv(_bf16(act32), _bf16(w), b.double(), ks, stride, pad, reflect)
     exact = _ref_conv(act32.double(), w.double(), b.double(), ks, stride, pad, reflect)
-    wf, wb = ly.pack(w.to(DEV), DEV, True, bf16=True)
-    out = ly.fwd(xg, st, True, wf, b.to(DEV), B)
+    wf, wb = ly.pack(w.to(DEV), DEV, True, 1)
+    out = ly.fwd(xg, st, True, wf, b.to(DEV), B, 1)
     recipe.record("conv bf16", "forward vs float64 on the rounded operands", f"{cin}->{cout} s{stride} h{h} B{B}",
                   _rel(out, want), 1e-5, note=f"{_rel(out, exact):.1e} from the unrounded convolution")
     assert _rel(out, want) <= 1e-5
@@ -101,7 +141,7 @@ def test_bf16_conv_forward_dgrad(cin, cout, ks, stride, pad, reflect, h, B):
     cd = _bf16(cot).requires_grad_(False)
     xin = torch.zeros(B, cin, h, h, dtype=torch.float64, requires_grad=True)
     (_ref_conv(xin, _bf16(w), None, ks, stride, pad, reflect) * cd).sum().backward()
-    gin = ly.dgrad(cot.to(DEV), wb, B)
+    gin = ly.dgrad(cot.to(DEV), wb, B, 1)
     if reflect:
         folded = torch.empty(B, cin, h, h, device=DEV)
         ops.call("mdnvae_fold_add", None, ops.ptr(gin), B * cin, h, h, ops.ptr(folded), ops.stream())
@@ -111,7 +151,7 @@ def test_bf16_conv_forward_dgrad(cin, cout, ks, stride, pad, reflect, h, B):
     assert _rel(gin, xin.grad) <= 1e-5
     wd = torch.zeros(cout, cin, ks, ks, dtype=torch.float64, requires_grad=True)
     (_ref_conv(_bf16(act32), wd, None, ks, stride, pad, reflect) * cd).sum().backward()
-    gw = ly.wgrad(xg, st, True, cot.to(DEV), B, bf16=True)
+    gw = ly.wgrad(xg, st, True, cot.to(DEV), B, 1)
     recipe.record("conv bf16", "weight gradient vs float64 on the rounded operands", f"{cin}->{cout} s{stride} h{h} B{B}",
                   _rel(gw, wd.grad), 1e-5)
     assert _rel(gw, wd.grad) <= 1e-5
@@ -232,3 +272,56 @@ def test_conv_vae_against_reference_fixture(variant):
     assert _rel(recon, fix["recon"]) <= 1e-5 and _rel(x_latent, fix["x_latent"]) <= 1e-5
     assert abs(loss.item() - float(fix["loss"])) <= 1e-5 * abs(float(fix["loss"]))
     _check_grads(fix, model)
+
+
+# bars of the bf16 mode against the fp32 reference fixture: every 3x3 convolution rounds its operands to
+# bf16 (2^-9 relative per value), thirteen of them in sequence with instance norms between; the errors are
+# random-walk sums of those roundings, not a systematic loss of accuracy
+BF16_OUT_BAR = 2e-2        # mu, logvar, recon, x_latent: largest deviation / largest entry
+BF16_LOSS_BAR = 5e-3
+BF16_GRAD_BAR = 5e-2       # L2 distance to the fp32-mode gradient / its norm: everything after the encoder
+BF16_ENC_GRAD_BAR = 0.3    # the encoder's own weights: their gradients cross up to thirteen instance norms, a chain
+                           # that carries the reference's own fp32 rounding (6e-8) to 3e-4 at the stem (see the
+                           # ec87 fixture's float64 entries), and bf16 rounding (4e-3) as far in proportion
+
+
+@pytest.mark.parametrize("variant", ["cnn_gcn_fc", "cnn_gcn_sc"])
+def test_bf16_conv_vae_against_reference_fixture(variant):
+    """The conv VAE of function_FC/VAE_CNN_GCN.py with its encoder convolutions on the bf16 matrix cores
+    (precision='bf16'), against the fp32 reference fixture at the bf16 bars above, and against this
+    library's own fp32 mode (same bars; the two modes share every kernel outside the convolutions)."""
+    fix = load_fixture(variant)
+    x = torch.from_numpy(fix["x"]).to(DEV)
+    eps = torch.from_numpy(fix["eps"]).to(DEV)
+    results = {}
+    for precision in ("bf16", "fp32"):
+        model = M.ConvVAE(precision=precision, **VARIANT_CTOR[variant]).eval()
+        model.load_state_dict(fixture_params(fix), strict=False)
+        model = model.to(DEV)
+        if "mask" in fix.files:
+            model.set_mask([torch.from_numpy(fix["mask"])] * 5 + [torch.eye(68 * 68)])
+        recon, mu, logvar, x_latent = model(x, eps=eps)
+        loss = M.vae_loss(recon, x, mu, logvar, R.loss_mode(variant))
+        loss.backward()
+        results[precision] = (dict(mu=mu, logvar=logvar, recon=recon, x_latent=x_latent), loss.item(),
+                              {n: p.grad.detach().clone() for n, p in model.named_parameters()})
+    outs, loss, grads = results["bf16"]
+    for name, got in outs.items():
+        err = _rel(got, fix[name])
+        recipe.record(fix, "bf16 mode vs reference fp32", name, err, BF16_OUT_BAR)
+        assert err <= BF16_OUT_BAR, (name, err)
+    lerr = abs(loss - float(fix["loss"])) / abs(float(fix["loss"]))
+    recipe.record(fix, "bf16 mode vs reference fp32", "loss", lerr, BF16_LOSS_BAR)
+    assert lerr <= BF16_LOSS_BAR
+    worst = 0.0
+    for name, g in grads.items():
+        if name.startswith("ec.") and name.endswith(".bias"):
+            continue                                   # exactly zero in exact arithmetic (instance norm follows)
+        ref = results["fp32"][2][name]
+        err = float((g - ref).norm() / ref.norm())
+        worst = max(worst, err)
+        bar = BF16_ENC_GRAD_BAR if name.startswith("ec.") else BF16_GRAD_BAR
+        recipe.record(fix, "bf16 mode vs fp32 mode, gradient L2 " + ("(encoder weights)" if name.startswith("ec.") else "(after the encoder)"),
+                      name, err, bar)
+        assert err <= bar, (name, err)
+    assert worst > 1e-5                                # the bf16 kernels really ran

@@ -55,22 +55,23 @@ def bench_conv(B):
         geoms = [tuple(int(v) for v in g.split(",")) for g in os.environ["KB_GEOMS"].split(";")]
         geoms = [(a, b, c, d, e, bool(f), h) for a, b, c, d, e, f, h in geoms]
     plain = not os.environ.get("KB_NORM")       # the encoder feeds materialised activations (no norm on load)
+    parts = int(os.environ.get("KB_PARTS", "0"))   # 0 = fp32 matrix instruction, 1..3 = bf16 parts
     out = []
     for cin, cout, ks, stride, pad, reflect, h in geoms:
         ly = ops._ConvLayer(cin, cout, ks, stride, pad, reflect, h)
         x = torch.randn(B, cin, h, h, device=dev)
         w = torch.randn(cout, cin, ks, ks, device=dev) * 0.05
         b = torch.randn(cout, device=dev)
-        wf, wb = ly.pack(w, dev, True)
+        wf, wb = ly.pack(w, dev, True, parts)
         st = ops._plane_stats(x) if (cin > 1 and not plain) else None
         g = torch.randn(B, cout, ly.oh, ly.oh, device=dev)
         fl = 2.0 * ks * ks * cin * cout * ly.oh * ly.oh * B
-        med, best = timeit(lambda: ly.fwd(x, st, cin > 1 and not plain, wf, b, B), iters=10)
-        out.append(dict(kernel="conv_fwd", geom=[cin, cout, ks, stride, h], B=B, ms=med * 1e3, TFLOPs=fl / med / 1e12))
+        med, best = timeit(lambda: ly.fwd(x, st, cin > 1 and not plain, wf, b, B, parts), iters=10)
+        out.append(dict(kernel="conv_fwd", parts=parts, norm=not plain, geom=[cin, cout, ks, stride, h], B=B, ms=med * 1e3, TFLOPs=fl / med / 1e12))
         if cin > 1:
-            med, best = timeit(lambda: ly.dgrad(g, wb, B), iters=10)
+            med, best = timeit(lambda: ly.dgrad(g, wb, B, parts), iters=10)
             out.append(dict(kernel="conv_dgrad", geom=[cin, cout, ks, stride, h], B=B, ms=med * 1e3, TFLOPs=fl / med / 1e12))
-        med, best = timeit(lambda: ly.wgrad(x, st, cin > 1 and not plain, g, B), iters=10)
+        med, best = timeit(lambda: ly.wgrad(x, st, cin > 1 and not plain, g, B, parts), iters=10)
         out.append(dict(kernel="conv_wgrad", geom=[cin, cout, ks, stride, h], B=B, ms=med * 1e3, TFLOPs=fl / med / 1e12))
     return out
 
