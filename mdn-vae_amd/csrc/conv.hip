@@ -1939,6 +1939,10 @@ extern "C" int mdnvae_conv2d_wgrad_bf16(const float* x, const float* in_stats, i
             if (lds_of(nr) <= cap) best = nr;
         if (best) break;
     }
+    if (const char* e = getenv("MDNVAE_WGRAD_NR")) {                  // tuning knob: rows per chunk
+        const int nr = atoi(e);
+        if (nr >= 1 && nr <= OH && lds_of(nr) <= 156 * 1024) best = nr;
+    }
     MV_REQUIRE(best > 0, E_SHAPE, "mdnvae_conv2d_wgrad_bf16: no chunk of output rows fits in LDS (OW = %d)", OW);
     p.nr = best;
     p.rows = (best - 1) * stride + 3;
