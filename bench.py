@@ -224,7 +224,7 @@ BF16_TAGS = {"split_gemm_kernel", "conv_bf16_kernel", "conv_wgrad_bf16_kernel"}
 # kernels that reach fp32 accuracy with several bf16 products per multiply: rated in fp32-equivalent
 # flops against the bf16 peak divided by their number of products
 SPLIT_PRODUCTS = {"conv_bf16x2_kernel": 3, "conv_bf16x3_kernel": 6, "conv_wgrad_bf16x2_kernel": 3, "conv_wgrad_bf16x3_kernel": 6}
-ABI_TAGS["mdnvae_split_gemm"] = ("split_gemm_kernel", lambda a: 12.0 * a[5] * a[3] * a[4])
+ABI_TAGS["mdnvae_split_gemm"] = ("split_gemm_kernel", lambda a: 12.0 * a[5] * min(a[3], a[6] * (a[3] // a[13])) * a[4])
 # matrix-core entry points with a fixed tag (work in flops; kept out of HBM_TAGS)
 ABI_TAGS.update({
     # (layer_in, layer_dpre, B, count, ...): one 96 x 96 x B product per (channel, layer)
@@ -502,7 +502,7 @@ def main():
                        # that shortcut is full_first_layer_value
                        "symmetric_first_layer": bool(args.model in ("mm_gate", "mdn_gate") and not args.full_first_layer),
                        "first_layer_gemm": "split-bf16 MFMA (fp32-accurate), hand-written"
-                       if args.model in ("mm_gate", "mdn_gate") and not args.full_first_layer else "library fp32"},
+                       if args.model in ("mm_gate", "mdn_gate") else "library fp32"},
         }
         kernels = kernel_table(clock, clocked) if clocked else {}
         if kernels:

@@ -252,10 +252,11 @@ int mdnvae_split_rows(const float* src, long R, long K, long ld, long row_tile0,
 int mdnvae_split_cols(const float* src, long Kd, long R, long ld, long row_tile0, void* out, void* stream);
 /* out[m][n] = sum_k a[m][k] b[n][k] (+ bias[n], ReLU when relu != 0) for m < m_valid: columns
  * n < n_split go to out0 (bias0), the others to out1 (bias1) at column n - n_split; row stride ld_out.
- * M a multiple of tile_m (128 or 256), N and n_split multiples of 256, K of 16. */
-int mdnvae_split_gemm(const void* a, const void* b, long M, long N, long K, long m_valid, const float* bias0,
-                      const float* bias1, int relu, float* out0, float* out1, long n_split, long ld_out, int tile_m,
-                      void* stream);
+ * M a multiple of tile_m (128 or 256), N and n_split multiples of 256, K of 16.  Only rows < m_valid and, of
+ * each output, columns < n_valid are stored; accumulate = 1 adds to what the output holds (no ReLU then). */
+int mdnvae_split_gemm(const void* a, const void* b, long M, long N, long K, long m_valid, long n_valid,
+                      const float* bias0, const float* bias1, int relu, int accumulate, float* out0, float* out1,
+                      long n_split, long ld_out, int tile_m, void* stream);
 
 /* ---- conv / ResNet encoder ---------------------------------------------------------------
  * The ATen conv2d / instance_norm / relu / max_pool2d calls (and their autograd) of the encoder

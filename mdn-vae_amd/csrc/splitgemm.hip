@@ -51,32 +51,50 @@ __device__ __forceinline__ void sg_emit(const float (&v)[8], char* dst) {
     for (int s = 0; s < 3; ++s) *reinterpret_cast<sg_frag*>(dst + s * SG_FRAG) = p[s];
 }
 
-// src [R][ld] fp32, K columns used (multiple of 16) -> tiled parts, operand row = src row, k = src
-// column.  One workgroup: 32 rows x 64 columns; a thread owns 8 consecutive columns of one row, which
-// is one 16-byte chunk of each part.  Rows >= R are written as zeros.
+// src [R][ld] fp32, K columns used -> tiled parts, operand row = src row, k = src column (ceil(K/16) k
+// steps, zero beyond K).  One workgroup: 32 rows x 64 columns; a thread owns 8 consecutive columns of one
+// row, which is one 16-byte chunk of each part.  Rows >= R are written as zeros.  VEC: K a multiple of
+// 16, rows 16-byte aligned - two 16-byte loads per thread.  Otherwise the 32 x 64 block goes through LDS:
+// consecutive lanes load consecutive floats, whatever the row stride and alignment.
+template <bool VEC>
 __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict__ src, int R, int K, long ld,
-                                                         int row_tile0, char* __restrict__ out) {
+                                                         int row_tile0, int KS, char* __restrict__ out) {
+    __shared__ float tile[VEC ? 1 : 32][VEC ? 1 : 65];
     const int rt = blockIdx.x, r = threadIdx.x >> 3, c = threadIdx.x & 7;
     const int k0 = blockIdx.y * 64 + c * 8;
-    if (k0 >= K) return;
     const int row = rt * 32 + r;
     float v[8];
-    if (row < R) {
-        const sg_v4 a = *reinterpret_cast<const sg_v4*>(src + (long)row * ld + k0);
-        const sg_v4 b = *reinterpret_cast<const sg_v4*>(src + (long)row * ld + k0 + 4);
-        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
-        v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-    } else {
+    if (VEC) {
+        if (k0 >= K) return;
+        if (row < R) {
+            const sg_v4 a = *reinterpret_cast<const sg_v4*>(src + (long)row * ld + k0);
+            const sg_v4 b = *reinterpret_cast<const sg_v4*>(src + (long)row * ld + k0 + 4);
+            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+            v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+        } else {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = 0.0f;
+            for (int e = 0; e < 8; ++e) v[e] = 0.0f;
+        }
+    } else {
+        const int lc = threadIdx.x & 63, lr = threadIdx.x >> 6;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int rr = rt * 32 + lr + 4 * i, kk = blockIdx.y * 64 + lc;
+            tile[lr + 4 * i][lc] = (rr < R && kk < K) ? src[(long)rr * ld + kk] : 0.0f;
+        }
+        __syncthreads();
+        if (k0 >= KS * 16) return;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = tile[r][c * 8 + e];
     }
-    const int ks = k0 >> 4, h = (k0 >> 3) & 1, KS = K >> 4;
+    const int ks = k0 >> 4, h = (k0 >> 3) & 1;
     sg_emit(v, out + ((long)(row_tile0 + rt) * KS + ks) * SG_STEP + h * 512 + r * 16);
 }
 
 // src [Kd][ld] fp32, R columns used -> tiled parts with operand row = src COLUMN and k = src row (the
 // transposed operand of a weight-gradient product).  One workgroup: 64 src rows x 32 src columns
 // through LDS; k beyond Kd is written as zeros (the tiled operand holds ceil(Kd/16) steps).
+template <bool VEC>
 __global__ __launch_bounds__(256) void split_cols_kernel(const float* __restrict__ src, int Kd, int R, long ld,
                                                          int row_tile0, int KS, char* __restrict__ out) {
     __shared__ float tile[64][33];
@@ -88,8 +106,9 @@ __global__ __launch_bounds__(256) void split_cols_kernel(const float* __restrict
             const int kk = kb + pass * 32 + rr, col = rt * 32 + c4;
             sg_v4 a = {0.0f, 0.0f, 0.0f, 0.0f};
             if (kk < Kd) {
-                if (col + 3 < R) a = *reinterpret_cast<const sg_v4*>(src + (long)kk * ld + col);
+                if (VEC && col + 3 < R) a = *reinterpret_cast<const sg_v4*>(src + (long)kk * ld + col);
                 else {
+                    if (col + 3 < R) a.w = src[(long)kk * ld + col + 3];
                     if (col < R) a.x = src[(long)kk * ld + col];
                     if (col + 1 < R) a.y = src[(long)kk * ld + col + 1];
                     if (col + 2 < R) a.z = src[(long)kk * ld + col + 2];
@@ -126,7 +145,7 @@ __global__ __launch_bounds__(512) void split_gemm_kernel(const char* __restrict_
                                                          int KS, int ntm, int ntn, int m_valid,
                                                          const float* __restrict__ bias0, const float* __restrict__ bias1,
                                                          float* __restrict__ out0, float* __restrict__ out1, int n_split,
-                                                         long ld_out) {
+                                                         long ld_out, int n_valid, int accumulate) {
     constexpr int TA = 2 * WM, TB = 8;                   // fragment rows-tiles of A / B per workgroup
     constexpr int STAGE = (TA + TB) * SG_STEP;
     constexpr int PIECES = (TA + TB) * 3;
@@ -170,8 +189,8 @@ __global__ __launch_bounds__(512) void split_gemm_kernel(const char* __restrict_
     float bv[2] = {0.0f, 0.0f};
     if (EPI == SG_EPI_BIAS_RELU) {
         const float* bias = second ? bias1 : bias0;
-        bv[0] = bias[n_base + (lane & 31)];
-        bv[1] = bias[n_base + 32 + (lane & 31)];
+        bv[0] = n_base + (lane & 31) < n_valid ? bias[n_base + (lane & 31)] : 0.0f;
+        bv[1] = n_base + 32 + (lane & 31) < n_valid ? bias[n_base + 32 + (lane & 31)] : 0.0f;
     }
 
     sg_acc acc[WM][2];
@@ -223,10 +242,12 @@ __global__ __launch_bounds__(512) void split_gemm_kernel(const char* __restrict_
 
     // epilogue: accumulator register e of a 32 x 32 tile is row (e & 3) + 8 (e >> 2) + 4 (lane >> 5),
     // column lane & 31.  A tile that lies wholly inside the valid rows stores without per-row tests.
-    const bool whole = (tm * TA + wm * WM + WM) * 32 <= m_valid;
+    // n_valid counts columns of the selected output; accumulate adds to what the output holds
+    const bool whole = (tm * TA + wm * WM + WM) * 32 <= m_valid && n_base + 64 <= n_valid && !accumulate;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        float* col = out + n_base + j * 32 + (lane & 31);
+        const int n = n_base + j * 32 + (lane & 31);
+        float* col = out + n;
 #pragma unroll
         for (int i = 0; i < WM; ++i) {
             const int m0 = (tm * TA + wm * WM + i) * 32 + 4 * (lane >> 5);
@@ -236,7 +257,7 @@ __global__ __launch_bounds__(512) void split_gemm_kernel(const char* __restrict_
                 float v = acc[i][j][e];
                 if (EPI == SG_EPI_BIAS_RELU) v = fmaxf(v + bv[j], 0.0f);
                 if (whole) col[(long)m * ld_out] = v;
-                else if (m < m_valid) col[(long)m * ld_out] = v;
+                else if (m < m_valid && n < n_valid) col[(long)m * ld_out] = accumulate ? col[(long)m * ld_out] + v : v;
             }
         }
     }
@@ -254,36 +275,46 @@ size_t mdnvae_split_operand_bytes(long rows, long k) {
 
 int mdnvae_split_rows(const float* src, long R, long K, long ld, long row_tile0, void* out, void* stream) {
     MV_REQUIRE(R >= 0 && K >= 0 && ld >= K && row_tile0 >= 0, E_ARG, "mdnvae_split_rows: bad shape");
-    MV_REQUIRE(K % 16 == 0 && ld % 4 == 0, E_SHAPE, "mdnvae_split_rows: K must be a multiple of 16 and ld of 4");
     if (R == 0 || K == 0) return 0;
     MV_REQUIRE(src && out, E_ARG, "mdnvae_split_rows: null pointer");
-    MV_REQUIRE(aligned16(src) && aligned16(out), E_ALIGN, "mdnvae_split_rows: operands must be 16-byte aligned");
-    const long rt = (R + 31) / 32, kb = (K + 63) / 64;
+    MV_REQUIRE(aligned16(out), E_ALIGN, "mdnvae_split_rows: the operand must be 16-byte aligned");
+    const long rt = (R + 31) / 32, KS = (K + 15) / 16, kb = (KS * 16 + 63) / 64;
     MV_REQUIRE(rt <= 0x7fffffffL && kb <= 65535, E_SHAPE, "mdnvae_split_rows: shape too large for one launch");
-    hipLaunchKernelGGL(split_rows_kernel, dim3((unsigned)rt, (unsigned)kb), dim3(256), 0, (hipStream_t)stream, src,
-                       (int)R, (int)K, ld, (int)row_tile0, (char*)out);
+    const bool vec = K % 16 == 0 && ld % 4 == 0 && aligned16(src);
+    if (vec)
+        hipLaunchKernelGGL(split_rows_kernel<true>, dim3((unsigned)rt, (unsigned)kb), dim3(256), 0, (hipStream_t)stream, src,
+                           (int)R, (int)K, ld, (int)row_tile0, (int)KS, (char*)out);
+    else
+        hipLaunchKernelGGL(split_rows_kernel<false>, dim3((unsigned)rt, (unsigned)kb), dim3(256), 0, (hipStream_t)stream, src,
+                           (int)R, (int)K, ld, (int)row_tile0, (int)KS, (char*)out);
     MV_LAUNCH_CHECK("split_rows_kernel");
     return 0;
 }
 
 int mdnvae_split_cols(const float* src, long Kd, long R, long ld, long row_tile0, void* out, void* stream) {
     MV_REQUIRE(R >= 0 && Kd >= 0 && ld >= R && row_tile0 >= 0, E_ARG, "mdnvae_split_cols: bad shape");
-    MV_REQUIRE(ld % 4 == 0, E_SHAPE, "mdnvae_split_cols: ld must be a multiple of 4");
     if (R == 0 || Kd == 0) return 0;
     MV_REQUIRE(src && out, E_ARG, "mdnvae_split_cols: null pointer");
-    MV_REQUIRE(aligned16(src) && aligned16(out), E_ALIGN, "mdnvae_split_cols: operands must be 16-byte aligned");
+    MV_REQUIRE(aligned16(out), E_ALIGN, "mdnvae_split_cols: the operand must be 16-byte aligned");
     const long rt = (R + 31) / 32, kb = (Kd + 63) / 64, KS = (Kd + 15) / 16;
     MV_REQUIRE(rt <= 0x7fffffffL && kb <= 65535, E_SHAPE, "mdnvae_split_cols: shape too large for one launch");
-    hipLaunchKernelGGL(split_cols_kernel, dim3((unsigned)rt, (unsigned)kb), dim3(256), 0, (hipStream_t)stream, src,
-                       (int)Kd, (int)R, ld, (int)row_tile0, (int)KS, (char*)out);
+    const bool vec = ld % 4 == 0 && aligned16(src);
+    if (vec)
+        hipLaunchKernelGGL(split_cols_kernel<true>, dim3((unsigned)rt, (unsigned)kb), dim3(256), 0, (hipStream_t)stream, src,
+                           (int)Kd, (int)R, ld, (int)row_tile0, (int)KS, (char*)out);
+    else
+        hipLaunchKernelGGL(split_cols_kernel<false>, dim3((unsigned)rt, (unsigned)kb), dim3(256), 0, (hipStream_t)stream, src,
+                           (int)Kd, (int)R, ld, (int)row_tile0, (int)KS, (char*)out);
     MV_LAUNCH_CHECK("split_cols_kernel");
     return 0;
 }
 
-int mdnvae_split_gemm(const void* a, const void* b, long M, long N, long K, long m_valid, const float* bias0,
-                      const float* bias1, int relu, float* out0, float* out1, long n_split, long ld_out, int tile_m,
-                      void* stream) {
+int mdnvae_split_gemm(const void* a, const void* b, long M, long N, long K, long m_valid, long n_valid,
+                      const float* bias0, const float* bias1, int relu, int accumulate, float* out0, float* out1,
+                      long n_split, long ld_out, int tile_m, void* stream) {
     MV_REQUIRE(M >= 1 && N >= 1 && K >= 16 && m_valid >= 0 && m_valid <= M, E_ARG, "mdnvae_split_gemm: bad shape");
+    MV_REQUIRE(n_valid >= 0 && n_valid <= n_split, E_ARG, "mdnvae_split_gemm: n_valid counts columns of one output (at most n_split)");
+    MV_REQUIRE(!(relu && accumulate), E_ARG, "mdnvae_split_gemm: the bias + ReLU epilogue does not accumulate");
     MV_REQUIRE(tile_m == 256 || tile_m == 128, E_ARG, "mdnvae_split_gemm: tile_m must be 128 or 256");
     MV_REQUIRE(M % tile_m == 0 && N % 256 == 0 && K % 16 == 0, E_SHAPE,
                "mdnvae_split_gemm: M must be a multiple of tile_m, N of 256, K of 16 (pad the split operands)");
@@ -309,7 +340,7 @@ int mdnvae_split_gemm(const void* a, const void* b, long M, long N, long K, long
         }                                                                                                           \
         hipLaunchKernelGGL((split_gemm_kernel<WM, EPI>), dim3((unsigned)(ntm * ntn)), dim3(512), lds, st,           \
                            (const char*)a, (const char*)b, KS, (int)ntm, (int)ntn, (int)m_valid, bias0, bias1,      \
-                           out0, out1 ? out1 : out0, (int)n_split, ld_out);                                         \
+                           out0, out1 ? out1 : out0, (int)n_split, ld_out, (int)n_valid, accumulate);               \
     } while (0)
     if (tile_m == 256) {
         if (relu) SG_LAUNCH(4, SG_EPI_BIAS_RELU);

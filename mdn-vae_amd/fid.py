@@ -263,7 +263,7 @@ def _newton_schulz_f32(y64, d):
         call("mdnvae_split_rows", ptr(src), d, kp, ld, 0, op.data_ptr(), stream())
 
     def product(a_op, b_op, out):                  # out = a . b^T = a . b for the symmetric matrices here
-        call("mdnvae_split_gemm", a_op.data_ptr(), b_op.data_ptr(), ld, ld, kp, d, None, None, 0, ptr(out), None, ld, ld,
+        call("mdnvae_split_gemm", a_op.data_ptr(), b_op.data_ptr(), ld, ld, kp, d, ld, None, None, 0, 0, ptr(out), None, ld, ld,
              256, stream())
 
     prev, last_delta, iters = None, None, 0

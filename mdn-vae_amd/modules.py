@@ -392,6 +392,9 @@ class GCNVAE(nn.Module):
             else:
                 a11 = ops.sym_linear_act(xt, self.fc11.weight, self.fc11.bias, "relu", self.n_nodes)
                 a12 = ops.sym_linear_act(xt, self.fc12.weight, self.fc12.bias, "relu", self.n_nodes)
+        elif (self.first_layer_gemm == "split" and x.dim() == 2 and x.shape[0] >= ops.SPLIT_GEMM_MIN_BATCH
+              and not x.requires_grad):
+            a11, a12 = ops.linear_pair(x, self.fc11.weight, self.fc11.bias, self.fc12.weight, self.fc12.bias)
         else:
             a11, a12 = self.fc11(x, act="relu"), self.fc12(x, act="relu")
         h11 = self.fc111(a11, act="relu")

@@ -407,7 +407,7 @@ class _SymLinearPair(torch.autograd.Function):
         call("mdnvae_split_rows", ptr(xt, "x"), B, T, T, 0, xa.data_ptr(), stream())
         y1 = torch.empty(B, H, dtype=torch.float32, device=dev)
         y2 = torch.empty(B, H, dtype=torch.float32, device=dev)
-        call("mdnvae_split_gemm", xa.data_ptr(), wb.data_ptr(), Mp, 2 * H, T, B, ptr(b1, "bias"), ptr(b2, "bias"), 1,
+        call("mdnvae_split_gemm", xa.data_ptr(), wb.data_ptr(), Mp, 2 * H, T, B, H, ptr(b1, "bias"), ptr(b2, "bias"), 1, 0,
              ptr(y1), ptr(y2), H, H, 256, stream())
         ctx.save_for_backward(xt, y1, y2)
         ctx.n_nodes = n_nodes
@@ -435,8 +435,8 @@ class _SymLinearPair(torch.autograd.Function):
             xb = _split_operand(Tp, Kp, dev)
             call("mdnvae_split_cols", ptr(xt), B, T, T, 0, xb.data_ptr(), stream())
             gts = [torch.empty(T, H, dtype=torch.float32, device=dev) for _ in range(2)]
-            call("mdnvae_split_gemm", xb.data_ptr(), pb.data_ptr(), Tp, 2 * H, Kp, T, None, None, 0, ptr(gts[0]), ptr(gts[1]),
-                 H, H, 128, stream())
+            call("mdnvae_split_gemm", xb.data_ptr(), pb.data_ptr(), Tp, 2 * H, Kp, T, H, None, None, 0, 0, ptr(gts[0]),
+                 ptr(gts[1]), H, H, 128, stream())
             for i, (param, gt) in enumerate(((w1, gts[0]), (w2, gts[1]))):
                 if not ctx.needs_input_grad[1 + 2 * i]:
                     continue
@@ -456,6 +456,77 @@ class _SymLinearPair(torch.autograd.Function):
 
 def sym_linear_pair(x_tri, w1, b1, w2, b2, n_nodes):
     return _SymLinearPair.apply(x_tri, w1, b1, w2, b2, n_nodes)
+
+
+class _LinearPair(torch.autograd.Function):
+    """relu(x W1^T + b1), relu(x W2^T + b2) on all columns of x [B,D] (self.fc11 / self.fc12 of
+    function/MM_Gate.py:157-158 as the reference runs them: no symmetry promise): one split-bf16 product
+    forward, one per weight for the gradients, which land in the parameters' own [H,D] layout (added
+    straight into .grad when a sink is active).  D need not be a multiple of anything: the splitting
+    kernels take the rows as they lie (N*N is odd for the connectomes) and pad k with zeros."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2):
+        x, w1, w2 = _c(x), _c(w1), _c(w2)
+        B, D = x.shape
+        H = w1.shape[0]
+        if w2.shape != w1.shape or w1.shape[1] != D or H % 256 != 0 or b1 is None or b2 is None:
+            raise RuntimeError(f"linear_pair: two [H,{D}] weights with biases, H a multiple of 256 (got {tuple(w1.shape)}, "
+                               f"{tuple(w2.shape)})")
+        dev = x.device
+        Kp = _round_up(D, 16)
+        wb = _split_operand(2 * H, Kp, dev)
+        call("mdnvae_split_rows", ptr(w1, "weight"), H, D, D, 0, wb.data_ptr(), stream())
+        call("mdnvae_split_rows", ptr(w2, "weight"), H, D, D, H // 32, wb.data_ptr(), stream())
+        Mp = _round_up(B, 256)
+        xa = _split_operand(Mp, Kp, dev)
+        call("mdnvae_split_rows", ptr(x, "x"), B, D, D, 0, xa.data_ptr(), stream())
+        y1 = torch.empty(B, H, dtype=torch.float32, device=dev)
+        y2 = torch.empty(B, H, dtype=torch.float32, device=dev)
+        call("mdnvae_split_gemm", xa.data_ptr(), wb.data_ptr(), Mp, 2 * H, Kp, B, H, ptr(b1, "bias"), ptr(b2, "bias"), 1, 0,
+             ptr(y1), ptr(y2), H, H, 256, stream())
+        ctx.save_for_backward(x, y1, y2)
+        ctx.params = (w1, b1, w2, b2)
+        return y1, y2
+
+    @staticmethod
+    def backward(ctx, g1, g2):
+        x, y1, y2 = ctx.saved_tensors
+        w1, b1, w2, b2 = ctx.params
+        B, D = x.shape
+        H, dev = y1.shape[1], x.device
+        gpre = []
+        for y, g in ((y1, g1), (y2, g2)):
+            gp = torch.empty_like(y)
+            call("mdnvae_act_bwd", ptr(y), ptr(_c(g)), ptr(gp), gp.numel(), ACTS["relu"], stream())
+            gpre.append(gp)
+        gws = [None, None]
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[3]:
+            Kp, Np = _round_up(B, 16), _round_up(D, 256)
+            xb = _split_operand(Np, Kp, dev)
+            tail = (D + 31) // 32 * (Kp // 16) * 3072          # operand row tiles past D: zero (their columns are not stored)
+            xb[tail:].zero_()
+            call("mdnvae_split_cols", ptr(x), B, D, D, 0, xb.data_ptr(), stream())
+            pb = _split_operand(H, Kp, dev)
+            for i, (param, gp) in enumerate(((w1, gpre[0]), (w2, gpre[1]))):
+                if not ctx.needs_input_grad[1 + 2 * i]:
+                    continue
+                call("mdnvae_split_cols", ptr(gp), B, H, H, 0, pb.data_ptr(), stream())
+                target = _grad_target(param)
+                out = target if target is not None else torch.empty(H, D, dtype=torch.float32, device=dev)
+                call("mdnvae_split_gemm", pb.data_ptr(), xb.data_ptr(), H, Np, Kp, H, D, None, None, 0, int(target is not None),
+                     ptr(out), None, Np, D, 128, stream())
+                if target is not None:
+                    _grad_added(param)
+                else:
+                    gws[i] = out
+        gb1 = _bias_grad(gpre[0], b1) if ctx.needs_input_grad[2] else None
+        gb2 = _bias_grad(gpre[1], b2) if ctx.needs_input_grad[4] else None
+        return None, gws[0], gb1, gws[1], gb2
+
+
+def linear_pair(x, w1, b1, w2, b2):
+    return _LinearPair.apply(x, w1, b1, w2, b2)
 
 
 class _AddAct(torch.autograd.Function):

@@ -55,8 +55,8 @@ def test_split_product_against_float64(Mrows, N, K, tile):
         half = N // 2 if (N // 2) % 256 == 0 else N
         out0 = torch.full((Mrows, half), float("nan"), device=DEV)
         out1 = torch.full((Mrows, N - half), float("nan"), device=DEV) if half < N else None
-        call("mdnvae_split_gemm", oa.data_ptr(), ob.data_ptr(), Mp, N, Kp, Mrows, None, None, 0, ptr(out0), ptr(out1), half,
-             half, tile, stream())
+        call("mdnvae_split_gemm", oa.data_ptr(), ob.data_ptr(), Mp, N, Kp, Mrows, half, None, None, 0, 0, ptr(out0), ptr(out1),
+             half, half, tile, stream())
         got = torch.cat([out0] + ([out1] if out1 is not None else []), dim=1).double().cpu()
         assert torch.isfinite(got).all()
         assert float(((got - want).abs() / mag).max()) <= 1e-6, how        # fp32-accumulation level, entry by entry
@@ -65,8 +65,8 @@ def test_split_product_against_float64(Mrows, N, K, tile):
     bd_ = bias.to(DEV)
     out0 = torch.empty(Mrows, half, device=DEV)
     out1 = torch.empty(Mrows, N - half, device=DEV) if half < N else None
-    call("mdnvae_split_gemm", oa.data_ptr(), ob.data_ptr(), Mp, N, Kp, Mrows, ptr(bd_[:half].contiguous()),
-         ptr(bd_[half:].contiguous()) if half < N else None, 1, ptr(out0), ptr(out1), half, half, tile, stream())
+    call("mdnvae_split_gemm", oa.data_ptr(), ob.data_ptr(), Mp, N, Kp, Mrows, half, ptr(bd_[:half].contiguous()),
+         ptr(bd_[half:].contiguous()) if half < N else None, 1, 0, ptr(out0), ptr(out1), half, half, tile, stream())
     got = torch.cat([out0] + ([out1] if out1 is not None else []), dim=1).double().cpu()
     want_r = torch.relu(want + bias.double())
     assert float((got - want_r).abs().max() / want_r.abs().max()) <= 1e-5
@@ -106,3 +106,72 @@ def test_first_layer_pair_against_float64_and_the_library_path(B, n):
         err_lib = float((l_.double().cpu() - w_).abs().max() / w_.abs().max())
         assert err <= bar, (name, err)
         assert err <= max(4 * err_lib, 1e-6), (name, err, err_lib)      # no worse than the fp32 library GEMM
+
+
+@pytest.mark.parametrize("Mrows,N,K", [(300, 333, 77), (513, 7569, 1000)])
+def test_split_product_of_unaligned_tensors(Mrows, N, K):
+    """Operands straight from tensors whose rows are neither 16-byte aligned nor a multiple of 16 long
+    (the [B, N*N] connectomes with N*N odd), a ragged column count in the output, and accumulation."""
+    g = torch.Generator().manual_seed(Mrows + N)
+    a = torch.randn(Mrows, K, generator=g)
+    b = torch.randn(N, K, generator=g) * 0.05
+    want = a.double() @ b.double().t()
+    ad, bd = a.to(DEV), b.to(DEV)
+    Kp, Mp, Np = _up(K, 16), _up(Mrows, 128), _up(N, 256)
+    oa, ob = _operand(Mp, Kp), torch.zeros(int(_lib.load().mdnvae_split_operand_bytes(Np, Kp)), dtype=torch.uint8, device=DEV)
+    call("mdnvae_split_rows", ptr(ad), Mrows, K, K, 0, oa.data_ptr(), stream())
+    call("mdnvae_split_rows", ptr(bd), N, K, K, 0, ob.data_ptr(), stream())
+    base = torch.randn(Mrows, N, generator=g)
+    out = base.to(DEV)
+    call("mdnvae_split_gemm", oa.data_ptr(), ob.data_ptr(), Mp, Np, Kp, Mrows, N, None, None, 0, 1, ptr(out), None, Np, N, 128,
+         stream())
+    got = out.double().cpu() - base.double()
+    assert float((got - want).abs().max() / want.abs().max()) <= 1e-5
+    # the column-split form of the same tensors: operand rows = columns of the [K, rows] transposes
+    at, bt = ad.t().contiguous(), bd.t().contiguous()            # [K, Mrows], [K, N]: row strides 300 / 333 floats
+    oa2 = torch.zeros_like(oa)
+    ob2 = torch.zeros_like(ob)
+    call("mdnvae_split_cols", ptr(at), K, Mrows, Mrows, 0, oa2.data_ptr(), stream())
+    call("mdnvae_split_cols", ptr(bt), K, N, N, 0, ob2.data_ptr(), stream())
+    out2 = torch.full((Mrows, N), float("nan"), device=DEV)
+    call("mdnvae_split_gemm", oa2.data_ptr(), ob2.data_ptr(), Mp, Np, Kp, Mrows, N, None, None, 0, 0, ptr(out2), None, Np, N, 128,
+         stream())
+    assert float((out2.double().cpu() - want).abs().max() / want.abs().max()) <= 1e-5
+
+
+@pytest.mark.parametrize("B,n", [(1024, 68), (1100, 87)])
+def test_full_first_layer_pair_against_float64_and_the_library_path(B, n):
+    """ops.linear_pair: both first layers on all N*N inputs (no symmetry promise) as one split product."""
+    torch.manual_seed(B)
+    H, D = 1024, n * n
+    x = torch.rand(B, D, device=DEV) * (torch.rand(B, D, device=DEV) < 0.3)
+    w = [(torch.randn(H, D) / D ** 0.5).to(DEV).requires_grad_(True) for _ in range(2)]
+    b = [(torch.randn(H) * 0.05).to(DEV).requires_grad_(True) for _ in range(2)]
+    up = [torch.randn(B, H, device=DEV) * (torch.rand(B, H, device=DEV) < 0.5) for _ in range(2)]
+    y = ops.linear_pair(x, w[0], b[0], w[1], b[1])
+    torch.autograd.backward(list(y), up)
+    got = [t.detach().clone() for t in y] + [t.grad.clone() for t in w + b]
+    for t in w + b:
+        t.grad = None
+    y_lib = [ops.linear_act(x, w[i], b[i], "relu") for i in range(2)]
+    torch.autograd.backward(y_lib, up)
+    lib = [t.detach() for t in y_lib] + [t.grad for t in w + b]
+    # float64 reference with the ReLU gate taken from the device's own forward values: a pre-activation
+    # within rounding of zero may land on either side, and one flipped gate moves a gradient entry by a
+    # whole term (checked: the gates differ only where the float64 pre-activation is below 1e-5)
+    x64 = x.double().cpu()
+    w64 = [t.detach().double().cpu() for t in w]
+    b64 = [t.detach().double().cpu() for t in b]
+    pre64 = [x64 @ w64[i].t() + b64[i] for i in range(2)]
+    gate = [(got[i].cpu() > 0) for i in range(2)]
+    for i in range(2):
+        flipped = gate[i] != (pre64[i] > 0)
+        assert float(pre64[i][flipped].abs().max()) < 1e-5 if flipped.any() else True
+    gpre64 = [up[i].double().cpu() * gate[i] for i in range(2)]
+    want = [torch.relu(p_) for p_ in pre64] + [gpre64[i].t() @ x64 for i in range(2)] + [gpre64[i].sum(0) for i in range(2)]
+    for name, g_, l_, w_ in zip(["y1", "y2", "gw1", "gw2", "gb1", "gb2"], got, lib, want):
+        bar = 1e-5 if name.startswith("y") else 1e-4
+        err = float((g_.double().cpu() - w_).abs().max() / w_.abs().max())
+        err_lib = float((l_.double().cpu() - w_).abs().max() / w_.abs().max())
+        assert err <= bar, (name, err)
+        assert err <= max(4 * err_lib, 1e-6), (name, err, err_lib)
