@@ -18,6 +18,7 @@ import mdnvae_amd as M
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 B, STEPS = 48, 2
+B_SPLIT = 2048          # 1024 subjects per rank: the first layers take the split-bf16 product
 
 
 def _free_port():
@@ -26,7 +27,15 @@ def _free_port():
         return s.getsockname()[1]
 
 
+def _batch(kind):
+    return B_SPLIT if kind == "mdn_split" else B
+
+
 def _setup(kind):
+    split = kind == "mdn_split"
+    if split:
+        kind = "mdn"
+    B = _batch("mdn_split" if split else kind)
     fix = load_fixture("mm_gate")
     params = fixture_params(fix)
     adjacency = [list(map(int, r)) for r in fix["adjacency"]]
@@ -48,6 +57,7 @@ def _setup(kind):
 
 def _train(kind, lo, hi, **trainer_kw):
     model, adjacency, x, eps, traits = _setup(kind)
+    kind = "mdn" if kind == "mdn_split" else kind
     trainer = M.Trainer(model, "mdn" if kind == "mdn" else "poisson_log", **trainer_kw)
     losses = []
     for s in range(STEPS):
@@ -64,7 +74,7 @@ def _worker(rank, world, port, kind, overlap, out):
     os.environ["MASTER_PORT"] = str(port)
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    lo, hi = M.data.shard_range(B, rank, world)
+    lo, hi = M.data.shard_range(_batch(kind), rank, world)
     losses, params, trainer = _train(kind, lo, hi, **({} if overlap else {"overlap_floats": 0}))
     assert bool(trainer._hook_of) == overlap
     assert all(a >= trainer._fold_end for a, _ in trainer._rest)      # unfolded first-layer gradients never travel
@@ -72,12 +82,12 @@ def _worker(rank, world, port, kind, overlap, out):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("kind,overlap", [("mdn", True), ("mdn", False), ("mm", True)])
+@pytest.mark.parametrize("kind,overlap", [("mdn", True), ("mdn", False), ("mm", True), ("mdn_split", True)])
 def test_two_ranks_on_one_gpu_take_the_single_process_step(kind, overlap):
     world = 2
     out = mp.Manager().dict()
     mp.spawn(_worker, args=(world, _free_port(), kind, overlap, out), nprocs=world, join=True)
-    want_losses, want, _ = _train(kind, 0, B)
+    want_losses, want, _ = _train(kind, 0, _batch(kind))
     for s in range(STEPS):                                   # sum-reduced loss: the shards' losses add up
         got = out[0][0][s] + out[1][0][s]
         assert abs(got - want_losses[s]) <= 1e-5 * abs(want_losses[s])
