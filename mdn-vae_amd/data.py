@@ -33,6 +33,64 @@ def prepare_connectomes(raw, mode, crop=CORTICAL_CROP, offset=200.0):
     return out
 
 
+def load_mat_connectomes(path, key=None, channel=0, shape=(87, 87), device="cuda"):
+    """Raw connectomes [subjects, n, n] fp32 on `device` from one of the reference's MATLAB files,
+    ready for prepare_connectomes (host side: scipy's reader, one copy to the device).
+
+    Two layouts occur.  A dense array `[n, n, channels, subjects]` or `[n, n, subjects]`
+    (`loaded_tensor_sub` of HCP_subcortical_CMData_desikan.mat, function/VAE_CNN_NN.py:16-33, which
+    takes channel 0 for the networks and channel 1 for the group mean).  A 1 x S cell array of per-
+    subject matrices, some of another size, of which only those of `shape` are kept (`all_fc` /
+    `all_sc` of desikan_fc_all.mat / desikan_sc_all.mat, function_FC/VAE_CNN_GCN.py:21-28;
+    function_FC_SC/SC-FC.py:20-33 keeps a subject only if BOTH files hold a matrix of that shape - use
+    load_mat_pairs for that).  `key`: the variable name; default = the only non-private variable."""
+    arr = _mat_variable(path, key)
+    mats = _subject_stack(arr, channel, shape)
+    return torch.from_numpy(mats).to(device)
+
+
+def load_mat_pairs(path_a, path_b, key_a=None, key_b=None, shape=(87, 87), device="cuda"):
+    """Two cell-array files read side by side: subject i is kept only when both hold a matrix of
+    `shape` for it (function_FC_SC/SC-FC.py:26-33).  Returns the two stacks [subjects, n, n]."""
+    a, b = _mat_variable(path_a, key_a), _mat_variable(path_b, key_b)
+    if a.dtype != object or b.dtype != object:
+        raise ValueError("load_mat_pairs expects the cell-array layout in both files")
+    ca, cb = a.reshape(-1), b.reshape(-1)
+    keep = [i for i in range(min(len(ca), len(cb)))
+            if getattr(ca[i], "shape", None) == tuple(shape) and getattr(cb[i], "shape", None) == tuple(shape)]
+    if not keep:
+        raise ValueError(f"no subject has {shape} matrices in both files")
+    sa = np.stack([np.asarray(ca[i], dtype=np.float32) for i in keep])
+    sb = np.stack([np.asarray(cb[i], dtype=np.float32) for i in keep])
+    return torch.from_numpy(sa).to(device), torch.from_numpy(sb).to(device)
+
+
+def _mat_variable(path, key):
+    from scipy.io import loadmat
+    mat = loadmat(path)
+    names = [k for k in mat if not k.startswith("__")]
+    if key is None:
+        if len(names) != 1:
+            raise ValueError(f"{path} holds {names}: say which with key=")
+        key = names[0]
+    if key not in mat:
+        raise KeyError(f"{path} has no variable {key!r} (it holds {names})")
+    return mat[key]
+
+
+def _subject_stack(arr, channel, shape):
+    if arr.dtype == object:                       # cell array of per-subject matrices
+        cells = [np.asarray(m, dtype=np.float32) for m in arr.reshape(-1) if getattr(m, "shape", None) == tuple(shape)]
+        if not cells:
+            raise ValueError(f"no {shape} matrix among the {arr.size} cells")
+        return np.stack(cells)
+    if arr.ndim == 4:                             # [n, n, channels, subjects]
+        arr = arr[:, :, channel, :]
+    if arr.ndim != 3 or arr.shape[0] != arr.shape[1]:
+        raise ValueError(f"expected [n, n, (channels,) subjects], got {arr.shape}")
+    return np.ascontiguousarray(np.moveaxis(arr, -1, 0), dtype=np.float32)
+
+
 def prepare_sc(raw, offset=200.0, crop=CORTICAL_CROP):
     return prepare_connectomes(raw, "divide", crop, offset)
 
