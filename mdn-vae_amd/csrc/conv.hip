@@ -1139,7 +1139,8 @@ struct WgradBf16 {
     int G8;        // 8-pixel groups per output row (OW padded)
     int rows;      // input rows per chunk = (nr - 1) * S + 3
     int gunits;    // 16-byte units per grad_out channel in LDS (odd)
-    int sunits;    // 16-byte units per input channel in LDS (odd): rows x S planes x (G8 + 1)
+    int sunits;    // 16-byte units per input channel in LDS (odd): rows x ru
+    int ru;        // 16-byte units per staged input row: S planes x (G8 + 1), plus one where that keeps row strides odd
     int spg;       // samples per z group
 };
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -1160,7 +1161,11 @@ __device__ __forceinline__ bf16x8 frag_shift(u32x4 p0, unsigned nxt) {
     return __builtin_bit_cast(bf16x8, o);
 }
 
-template <int S, int PARTS>
+// RW > 0: the stride-1 reflect-pad-1 layers whose planes are RW x RW (the residual blocks: 22 at N = 87, 17 at
+// N = 68) stage whole rows per thread - RW loads (8 bytes each when RW is even), and the padded row of 32
+// positions (reflected border columns, zeros behind) is assembled at compile-time register indices, so staging
+// costs a handful of instructions per element instead of an index computation per element.
+template <int S, int PARTS, int RW>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(WgradBf16 p, const float* __restrict__ x,
                                                                   const float* __restrict__ stats,
                                                                   const float* __restrict__ gout,
@@ -1179,9 +1184,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(WgradBf16 p, co
     const int npc = (p.OH + p.nr - 1) / p.nr;
     const int nchunks = (b_end - b_begin) * npc;
     const long in_plane = (long)p.H * p.W, out_plane = (long)p.OH * p.OW;
-    const int RU = S * (p.G8 + 1);                       // units per staged input row
+    const int RU = p.ru;                                 // units per staged input row
     const unsigned m_g8 = magic_of(p.G8), m_gch = magic_of(p.nr * p.G8), m_sch = magic_of(p.rows * RU), m_ru = magic_of(RU),
-                   m_g9 = magic_of(p.G8 + 1);
+                   m_g9 = magic_of(p.G8 + 1), m_rows = magic_of(p.rows), m_nr = magic_of(p.nr);
 
     f32x16 acc[9];
 #pragma unroll
@@ -1193,6 +1198,73 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(WgradBf16 p, co
     for (int ci = 0; ci < nchunks; ++ci) {
         const int b = b_begin + ci / npc, a0 = (ci % npc) * p.nr;
         __syncthreads();                                 // the previous chunk's operand reads are done
+        if constexpr (RW > 0) {
+            static_assert(S == 1 && RW >= 8 && RW <= 24, "row staging: stride 1, planes of 8..24 columns");
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            auto load_row = [&](const float* src, float (&v)[RW]) {
+                if (RW % 2 == 0) {                       // rows of an even plane start 8-byte aligned
+#pragma unroll
+                    for (int j = 0; j < RW / 2; ++j) {
+                        const f32x2 t = *reinterpret_cast<const f32x2*>(src + 2 * j);
+                        v[2 * j] = t.x;
+                        v[2 * j + 1] = t.y;
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < RW; ++j) v[j] = src[j];
+                }
+            };
+            auto store_units = [&](const float (&pr)[32], int nunits, char* dst, int part_stride) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (u >= nunits) break;
+                    bf16x8 o[PARTS];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        __bf16 bp[PARTS];
+                        bf_split<PARTS>(pr[8 * u + j], bp);
+#pragma unroll
+                        for (int pt = 0; pt < PARTS; ++pt) o[pt][j] = bp[pt];
+                    }
+#pragma unroll
+                    for (int pt = 0; pt < PARTS; ++pt) *reinterpret_cast<bf16x8*>(dst + pt * part_stride + u * 16) = o[pt];
+                }
+            };
+            for (int it = tid; it < 64 * p.nr; it += 256) {          // grad_out rows: (n, output row)
+                const int n = p.nr == 1 ? it : fdiv(it, m_nr), r = it - n * p.nr;      // (the magic of 1 does not exist)
+                const bool ok = n0 + n < p.Cout && a0 + r < p.OH;
+                float v[RW], pr[32];
+                load_row(gout + ((long)b * p.Cout + (ok ? n0 + n : 0)) * out_plane + (long)(ok ? a0 + r : 0) * RW, v);
+#pragma unroll
+                for (int j = 0; j < 32; ++j) pr[j] = (j < RW && ok) ? v[j < RW ? j : 0] : 0.0f;
+                store_units(pr, p.G8, gl + (n * p.gunits + r * p.G8) * 16, gpart);
+            }
+            for (int it = tid; it < 64 * p.rows; it += 256) {        // input rows: (c, input row), reflected
+                const int c = fdiv(it, m_rows), r = it - c * p.rows;
+                int vy = a0 + r - 1;
+                vy = vy < 0 ? -vy : (vy >= RW ? 2 * (RW - 1) - vy : vy);
+                const bool rok = c0 + c < p.Cin && vy >= 0;           // rows far past the plane pair with zero grad_out only
+                const long pl = (long)b * p.Cin + (rok ? c0 + c : 0);
+                float v[RW], pr[32];
+                load_row(x + pl * in_plane + (long)(rok ? vy : 0) * RW, v);
+                if (stats) {
+                    const float mean = stats[2 * pl], rstd = stats[2 * pl + 1];
+#pragma unroll
+                    for (int j = 0; j < RW; ++j) v[j] = (v[j] - mean) * rstd;
+                }
+                if (p.relu_in) {
+#pragma unroll
+                    for (int j = 0; j < RW; ++j) v[j] = fmaxf(v[j], 0.0f);
+                }
+#pragma unroll
+                for (int j = 0; j < 32; ++j) {
+                    // padded column j holds x[reflect(j - 1)]; past column RW + 1 nothing
+                    const int sx = j == 0 ? 1 : (j <= RW ? j - 1 : (j == RW + 1 ? RW - 2 : -1));
+                    pr[j] = (sx >= 0 && rok) ? v[sx >= 0 ? sx : 0] : 0.0f;
+                }
+                store_units(pr, p.G8 + 1, slab + (c * p.sunits + r * RU) * 16, spart);
+            }
+        } else {
         // Staging runs U items at a time: their 8 loads each are all issued (unconditionally, clamped into the
         // plane, the value dropped where there is no pixel) before the first is converted.
         constexpr int U = 4;
@@ -1275,6 +1347,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(WgradBf16 p, co
 #pragma unroll
                 for (int pt = 0; pt < PARTS; ++pt) *reinterpret_cast<bf16x8*>(slab + pt * spart + dst[u]) = o[pt];
             }
+        }
         }
         __syncthreads();
         const char* ga = gl + (wn * 32 + l32) * p.gunits * 16;
@@ -1904,12 +1977,12 @@ int mdnvae_conv2d_wgrad(const float* x, const float* in_stats, int relu_in, cons
 
 }  // extern "C"
 
-template <int S, int PARTS>
+template <int S, int PARTS, int RW>
 static void launch_wgrad_bf16(const WgradBf16& p, dim3 grid, size_t lds, const float* x, const float* stats,
                               const float* grad_out, float* workspace, hipStream_t st) {
     static bool once = false;
-    if (!once) { set_attr_once(reinterpret_cast<const void*>(conv_wgrad_bf16_kernel<S, PARTS>)); once = true; }
-    hipLaunchKernelGGL((conv_wgrad_bf16_kernel<S, PARTS>), grid, dim3(256), lds, st, p, x, stats, grad_out, workspace);
+    if (!once) { set_attr_once(reinterpret_cast<const void*>(conv_wgrad_bf16_kernel<S, PARTS, RW>)); once = true; }
+    hipLaunchKernelGGL((conv_wgrad_bf16_kernel<S, PARTS, RW>), grid, dim3(256), lds, st, p, x, stats, grad_out, workspace);
 }
 
 extern "C" int mdnvae_conv2d_wgrad_bf16(const float* x, const float* in_stats, int relu_in, const float* grad_out,
@@ -1929,9 +2002,12 @@ extern "C" int mdnvae_conv2d_wgrad_bf16(const float* x, const float* in_stats, i
     p.reflect = reflect; p.relu_in = relu_in;
     p.G8 = (OW + 7) / 8;
     // the largest chunk of output rows whose tiles leave room for two workgroups
+    // whole-row staging for the square stride-1 reflect layers of the residual blocks
+    const int rw = (stride == 1 && reflect && H == W && (W == 22 || W == 17)) ? W : 0;
+    p.ru = stride * (p.G8 + 1) + (rw ? 1 : 0);
     auto lds_of = [&](int nr) {
         const int rows = (nr - 1) * stride + 3;
-        return (size_t)parts * 64 * (((nr * p.G8) | 1) + ((rows * stride * (p.G8 + 1)) | 1)) * 16;
+        return (size_t)parts * 64 * (((nr * p.G8) | 1) + ((rows * p.ru) | 1)) * 16;
     };
     int best = 0;
     for (size_t cap : {(size_t)78 * 1024, (size_t)156 * 1024}) {      // room for two workgroups per CU, else for one
@@ -1947,7 +2023,7 @@ extern "C" int mdnvae_conv2d_wgrad_bf16(const float* x, const float* in_stats, i
     p.nr = best;
     p.rows = (best - 1) * stride + 3;
     p.gunits = (best * p.G8) | 1;
-    p.sunits = (p.rows * stride * (p.G8 + 1)) | 1;
+    p.sunits = (p.rows * p.ru) | 1;
     const size_t lds = lds_of(best);
     const int ntiles = ((Cout + 63) / 64) * ((Cin + 63) / 64);
     const int Gz0 = wgrad_groups(B, ntiles);
@@ -1955,15 +2031,17 @@ extern "C" int mdnvae_conv2d_wgrad_bf16(const float* x, const float* in_stats, i
     const int Gz = (B + p.spg - 1) / p.spg;
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((Cout + 63) / 64, (Cin + 63) / 64, Gz);
-    if (stride == 1) {
-        if (parts == 1) launch_wgrad_bf16<1, 1>(p, grid, lds, x, in_stats, grad_out, workspace, st);
-        else if (parts == 2) launch_wgrad_bf16<1, 2>(p, grid, lds, x, in_stats, grad_out, workspace, st);
-        else launch_wgrad_bf16<1, 3>(p, grid, lds, x, in_stats, grad_out, workspace, st);
-    } else {
-        if (parts == 1) launch_wgrad_bf16<2, 1>(p, grid, lds, x, in_stats, grad_out, workspace, st);
-        else if (parts == 2) launch_wgrad_bf16<2, 2>(p, grid, lds, x, in_stats, grad_out, workspace, st);
-        else launch_wgrad_bf16<2, 3>(p, grid, lds, x, in_stats, grad_out, workspace, st);
-    }
+#define MV_WG(S_, RW_)                                                                                  \
+    do {                                                                                                \
+        if (parts == 1) launch_wgrad_bf16<S_, 1, RW_>(p, grid, lds, x, in_stats, grad_out, workspace, st);      \
+        else if (parts == 2) launch_wgrad_bf16<S_, 2, RW_>(p, grid, lds, x, in_stats, grad_out, workspace, st); \
+        else launch_wgrad_bf16<S_, 3, RW_>(p, grid, lds, x, in_stats, grad_out, workspace, st);                 \
+    } while (0)
+    if (rw == 22) MV_WG(1, 22);
+    else if (rw == 17) MV_WG(1, 17);
+    else if (stride == 1) MV_WG(1, 0);
+    else MV_WG(2, 0);
+#undef MV_WG
     MV_LAUNCH_CHECK("conv_wgrad_bf16_kernel");
     const long total = 9L * Cout * Cin;
     hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, workspace, Gz, 9,
