@@ -185,8 +185,9 @@ int mdnvae_mul(const float* a, const float* b, float* y, long n, void* stream);
 
 /* ---- companions of the library GEMMs for plain dense layers ----------------------------
  * (FNN towers function/MM_Gate.py:157-162; cVAE function_FC_SC/SC-FC.py:95-113; latent heads
- * function/VAE_CNN_NN.py:160-161; dense intercept :187).  The matrix products themselves are
- * rocBLAS calls made by the host; these kernels do the rest of F.linear + activation. */
+ * function/VAE_CNN_NN.py:160-161; dense intercept :187).  The matrix products of the small layers are
+ * rocBLAS calls made by the host (large ones take mdnvae_split_gemm below); these kernels do the rest of
+ * F.linear + activation. */
 /* y[r,c] = act(y[r,c] + bias[c]) in place (bias may be NULL). */
 int mdnvae_bias_act(float* y, const float* bias, long rows, int cols, int act, void* stream);
 /* y = act(a + b): the residual joins of function_fc_new/ResNet.py:101-107,150-153 */
@@ -245,12 +246,13 @@ int mdnvae_tri_unfold(const float* g, long H, int N, long stride_t, long stride_
  * Split operands are opaque buffers of mdnvae_split_operand_bytes(rows, k) bytes holding an operand
  * [rows][k] (rows padded to a multiple of 32, k to a multiple of 16) in MFMA-fragment tiles. */
 size_t mdnvae_split_operand_bytes(long rows, long k);
-/* operand[row_tile0 * 32 + r][c] = src[r][c] for src [R][ld] fp32, c < K (K a multiple of 16). */
+/* operand[row_tile0 * 32 + r][c] = src[r][c] for src [R][ld] fp32, c < K (any K <= ld: the operand's k
+ * extent is K rounded up to 16, zero filled; rows of any alignment). */
 int mdnvae_split_rows(const float* src, long R, long K, long ld, long row_tile0, void* out, void* stream);
 /* operand[row_tile0 * 32 + c][r] = src[r][c] for src [Kd][ld] fp32, c < R: the transposed operand (of
  * k extent Kd rounded up to 16, zero filled) that a weight-gradient product takes. */
 int mdnvae_split_cols(const float* src, long Kd, long R, long ld, long row_tile0, void* out, void* stream);
-/* out[m][n] = sum_k a[m][k] b[n][k] (+ bias[n], ReLU when relu != 0) for m < m_valid: columns
+/* out[m][n] = sum_k a[m][k] b[n][k] (+ bias[n] when biases are given, then ReLU when relu != 0) for m < m_valid: columns
  * n < n_split go to out0 (bias0), the others to out1 (bias1) at column n - n_split; row stride ld_out.
  * M a multiple of tile_m (128 or 256), N and n_split multiples of 256, K of 16.  Only rows < m_valid and, of
  * each output, columns < n_valid are stored; accumulate = 1 adds to what the output holds (no ReLU then). */

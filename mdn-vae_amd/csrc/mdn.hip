@@ -535,7 +535,7 @@ __global__ __launch_bounds__(MDN_NT) void mdn_outer_kernel(const float* __restri
 // the sweep every per-component quantity is uniform over the wave (sums by DPP, no LDS), so the
 // log-sum-exp over the components is plain arithmetic.
 #ifndef MS_AHEAD_N
-#define MS_AHEAD_N 4
+#define MS_AHEAD_N 6
 #endif
 #ifndef MS_RING_N
 #define MS_RING_N 8

@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256) void split_cols_kernel(const float* __restrict
 #define SG_GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 #define SG_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 
-enum { SG_EPI_BIAS_RELU = 0, SG_EPI_PLAIN = 1 };
+enum { SG_EPI_BIAS_RELU = 0, SG_EPI_PLAIN = 1, SG_EPI_BIAS = 2 };
 
 template <int WM, int EPI>
 __global__ __launch_bounds__(512) void split_gemm_kernel(const char* __restrict__ A, const char* __restrict__ Bop,
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(512) void split_gemm_kernel(const char* __restrict_
     float* out = second ? out1 : out0;
     const int n_base = n_tile0 - (second ? n_split : 0);
     float bv[2] = {0.0f, 0.0f};
-    if (EPI == SG_EPI_BIAS_RELU) {
+    if (EPI != SG_EPI_PLAIN) {
         const float* bias = second ? bias1 : bias0;
         bv[0] = n_base + (lane & 31) < n_valid ? bias[n_base + (lane & 31)] : 0.0f;
         bv[1] = n_base + 32 + (lane & 31) < n_valid ? bias[n_base + 32 + (lane & 31)] : 0.0f;
@@ -256,6 +256,7 @@ __global__ __launch_bounds__(512) void split_gemm_kernel(const char* __restrict_
                 const int m = m0 + (e & 3) + 8 * (e >> 2);
                 float v = acc[i][j][e];
                 if (EPI == SG_EPI_BIAS_RELU) v = fmaxf(v + bv[j], 0.0f);
+                if (EPI == SG_EPI_BIAS) v += bv[j];
                 if (whole) col[(long)m * ld_out] = v;
                 else if (m < m_valid && n < n_valid) col[(long)m * ld_out] = accumulate ? col[(long)m * ld_out] + v : v;
             }
@@ -322,6 +323,9 @@ int mdnvae_split_gemm(const void* a, const void* b, long M, long N, long K, long
                "mdnvae_split_gemm: n_split must be a multiple of 256 within N");
     MV_REQUIRE(a && b && out0 && (n_split == N || out1), E_ARG, "mdnvae_split_gemm: null pointer");
     MV_REQUIRE(!relu || (bias0 && (n_split == N || bias1)), E_ARG, "mdnvae_split_gemm: the bias + ReLU epilogue needs biases");
+    MV_REQUIRE(!bias0 || n_split == N || bias1, E_ARG, "mdnvae_split_gemm: two outputs with a bias need both biases");
+    MV_REQUIRE(!(bias0 && accumulate), E_ARG, "mdnvae_split_gemm: a bias epilogue does not accumulate");
+    const bool bias_only = bias0 && !relu;
     MV_REQUIRE(aligned16(a) && aligned16(b), E_ALIGN, "mdnvae_split_gemm: operands must be 16-byte aligned");
     const long ntm = M / tile_m, ntn = N / 256;
     MV_REQUIRE(ntm * ntn <= 0x7fffffffL, E_SHAPE, "mdnvae_split_gemm: too many tiles");
@@ -344,9 +348,11 @@ int mdnvae_split_gemm(const void* a, const void* b, long M, long N, long K, long
     } while (0)
     if (tile_m == 256) {
         if (relu) SG_LAUNCH(4, SG_EPI_BIAS_RELU);
+        else if (bias_only) SG_LAUNCH(4, SG_EPI_BIAS);
         else SG_LAUNCH(4, SG_EPI_PLAIN);
     } else {
         if (relu) SG_LAUNCH(2, SG_EPI_BIAS_RELU);
+        else if (bias_only) SG_LAUNCH(2, SG_EPI_BIAS);
         else SG_LAUNCH(2, SG_EPI_PLAIN);
     }
 #undef SG_LAUNCH

@@ -249,9 +249,80 @@ def _narrow_wgrad(gpre, x, weight_param, bias_param, want_w, want_b):
     return (gw if want_w else None), gb
 
 
+SPLIT_LINEAR_MIN_OUTPUTS = 6_000_000     # B * n_out from which the split product has enough 128 x 256 tiles for the chip
+
+
+def _split_linear_ok(x, weight, bias):
+    """Large dense layers (the N*N x N*N intercept of function/VAE_CNN_NN.py:187 at batch 1024, the
+    cVAE layers of function_FC_SC/SC-FC.py:95-113 at large batches) run on the hand-written split-bf16
+    product: fp32 accuracy, bf16 matrix cores."""
+    return (SPLIT_LINEAR and x.dim() == 2 and bias is not None and x.shape[0] >= SPLIT_GEMM_MIN_BATCH
+            and weight.shape[1] >= 256 and x.shape[0] * weight.shape[0] >= SPLIT_LINEAR_MIN_OUTPUTS)
+
+
+SPLIT_LINEAR = True
+
+
+def _split_linear_fwd(x, weight, bias, act):
+    B, K = x.shape
+    n_out = weight.shape[0]
+    dev = x.device
+    Kp, Mp, Np = _round_up(K, 16), _round_up(B, 128), _round_up(n_out, 256)
+    wb = _split_operand(Np, Kp, dev)
+    wb[(n_out + 31) // 32 * (Kp // 16) * 3072:].zero_()
+    call("mdnvae_split_rows", ptr(weight, "weight"), n_out, K, K, 0, wb.data_ptr(), stream())
+    xa = _split_operand(Mp, Kp, dev)
+    call("mdnvae_split_rows", ptr(x, "x"), B, K, K, 0, xa.data_ptr(), stream())
+    y = torch.empty(B, n_out, dtype=torch.float32, device=dev)
+    call("mdnvae_split_gemm", xa.data_ptr(), wb.data_ptr(), Mp, Np, Kp, B, n_out, ptr(bias, "bias"), None,
+         int(act == ACTS["relu"]), 0, ptr(y), None, Np, n_out, 128, stream())
+    if act not in (ACTS[None], ACTS["relu"]):
+        call("mdnvae_bias_act", ptr(y), None, B, n_out, act, stream())
+    return y
+
+
+def _split_linear_dgrad(gpre, weight):
+    """gx [B, n_in] = gpre [B, n_out] . weight [n_out, n_in]"""
+    B, n_out = gpre.shape
+    n_in = weight.shape[1]
+    dev = gpre.device
+    Kp, Mp, Np = _round_up(n_out, 16), _round_up(B, 128), _round_up(n_in, 256)
+    ga = _split_operand(Mp, Kp, dev)
+    call("mdnvae_split_rows", ptr(gpre, "grad_pre"), B, n_out, n_out, 0, ga.data_ptr(), stream())
+    wb = _split_operand(Np, Kp, dev)
+    wb[(n_in + 31) // 32 * (Kp // 16) * 3072:].zero_()
+    call("mdnvae_split_cols", ptr(weight, "weight"), n_out, n_in, n_in, 0, wb.data_ptr(), stream())
+    gx = torch.empty(B, n_in, dtype=torch.float32, device=dev)
+    call("mdnvae_split_gemm", ga.data_ptr(), wb.data_ptr(), Mp, Np, Kp, B, n_in, None, None, 0, 0, ptr(gx), None, Np, n_in, 128,
+         stream())
+    return gx
+
+
+def _split_linear_wgrad(gpre, x, param):
+    """grad_w [n_out, n_in] = gpre^T . x; None when it was added straight into param.grad"""
+    B, n_out = gpre.shape
+    n_in = x.shape[1]
+    dev = x.device
+    Kp, Mp, Np = _round_up(B, 16), _round_up(n_out, 128), _round_up(n_in, 256)
+    pa = _split_operand(Mp, Kp, dev)
+    pa[(n_out + 31) // 32 * (Kp // 16) * 3072:].zero_()
+    call("mdnvae_split_cols", ptr(gpre, "grad_pre"), B, n_out, n_out, 0, pa.data_ptr(), stream())
+    xb = _split_operand(Np, Kp, dev)
+    xb[(n_in + 31) // 32 * (Kp // 16) * 3072:].zero_()
+    call("mdnvae_split_cols", ptr(x, "x"), B, n_in, n_in, 0, xb.data_ptr(), stream())
+    target = _grad_target(param)
+    out = target if target is not None else torch.empty(n_out, n_in, dtype=torch.float32, device=dev)
+    call("mdnvae_split_gemm", pa.data_ptr(), xb.data_ptr(), Mp, Np, Kp, n_out, n_in, None, None, 0, int(target is not None),
+         ptr(out), None, Np, n_in, 128, stream())
+    if target is not None:
+        _grad_added(param)
+        return None
+    return out
+
+
 class _LinearAct(torch.autograd.Function):
-    """act(x @ W^T + b): the product is a rocBLAS GEMM, bias+activation and the backward's
-    elementwise / column-sum parts are HIP kernels."""
+    """act(x @ W^T + b): the product is a rocBLAS GEMM - or, for large layers, the split-bf16 product -
+    bias+activation and the backward's elementwise / column-sum parts are HIP kernels."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, act):
@@ -261,6 +332,8 @@ class _LinearAct(torch.autograd.Function):
             y = torch.empty(x.shape[0], weight.shape[0], dtype=torch.float32, device=x.device)
             call("mdnvae_narrow_linear_fwd", ptr(x), ptr(weight), ptr(bias, "bias"), x.shape[0], weight.shape[0],
                  weight.shape[1], act, ptr(y), stream())
+        elif _split_linear_ok(x, weight, bias):
+            y = _split_linear_fwd(x, weight, bias, act)
         else:
             y = _library_linear(x, weight.t(), bias, act)
         ctx.save_for_backward(x, weight, y)
@@ -278,14 +351,20 @@ class _LinearAct(torch.autograd.Function):
             call("mdnvae_act_bwd", ptr(y), ptr(gy), ptr(gpre), gy.numel(), ctx.act, stream())
         else:
             gpre = gy
-        gx = _library_gemm(gpre, weight) if ctx.needs_input_grad[0] else None
+        split = ctx.has_bias and _split_linear_ok(x, weight, ctx.params[1])
+        if ctx.needs_input_grad[0]:
+            gx = _split_linear_dgrad(_c(gpre), weight) if split else _library_gemm(gpre, weight)
+        else:
+            gx = None
         if _narrow(weight) and x.shape[0] >= 1 and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]):
             gw, gb = _narrow_wgrad(_c(gpre), x, ctx.params[0], ctx.params[1], ctx.needs_input_grad[1],
                                    ctx.has_bias and ctx.needs_input_grad[2])
             return gx, gw, gb, None
         gw = None
         if ctx.needs_input_grad[1]:
-            if _small_wgrad_ok(x.shape[0], weight.shape[0], weight.shape[1]):
+            if split:
+                gw = _split_linear_wgrad(_c(gpre), x, ctx.params[0])
+            elif _small_wgrad_ok(x.shape[0], weight.shape[0], weight.shape[1]):
                 target = _grad_target(ctx.params[0])
                 if target is not None:
                     _linear_wgrad(_c(gpre), x, into=target)

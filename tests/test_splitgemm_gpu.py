@@ -175,3 +175,42 @@ def test_full_first_layer_pair_against_float64_and_the_library_path(B, n):
         err_lib = float((l_.double().cpu() - w_).abs().max() / w_.abs().max())
         assert err <= bar, (name, err)
         assert err <= max(4 * err_lib, 1e-6), (name, err, err_lib)
+
+
+@pytest.mark.parametrize("act", [None, "sigmoid", "relu"])
+def test_large_dense_layer_on_the_split_product(act):
+    """ops.linear_act sends a layer with B * n_out >= 6e6 through the split product (the N*N x N*N
+    intercept of function/VAE_CNN_NN.py:187 at batch 1024; the cVAE layers at large batches): forward,
+    data gradient and weight gradient against float64 at the fp32 bars, odd sizes on purpose."""
+    torch.manual_seed(3)
+    B, n_in, n_out = 1024, 4624, 6101
+    assert B * n_out >= ops.SPLIT_LINEAR_MIN_OUTPUTS
+    x = (torch.randn(B, n_in) * 0.5).to(DEV).requires_grad_(True)
+    w = (torch.randn(n_out, n_in) / n_in ** 0.5).to(DEV).requires_grad_(True)
+    b = (torch.randn(n_out) * 0.1).to(DEV).requires_grad_(True)
+    up = torch.randn(B, n_out, device=DEV)
+    calls = []
+    orig = ops.call
+
+    def spy(name, *a):
+        calls.append(name)
+        return orig(name, *a)
+
+    ops.call = spy
+    try:
+        y = ops.linear_act(x, w, b, act)
+        y.backward(up)
+    finally:
+        ops.call = orig
+    assert calls.count("mdnvae_split_gemm") == 3                       # forward, data gradient, weight gradient
+    x64, w64, b64 = (t.detach().double().cpu() for t in (x, w, b))
+    pre = x64 @ w64.t() + b64
+    want = {None: pre, "sigmoid": torch.sigmoid(pre), "relu": torch.relu(pre)}[act]
+    yd = y.detach().double().cpu()
+    slope = {None: torch.ones_like(pre), "sigmoid": yd * (1 - yd), "relu": (yd > 0).double()}[act]
+    gpre = up.double().cpu() * slope                                   # through the device's own outputs (ReLU gates)
+    checks = [("y", yd, want, 1e-5), ("gx", x.grad, gpre @ w64, 1e-4), ("gw", w.grad, gpre.t() @ x64, 1e-4),
+              ("gb", b.grad, gpre.sum(0), 1e-4)]
+    for name, got, ref, bar in checks:
+        err = float((got.double().cpu() - ref).abs().max() / ref.abs().max())
+        assert err <= bar, (name, err)
