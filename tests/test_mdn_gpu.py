@@ -271,7 +271,7 @@ def test_mdn_trainer_streams_a_target_that_is_the_verified_symmetric_input(monke
 
 
 def test_mixture_model_on_the_reference_traits_and_subjects():
-    """BASELINE config 2 on the reference's own data: the 100 structural connectomes of
+    """The trait-gated mixture model on the reference's own data: the 100 structural connectomes of
     data/HCP_samples.mat conditioned on data/trait.pt (tests/golden/traits.npz).  The mixture head is
     build-defined (the reference never loads trait.pt), so the expected values are the build's own
     float64 statement: loss 1e-5, gradients 1e-4, for the plain and the symmetric-input model; then
