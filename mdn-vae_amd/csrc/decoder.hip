@@ -18,6 +18,8 @@
 // tile, walks it backwards, and emits per-layer (input activation, pre-activation gradient)
 // rows; the weight/bias gradients are then [K x B].[B x N] library GEMMs over those rows.
 #include "common.h"
+#include <cstdlib>
+#include <type_traits>
 #include "../../include/mdnvae_hip.h"
 
 namespace mdnvae {
@@ -35,9 +37,24 @@ constexpr int ACT_NONE = 0, ACT_SIGMOID = 1, ACT_TANH = 2;
 __device__ __forceinline__ float sigmoid_fast(float v) {
     return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v));
 }
+// tanh without a branch: (1 - e) / (1 + e), e = exp(-2|v|), where the difference keeps its digits, and
+// the odd series through v^9 below |v| = 1/4 (its first dropped term is 8e-9 of the value there)
+__device__ __forceinline__ float tanh_fast(float v) {
+    const float t = fabsf(v), e = __builtin_amdgcn_exp2f(-2.8853900817779268f * t);
+    const float big = copysignf((1.0f - e) * __builtin_amdgcn_rcpf(1.0f + e), v);
+    const float q = v * v;
+    const float small = v * (1.0f + q * (-0.33333333333f + q * (0.13333333333f + q * (-0.05396825397f + q * 0.02186948854f))));
+    return t < 0.25f ? small : big;
+}
+template <int ACT>
+__device__ __forceinline__ float act_of(float v) {
+    if (ACT == ACT_SIGMOID) return sigmoid_fast(v);
+    if (ACT == ACT_TANH) return tanh_fast(v);
+    return v;
+}
 __device__ __forceinline__ float act_apply(int a, float v) {
     if (a == ACT_SIGMOID) return sigmoid_fast(v);
-    if (a == ACT_TANH) return tanhf(v);
+    if (a == ACT_TANH) return tanh_fast(v);
     return v;
 }
 // derivative expressed through the activation's output h
@@ -345,6 +362,182 @@ __global__ __launch_bounds__(CH_NT, 2) void chain_fwd_mfma_kernel(DecArgs a, con
                 if (b0 + sr < a.B) xlat[(long)(b0 + sr) * N + n] = xl[j];
             }
         }
+    }
+}
+
+// Forward for large batches: every wave owns 16 samples through all channels and layers, so activations
+// never cross waves - a layer's output goes through a wave-private LDS tile back into the wave's own
+// A-operand registers (v_mfma_f32_16x16x4_f32: 16 rows x 4 k per instruction), and no barrier orders
+// activations at all.  What the four waves of a workgroup share is the layer's 96 x 96 panel, read-only:
+// it arrives by LDS-DMA in the layout it has in memory, one step ahead into the other of two buffers,
+// and the single barrier per step is for that copy alone.  Each wave runs 144 MFMAs per step for its
+// 16 x 96 outputs with the A operand in 24 registers.  (The 32-sample form above splits a layer's columns
+// over three waves, needs every wave's output before the next layer starts, and leaves two of the four
+// SIMDs with twice the work.)
+constexpr int CR_ROWS = 16;                 // samples per wave
+constexpr int CR_WAVES = 4;
+constexpr int CR_TS = CR_ROWS * CR_WAVES;   // samples per workgroup
+constexpr int CR_LD = 100;                  // row stride of the private tile: 16-byte rows, conflict-free column reads
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void chain_fwd_rows_kernel(DecArgs a, const float* __restrict__ z,
+                                                             const float* __restrict__ wt,
+                                                             const float* __restrict__ drop, float* __restrict__ nodes,
+                                                             float* __restrict__ xlat, float* __restrict__ hin) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int PANEL = KP * NP;                       // floats
+    static_assert(PANEL % (256 * 4) == 0, "the panel is copied in whole 16-byte pieces per thread");
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int c16 = lane & 15, g = lane >> 4;            // MFMA lane coordinates: row / column 0..15, k group 0..3
+    float* priv = smem + 2 * PANEL + wave * CR_ROWS * CR_LD;
+    const int N = a.N, steps = a.R * a.NL;
+    const int ntiles = (a.B + CR_TS - 1) / CR_TS;
+    auto panel_dma = [&](int s, int buf) {
+        const float* src = wt + (long)s * PANEL;
+#pragma unroll
+        for (int i = 0; i < PANEL / (256 * 4); ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (i * 256 + t) * 4),
+                                             (__attribute__((address_space(3))) void*)(smem + buf * PANEL + (i * 256 + wave * 64) * 4),
+                                             16, 0, 0);
+    };
+    if ((int)blockIdx.x >= ntiles) return;
+    panel_dma(0, 0);
+    int buf = 0;
+    constexpr int PER = CR_ROWS * KP / 64;               // 24 elements of a 16 x 96 tile per lane
+    constexpr int QPL = CR_ROWS * KP / 4 / 64;           // 6 16-byte pieces of its rows per lane
+    // rows of the private tile to memory, 16 bytes per lane and 384 contiguous bytes per row
+    auto store_rows = [&](float* dst, long row_stride, int b0) {
+        f32x4_t v[QPL];
+#pragma unroll
+        for (int i = 0; i < QPL; ++i) {
+            const int chunk = i * 64 + lane, r = chunk / (KP / 4), c4 = chunk - r * (KP / 4);
+            v[i] = *reinterpret_cast<const f32x4_t*>(priv + r * CR_LD + 4 * c4);
+        }
+#pragma unroll
+        for (int i = 0; i < QPL; ++i) {
+            const int chunk = i * 64 + lane, r = chunk / (KP / 4), c4 = chunk - r * (KP / 4);
+            if (b0 + r < a.B) *reinterpret_cast<f32x4_t*>(dst + (long)(b0 + r) * row_stride + 4 * c4) = v[i];
+        }
+    };
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int b0 = tile * CR_TS + wave * CR_ROWS;
+        // the latent rows with the ones column and zero padding, kept for all channels.  Every load is
+        // issued before the first value is used (clamped addresses, the value dropped where there is
+        // none): one load at a time costs a memory round trip per element
+        float zl[PER];
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int idx = i * 64 + lane, r = idx / KP, k = idx - r * KP;
+            const bool ok = k < a.L && b0 + r < a.B;
+            const float t = z[(long)(ok ? b0 + r : 0) * a.L + (ok ? k : 0)];
+            zl[i] = k == KP - 1 ? 1.0f : (ok ? t : 0.0f);
+        }
+        float xl[6][4];
+#pragma unroll
+        for (int ct = 0; ct < 6; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) xl[ct][r] = 0.0f;
+        for (int s = 0; s < steps; ++s, buf ^= 1) {
+            const int r_ch = s / a.NL, l = s - r_ch * a.NL;
+            __syncthreads();                             // this step's panel has landed; the other buffer is free
+            const bool more = s + 1 < steps || tile + (int)gridDim.x < ntiles;
+            if (more) panel_dma(s + 1 < steps ? s + 1 : 0, buf ^ 1);
+            __builtin_amdgcn_wave_barrier();
+            if (l == 0) {
+                // the tile holds the previous channel's node vectors: out they go, in come the latent rows
+                if (s > 0) store_rows(nodes + (long)(r_ch - 1) * NP, (long)a.R * NP, b0);
+#pragma unroll
+                for (int i = 0; i < PER; ++i) {
+                    const int idx = i * 64 + lane, r = idx / KP, k = idx - r * KP;
+                    priv[r * CR_LD + k] = zl[i];
+                }
+            }
+            // this layer's input rows: the A operand, and (training) the saved copy for the backward pass
+            float af[KP / 4];
+#pragma unroll
+            for (int kk = 0; kk < KP / 4; ++kk) af[kk] = priv[c16 * CR_LD + 4 * kk + g];
+            if (hin) store_rows(hin + (long)s * a.B * KP, KP, b0);
+            const float* pan = smem + buf * PANEL;
+            f32x4_t acc[6];
+#pragma unroll
+            for (int ct = 0; ct < 6; ++ct) acc[ct] = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
+            // B values of four k steps (24 registers) are read one block ahead of the 24 MFMAs that use them:
+            // left to itself the compiler reads two values, waits for LDS, issues two MFMAs, and so on
+            float bv[2][24];
+            auto load_b = [&](int kq, float (&b)[24]) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int ct = 0; ct < 6; ++ct) b[e * 6 + ct] = pan[(4 * (4 * kq + e) + g) * NP + ct * 16 + c16];
+            };
+            load_b(0, bv[0]);
+#pragma unroll
+            for (int kq = 0; kq < KP / 16; ++kq) {
+                if (kq + 1 < KP / 16) load_b(kq + 1, bv[(kq + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int ct = 0; ct < 6; ++ct)
+                        acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[4 * kq + e], bv[kq & 1][e * 6 + ct], acc[ct], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __builtin_amdgcn_wave_barrier();
+            // the layer's output into the private tile, as the next layer's input rows or as the node
+            // vectors on their way out; the activation is chosen once per step, outside the element loop
+            const bool last = l == a.NL - 1;
+            auto epilogue = [&](auto act_tag) {
+                constexpr int ACT = decltype(act_tag)::value;
+#pragma unroll
+                for (int ct = 0; ct < 6; ++ct) {
+                    const int n = ct * 16 + c16;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float v = act_of<ACT>(acc[ct][r]);
+                        v = n < N ? v : 0.0f;
+                        if (!last && n == KP - 1) v = 1.0f;
+                        acc[ct][r] = v;
+                    }
+                }
+            };
+            switch (layer_act(a.acts, l)) {
+                case ACT_SIGMOID: epilogue(std::integral_constant<int, ACT_SIGMOID>{}); break;
+                case ACT_TANH: epilogue(std::integral_constant<int, ACT_TANH>{}); break;
+                default: epilogue(std::integral_constant<int, ACT_NONE>{}); break;
+            }
+            if (last && drop) {
+#pragma unroll
+                for (int ct = 0; ct < 6; ++ct)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int n = ct * 16 + c16, row = 4 * g + r;
+                        const bool ok = n < N && b0 + row < a.B;
+                        const float d = drop[ok ? ((long)r_ch * a.B + b0 + row) * N + n : 0];
+                        acc[ct][r] *= ok ? d : 1.0f;
+                    }
+            }
+            if (last && r_ch < a.xlat_r) {
+#pragma unroll
+                for (int ct = 0; ct < 6; ++ct)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) xl[ct][r] += acc[ct][r];
+            }
+#pragma unroll
+            for (int ct = 0; ct < 6; ++ct)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) priv[(4 * g + r) * CR_LD + ct * 16 + c16] = acc[ct][r];
+            __builtin_amdgcn_wave_barrier();
+        }
+        store_rows(nodes + (long)(a.R - 1) * NP, (long)a.R * NP, b0);
+        if (xlat) {
+#pragma unroll
+            for (int ct = 0; ct < 6; ++ct) {
+                const int n = ct * 16 + c16;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (n < N && b0 + 4 * g + r < a.B) xlat[(long)(b0 + 4 * g + r) * N + n] = xl[ct][r];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -944,11 +1137,28 @@ int mdnvae_decoder_fwd(const float* z, const float* wt, int B, int N, int L, int
         MV_REQUIRE(e == hipSuccess, (int)e, "mdnvae_decoder_fwd: cannot raise the LDS limit: %s", hipGetErrorString(e));
         fwd_attr_set = true;
     }
-    // x_latent sums channels inside one workgroup, so the channel split is for decoders without it
-    const unsigned ysplit = (ntiles <= 128 && xlat_channels == 0) ? (unsigned)R : 1u;
-    hipLaunchKernelGGL(chain_fwd_mfma_kernel, dim3(ntiles < 2048 ? ntiles : 2048, ysplit), dim3(CH_NT), fwd_lds,
-                       (hipStream_t)stream, a, z, wt, drop, nodes, xlat_channels ? xlat : nullptr, layer_in);
-    MV_LAUNCH_CHECK("chain_fwd_mfma_kernel");
+    static const bool rows_off = getenv("MDNVAE_CHAIN_ROWS_OFF") != nullptr;       // tuning knob
+    if (B >= CR_TS * 128 && !rows_off) {
+        // enough 64-sample tiles for half the chip and more: the wave-per-16-samples form
+        static bool rows_attr_set = false;
+        if (!rows_attr_set) {
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(chain_fwd_rows_kernel),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            MV_REQUIRE(e == hipSuccess, (int)e, "mdnvae_decoder_fwd: cannot raise the LDS limit: %s", hipGetErrorString(e));
+            rows_attr_set = true;
+        }
+        const int rtiles = (B + CR_TS - 1) / CR_TS;
+        const size_t lds = sizeof(float) * ((size_t)2 * KP * NP + (size_t)CR_WAVES * CR_ROWS * CR_LD);
+        hipLaunchKernelGGL(chain_fwd_rows_kernel, dim3(rtiles < 1024 ? rtiles : 1024), dim3(256), lds, (hipStream_t)stream, a, z,
+                           wt, drop, nodes, xlat_channels ? xlat : nullptr, layer_in);
+        MV_LAUNCH_CHECK("chain_fwd_rows_kernel");
+    } else {
+        // x_latent sums channels inside one workgroup, so the channel split is for decoders without it
+        const unsigned ysplit = (ntiles <= 128 && xlat_channels == 0) ? (unsigned)R : 1u;
+        hipLaunchKernelGGL(chain_fwd_mfma_kernel, dim3(ntiles < 2048 ? ntiles : 2048, ysplit), dim3(CH_NT), fwd_lds,
+                           (hipStream_t)stream, a, z, wt, drop, nodes, xlat_channels ? xlat : nullptr, layer_in);
+        MV_LAUNCH_CHECK("chain_fwd_mfma_kernel");
+    }
     if (!out) return 0;                               // the caller consumes the node vectors itself
     hipLaunchKernelGGL(outer_epilogue_kernel, dim3(wave_grid(components ? (long)B * R : B)), dim3(256), 0,
                        (hipStream_t)stream, a, nodes, icpt_w, icpt_b, (unsigned)(0x100000000ull / (unsigned)N) + 1u, out);

@@ -292,3 +292,32 @@ def test_mm_gate_trainer_fused_and_plain_steps_agree():
         assert abs(loss.item() - float(fix["loss"])) <= LOSS_RTOL * abs(float(fix["loss"]))
         _check_named_grads(fix, model)
     assert _rel(got[True][1], got[False][1]) <= 1e-4
+
+
+@pytest.mark.parametrize("n_nodes", [68, 87])
+def test_large_batch_chain_forward_matches_the_small_batch_kernel(n_nodes):
+    """From 8192 samples up the chain decoder's forward runs as one wave per 16 samples (no barrier between
+    layers); below, as 32-sample tiles with the columns split over three waves.  The same decoder on the same
+    latent rows must give the same node vectors through both - and the same gradients, which the backward
+    pass forms from the layer inputs the forward saved."""
+    torch.manual_seed(n_nodes)
+    B = 8192 + 37
+    dec = M.MultiChannelGCNDecoder(R=5, n_nodes=n_nodes, k=32, n_layers=3, latent_dim=68).to(DEV)
+    adjacency = [[(u + 3 * j) % n_nodes for j in range(32)] for u in range(n_nodes)]
+    z = torch.randn(B, 68, device=DEV)
+    cot = torch.randn(B, 5, 96, device=DEV)
+
+    def run(lo, hi):
+        zz = z[lo:hi].clone().requires_grad_(True)
+        for p in dec.parameters():
+            p.grad = None
+        nodes = dec.node_vectors(zz, adjacency)
+        (nodes * cot[lo:hi]).sum().backward()
+        return nodes.detach(), zz.grad.detach(), [p.grad.detach().clone() for p in dec.parameters()]
+
+    half = B // 2
+    big, lo, hi = run(0, B), run(0, half), run(half, B)
+    assert _rel(big[0], torch.cat([lo[0], hi[0]])) <= OUT_RTOL
+    assert _rel(big[1], torch.cat([lo[1], hi[1]])) <= GRAD_RTOL
+    for gb, gl, gh in zip(big[2], lo[2], hi[2]):          # parameter gradients: the halves add up to the whole
+        assert _rel(gb, gl + gh) <= GRAD_RTOL
