@@ -187,6 +187,8 @@ def _mdn_outer_work(a):
     return 4.0 * B * (N * N + 2 * K * ops.DEC_NP + 4 * L + 4 * K)
 
 
+CHAIN_ROWS_MIN_B = 8192       # from this batch size the chain decoder runs its wave-per-16-samples kernels
+
 # C-ABI entry point -> (tag = the kernel(s) it launches, possibly depending on the arguments; work of one call)
 ABI_TAGS = {
     "mdnvae_vae_loss_fwdbwd": ("loss_stream_kernel", lambda a: 4.0 * a[3] * (3 * a[4] + 4 * a[7])),
@@ -197,9 +199,11 @@ ABI_TAGS = {
     "mdnvae_outer_loss_fwdbwd": ("outer_loss_kernel",
                                  lambda a: 4.0 * a[3] * (a[5] * a[5] + 2 * a[4] * ops.DEC_NP + 4 * a[8])),
     "mdnvae_decoder_fwd": (lambda a: "chain_fwd_mfma_kernel+outer_epilogue_kernel" if a[15] is not None
-                           else "chain_fwd_mfma_kernel", lambda a: _decoder_work(a, 0)),
+                           else ("chain_fwd_rows_kernel" if a[2] >= CHAIN_ROWS_MIN_B else "chain_fwd_mfma_kernel"),
+                           lambda a: _decoder_work(a, 0)),
     "mdnvae_decoder_bwd": (lambda a: "outer_grad_kernel+chain_bwd_mfma_kernel" if a[16] is not None
-                           else ("chain_bwd_saved_kernel" if a[-3] else "chain_bwd_mfma_kernel"),
+                           else (("chain_bwd_rows_kernel" if a[3] >= CHAIN_ROWS_MIN_B else "chain_bwd_saved_kernel")
+                                 if a[-3] else "chain_bwd_mfma_kernel"),
                            lambda a: _decoder_work(a, 1)),
     "mdnvae_adam_step": ("adam_kernel", lambda a: 28.0 * a[4]),
     # (param, grad_t, m_t, v_t, H, N, ...): the weight in and out, the folded gradient in, both folded moments in and out
@@ -220,11 +224,14 @@ ABI_TAGS.update({
 })
 HBM_TAGS |= {"split_rows_kernel", "split_cols_kernel", "act_bwd_kernel", "tri_pack_kernel<fold>"}
 # bf16 matrix-core work: (a, b, M, N, K, m_valid, ...) executes six bf16 MFMA products per fp32 multiply-add
-BF16_TAGS = {"split_gemm_kernel", "conv_bf16_kernel", "conv_wgrad_bf16_kernel"}
+BF16_TAGS = {"split_gemm_kernel", "split_gemm_kernel<3 terms>", "conv_bf16_kernel", "conv_wgrad_bf16_kernel"}
 # kernels that reach fp32 accuracy with several bf16 products per multiply: rated in fp32-equivalent
 # flops against the bf16 peak divided by their number of products
 SPLIT_PRODUCTS = {"conv_bf16x2_kernel": 3, "conv_bf16x3_kernel": 6, "conv_wgrad_bf16x2_kernel": 3, "conv_wgrad_bf16x3_kernel": 6}
-ABI_TAGS["mdnvae_split_gemm"] = ("split_gemm_kernel", lambda a: 12.0 * a[5] * min(a[3], a[6] * (a[3] // a[13])) * a[4])
+# (a, b, M, N, K, m_valid, n_valid, ..., n_split at 13, ld_out, tile_m, terms at 16): bf16 matrix-core flops executed,
+# 2 * terms per fp32 multiply-add; the three-term form (weight gradients) is rated as a kernel of its own
+ABI_TAGS["mdnvae_split_gemm"] = (lambda a: "split_gemm_kernel" if a[16] == 6 else "split_gemm_kernel<3 terms>",
+                                 lambda a: 2.0 * a[16] * a[5] * min(a[3], a[6] * (a[3] // a[13])) * a[4])
 # matrix-core entry points with a fixed tag (work in flops; kept out of HBM_TAGS)
 ABI_TAGS.update({
     # (layer_in, layer_dpre, B, count, ...): one 96 x 96 x B product per (channel, layer)
@@ -502,7 +509,10 @@ def main():
                        # that shortcut is full_first_layer_value
                        "symmetric_first_layer": bool(args.model in ("mm_gate", "mdn_gate") and not args.full_first_layer),
                        "first_layer_gemm": "split-bf16 MFMA (fp32-accurate), hand-written"
-                       if args.model in ("mm_gate", "mdn_gate") else "library fp32"},
+                       if args.model in ("mm_gate", "mdn_gate") else "library fp32",
+                       # bf16 products per multiply-add: 6 in the forward product; the weight gradient's count
+                       # (3 = error about 1e-5 of the gradient's norm, bar 1e-4; MDNVAE_SPLIT_WGRAD_TERMS=6 for all)
+                       "first_layer_wgrad_terms": ops.SPLIT_WGRAD_TERMS},
         }
         kernels = kernel_table(clock, clocked) if clocked else {}
         if kernels:

@@ -255,10 +255,13 @@ int mdnvae_split_cols(const float* src, long Kd, long R, long ld, long row_tile0
 /* out[m][n] = sum_k a[m][k] b[n][k] (+ bias[n] when biases are given, then ReLU when relu != 0) for m < m_valid: columns
  * n < n_split go to out0 (bias0), the others to out1 (bias1) at column n - n_split; row stride ld_out.
  * M a multiple of tile_m (128 or 256), N and n_split multiples of 256, K of 16.  Only rows < m_valid and, of
- * each output, columns < n_valid are stored; accumulate = 1 adds to what the output holds (no ReLU then). */
+ * each output, columns < n_valid are stored; accumulate = 1 adds to what the output holds (no ReLU then).
+ * terms = 6: all six bf16 products of the three-part operands (error 2^-24 of |a||b|, one fp32 rounding);
+ * terms = 3: a1 b1 + a1 b2 + a2 b1 only (error up to 3 * 2^-16 per product, for weight gradients, which
+ * nothing downstream amplifies), at half the matrix-core work. */
 int mdnvae_split_gemm(const void* a, const void* b, long M, long N, long K, long m_valid, long n_valid,
                       const float* bias0, const float* bias1, int relu, int accumulate, float* out0, float* out1,
-                      long n_split, long ld_out, int tile_m, void* stream);
+                      long n_split, long ld_out, int tile_m, int terms, void* stream);
 
 /* ---- conv / ResNet encoder ---------------------------------------------------------------
  * The ATen conv2d / instance_norm / relu / max_pool2d calls (and their autograd) of the encoder

@@ -379,45 +379,82 @@ constexpr int CR_WAVES = 4;
 constexpr int CR_TS = CR_ROWS * CR_WAVES;   // samples per workgroup
 constexpr int CR_LD = 100;                  // row stride of the private tile: 16-byte rows, conflict-free column reads
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
+constexpr int CR_PANEL = KP * NP;                        // floats of one layer's panel
+constexpr int CR_PER = CR_ROWS * KP / 64;                // 24 elements of a 16 x 96 tile per lane
+constexpr int CR_QPL = CR_ROWS * KP / 4 / 64;            // 6 16-byte pieces of its rows per lane
+static_assert(CR_PANEL % (256 * 4) == 0, "the panel is copied in whole 16-byte pieces per thread");
+
+// one panel, global memory -> LDS in the layout it has in memory, by all 256 threads of the workgroup
+__device__ __forceinline__ void rows_panel_dma(const float* __restrict__ src, float* dst) {
+    const int t = threadIdx.x, wave = t >> 6;
+#pragma unroll
+    for (int i = 0; i < CR_PANEL / (256 * 4); ++i)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (i * 256 + t) * 4),
+                                         (__attribute__((address_space(3))) void*)(dst + (i * 256 + wave * 64) * 4), 16, 0, 0);
+}
+
+// rows of a wave's private tile to memory, 16 bytes per lane and 384 contiguous bytes per row
+__device__ __forceinline__ void rows_store(const float* priv, float* __restrict__ dst, long row_stride, int b0, int B,
+                                           int lane) {
+    f32x4_t v[CR_QPL];
+#pragma unroll
+    for (int i = 0; i < CR_QPL; ++i) {
+        const int chunk = i * 64 + lane, r = chunk / (KP / 4), c4 = chunk - r * (KP / 4);
+        v[i] = *reinterpret_cast<const f32x4_t*>(priv + r * CR_LD + 4 * c4);
+    }
+#pragma unroll
+    for (int i = 0; i < CR_QPL; ++i) {
+        const int chunk = i * 64 + lane, r = chunk / (KP / 4), c4 = chunk - r * (KP / 4);
+        if (b0 + r < B) *reinterpret_cast<f32x4_t*>(dst + (long)(b0 + r) * row_stride + 4 * c4) = v[i];
+    }
+}
+
+// acc[ct][r] = sum_k tile[4g + r][k] * pan[k][16 ct + c16]: the tile's rows are the A operand (24 registers),
+// the panel's values are read four k steps (24 registers) ahead of the 24 MFMAs that use them - left to
+// itself the compiler reads two values, waits for LDS, issues two MFMAs, and so on
+__device__ __forceinline__ void rows_product(const float* priv, const float* pan, int c16, int g, f32x4_t (&acc)[6]) {
+    float af[KP / 4];
+#pragma unroll
+    for (int kk = 0; kk < KP / 4; ++kk) af[kk] = priv[c16 * CR_LD + 4 * kk + g];
+#pragma unroll
+    for (int ct = 0; ct < 6; ++ct) acc[ct] = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
+    float bv[2][24];
+    auto load_b = [&](int kq, float (&b)[24]) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int ct = 0; ct < 6; ++ct) b[e * 6 + ct] = pan[(4 * (4 * kq + e) + g) * NP + ct * 16 + c16];
+    };
+    load_b(0, bv[0]);
+#pragma unroll
+    for (int kq = 0; kq < KP / 16; ++kq) {
+        if (kq + 1 < KP / 16) load_b(kq + 1, bv[(kq + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int ct = 0; ct < 6; ++ct)
+                acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[4 * kq + e], bv[kq & 1][e * 6 + ct], acc[ct], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 __global__ __launch_bounds__(256) void chain_fwd_rows_kernel(DecArgs a, const float* __restrict__ z,
                                                              const float* __restrict__ wt,
                                                              const float* __restrict__ drop, float* __restrict__ nodes,
                                                              float* __restrict__ xlat, float* __restrict__ hin) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int PANEL = KP * NP;                       // floats
-    static_assert(PANEL % (256 * 4) == 0, "the panel is copied in whole 16-byte pieces per thread");
+    constexpr int PANEL = CR_PANEL, PER = CR_PER;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int c16 = lane & 15, g = lane >> 4;            // MFMA lane coordinates: row / column 0..15, k group 0..3
     float* priv = smem + 2 * PANEL + wave * CR_ROWS * CR_LD;
     const int N = a.N, steps = a.R * a.NL;
     const int ntiles = (a.B + CR_TS - 1) / CR_TS;
-    auto panel_dma = [&](int s, int buf) {
-        const float* src = wt + (long)s * PANEL;
-#pragma unroll
-        for (int i = 0; i < PANEL / (256 * 4); ++i)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (i * 256 + t) * 4),
-                                             (__attribute__((address_space(3))) void*)(smem + buf * PANEL + (i * 256 + wave * 64) * 4),
-                                             16, 0, 0);
-    };
+    auto panel_dma = [&](int s, int buf) { rows_panel_dma(wt + (long)s * PANEL, smem + buf * PANEL); };
     if ((int)blockIdx.x >= ntiles) return;
     panel_dma(0, 0);
     int buf = 0;
-    constexpr int PER = CR_ROWS * KP / 64;               // 24 elements of a 16 x 96 tile per lane
-    constexpr int QPL = CR_ROWS * KP / 4 / 64;           // 6 16-byte pieces of its rows per lane
-    // rows of the private tile to memory, 16 bytes per lane and 384 contiguous bytes per row
-    auto store_rows = [&](float* dst, long row_stride, int b0) {
-        f32x4_t v[QPL];
-#pragma unroll
-        for (int i = 0; i < QPL; ++i) {
-            const int chunk = i * 64 + lane, r = chunk / (KP / 4), c4 = chunk - r * (KP / 4);
-            v[i] = *reinterpret_cast<const f32x4_t*>(priv + r * CR_LD + 4 * c4);
-        }
-#pragma unroll
-        for (int i = 0; i < QPL; ++i) {
-            const int chunk = i * 64 + lane, r = chunk / (KP / 4), c4 = chunk - r * (KP / 4);
-            if (b0 + r < a.B) *reinterpret_cast<f32x4_t*>(dst + (long)(b0 + r) * row_stride + 4 * c4) = v[i];
-        }
-    };
+    auto store_rows = [&](float* dst, long row_stride, int b0) { rows_store(priv, dst, row_stride, b0, a.B, lane); };
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int b0 = tile * CR_TS + wave * CR_ROWS;
         // the latent rows with the ones column and zero padding, kept for all channels.  Every load is
@@ -451,36 +488,10 @@ __global__ __launch_bounds__(256) void chain_fwd_rows_kernel(DecArgs a, const fl
                     priv[r * CR_LD + k] = zl[i];
                 }
             }
-            // this layer's input rows: the A operand, and (training) the saved copy for the backward pass
-            float af[KP / 4];
-#pragma unroll
-            for (int kk = 0; kk < KP / 4; ++kk) af[kk] = priv[c16 * CR_LD + 4 * kk + g];
+            // this layer's input rows: (training) the saved copy for the backward pass, and the A operand
             if (hin) store_rows(hin + (long)s * a.B * KP, KP, b0);
-            const float* pan = smem + buf * PANEL;
             f32x4_t acc[6];
-#pragma unroll
-            for (int ct = 0; ct < 6; ++ct) acc[ct] = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
-            // B values of four k steps (24 registers) are read one block ahead of the 24 MFMAs that use them:
-            // left to itself the compiler reads two values, waits for LDS, issues two MFMAs, and so on
-            float bv[2][24];
-            auto load_b = [&](int kq, float (&b)[24]) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-#pragma unroll
-                    for (int ct = 0; ct < 6; ++ct) b[e * 6 + ct] = pan[(4 * (4 * kq + e) + g) * NP + ct * 16 + c16];
-            };
-            load_b(0, bv[0]);
-#pragma unroll
-            for (int kq = 0; kq < KP / 16; ++kq) {
-                if (kq + 1 < KP / 16) load_b(kq + 1, bv[(kq + 1) & 1]);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-#pragma unroll
-                    for (int ct = 0; ct < 6; ++ct)
-                        acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[4 * kq + e], bv[kq & 1][e * 6 + ct], acc[ct], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
+            rows_product(priv, smem + buf * PANEL, c16, g, acc);
             __builtin_amdgcn_wave_barrier();
             // the layer's output into the private tile, as the next layer's input rows or as the node
             // vectors on their way out; the activation is chosen once per step, outside the element loop
@@ -935,6 +946,143 @@ __global__ __launch_bounds__(CH_NT, 2) void chain_bwd_saved_kernel(DecArgs a, co
     }
 }
 
+// The saved-rows backward for large batches, in the form of chain_fwd_rows_kernel: every wave walks its own
+// 16 samples through all channels, last layer first.  A step turns the gradient of a layer's output into
+// the pre-activation gradient (slope from the layer's saved output), leaves that in the wave's private
+// tile - from where it goes to memory as whole rows for the weight gradient, and into the A operand - and
+// multiplies by the layer's [n][k] panel, which the workgroup's waves share (LDS-DMA, one step ahead).  The
+// product is the gradient of the layer below in the register layout the next step's slope multiplies.  The
+// saved outputs arrive as whole rows one step ahead and turn into that layout through the private tile.
+__global__ __launch_bounds__(256) void chain_bwd_rows_kernel(DecArgs a, const float* __restrict__ wn,
+                                                             const float* __restrict__ dnode,
+                                                             const float* __restrict__ gxlat,
+                                                             const float* __restrict__ hin,
+                                                             const float* __restrict__ nodes, float* __restrict__ dz,
+                                                             float* __restrict__ dp) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int PANEL = CR_PANEL;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c16 = lane & 15, g = lane >> 4;
+    float* priv = smem + 2 * PANEL + wave * CR_ROWS * CR_LD;
+    const int N = a.N, R = a.R, NL = a.NL, steps = R * NL;
+    const int ntiles = (a.B + CR_TS - 1) / CR_TS;
+    if ((int)blockIdx.x >= ntiles) return;
+    // step q of a tile: channel q / NL, layer NL - 1 - q % NL
+    auto panel_dma = [&](int q, int buf) {
+        const int r = q / NL, l = NL - 1 - (q - r * NL);
+        rows_panel_dma(wn + (long)(r * NL + l) * PANEL, smem + buf * PANEL);
+    };
+    // the outputs of step q's layer, as 16-byte pieces of whole rows (rows past the batch: the last row's)
+    auto fetch_h = [&](int q, int b0, f32x4_t (&v)[CR_QPL]) {
+        const int r = q / NL, l = NL - 1 - (q - r * NL);
+        const float* src = l == NL - 1 ? nodes + (long)r * NP : hin + (long)(r * NL + l + 1) * a.B * KP;
+        const long stride = l == NL - 1 ? (long)R * NP : KP;
+#pragma unroll
+        for (int i = 0; i < CR_QPL; ++i) {
+            const int chunk = i * 64 + lane, rr = chunk / (KP / 4), c4 = chunk - rr * (KP / 4);
+            const int row = b0 + rr < a.B ? b0 + rr : a.B - 1;
+            v[i] = *reinterpret_cast<const f32x4_t*>(src + (long)row * stride + 4 * c4);
+        }
+    };
+    // the gradient of channel r's node vectors in the accumulator layout, zero outside the batch and the nodes
+    auto fetch_dnode = [&](int r, int b0, f32x4_t (&v)[6]) {
+#pragma unroll
+        for (int ct = 0; ct < 6; ++ct)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int n = ct * 16 + c16, row = b0 + 4 * g + rr;
+                const bool ok = n < N && row < a.B;
+                float t = dnode[ok ? ((long)row * R + r) * NP + n : 0];
+                if (gxlat && r < a.xlat_r) t += gxlat[ok ? (long)row * N + n : 0];
+                v[ct][rr] = ok ? t : 0.0f;
+            }
+    };
+    panel_dma(0, 0);
+    int buf = 0;
+    f32x4_t hq[CR_QPL], dn[6], dh[6];
+    {
+        const int b0 = blockIdx.x * CR_TS + wave * CR_ROWS;
+        fetch_h(0, b0, hq);
+        fetch_dnode(0, b0, dn);
+    }
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int b0 = tile * CR_TS + wave * CR_ROWS;
+        const bool more_tiles = tile + (int)gridDim.x < ntiles;
+        const int b0_next = b0 + (int)gridDim.x * CR_TS;
+        f32x4_t dzacc[6];
+#pragma unroll
+        for (int ct = 0; ct < 6; ++ct) dzacc[ct] = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
+        for (int q = 0; q < steps; ++q, buf ^= 1) {
+            const int r = q / NL, l = NL - 1 - (q - r * NL);
+            __syncthreads();                             // this step's panel has landed; the other buffer is free
+            const bool more = q + 1 < steps || more_tiles;
+            if (more) panel_dma(q + 1 < steps ? q + 1 : 0, buf ^ 1);
+            __builtin_amdgcn_wave_barrier();
+            // the layer's outputs: rows -> private tile -> accumulator layout
+#pragma unroll
+            for (int i = 0; i < CR_QPL; ++i) {
+                const int chunk = i * 64 + lane, rr = chunk / (KP / 4), c4 = chunk - rr * (KP / 4);
+                *reinterpret_cast<f32x4_t*>(priv + rr * CR_LD + 4 * c4) = hq[i];
+            }
+            __builtin_amdgcn_wave_barrier();
+            f32x4_t h[6];
+#pragma unroll
+            for (int ct = 0; ct < 6; ++ct)
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) h[ct][rr] = priv[(4 * g + rr) * CR_LD + ct * 16 + c16];
+            if (l == NL - 1) {
+#pragma unroll
+                for (int ct = 0; ct < 6; ++ct) dh[ct] = dn[ct];
+            }
+            // what the next step needs from memory, under this step's product
+            if (more) {
+                fetch_h(q + 1 < steps ? q + 1 : 0, q + 1 < steps ? b0 : b0_next, hq);
+                if (l == 0) fetch_dnode(q + 1 < steps ? r + 1 : 0, q + 1 < steps ? b0 : b0_next, dn);
+            }
+            auto slope = [&](auto act_tag) {
+                constexpr int ACT = decltype(act_tag)::value;
+#pragma unroll
+                for (int ct = 0; ct < 6; ++ct)
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) {
+                        const float v = dh[ct][rr] * act_slope(ACT, h[ct][rr]);
+                        h[ct][rr] = ct * 16 + c16 < N ? v : 0.0f;
+                    }
+            };
+            switch (layer_act(a.acts, l)) {
+                case ACT_SIGMOID: slope(std::integral_constant<int, ACT_SIGMOID>{}); break;
+                case ACT_TANH: slope(std::integral_constant<int, ACT_TANH>{}); break;
+                default: slope(std::integral_constant<int, ACT_NONE>{}); break;
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int ct = 0; ct < 6; ++ct)
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) priv[(4 * g + rr) * CR_LD + ct * 16 + c16] = h[ct][rr];
+            __builtin_amdgcn_wave_barrier();
+            rows_store(priv, dp + (long)(r * NL + l) * a.B * NP, NP, b0, a.B, lane);
+            // gradient of the layer's input rows: dpre . Wn
+            f32x4_t acc[6];
+            rows_product(priv, smem + buf * PANEL, c16, g, acc);
+            if (l == 0) {
+#pragma unroll
+                for (int ct = 0; ct < 6; ++ct) dzacc[ct] += acc[ct];
+            } else {
+#pragma unroll
+                for (int ct = 0; ct < 6; ++ct) dh[ct] = acc[ct];
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+#pragma unroll
+        for (int ct = 0; ct < 6; ++ct)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int n = ct * 16 + c16, row = b0 + 4 * g + rr;
+                if (n < a.L && row < a.B) dz[(long)row * a.L + n] = dzacc[ct][rr];
+            }
+    }
+}
+
 // out[i] = sum_p part[p][i] in index order (the per-channel partial latent gradients)
 __global__ __launch_bounds__(256) void add_parts_kernel(const float* __restrict__ part, int parts, long n,
                                                         float* __restrict__ out) {
@@ -1206,6 +1354,22 @@ int mdnvae_decoder_bwd(const float* z, const float* wt, const float* wn, int B, 
     }
     MV_LAUNCH_CHECK("outer_grad_kernel");
     const int ntiles = (B + CH_TS - 1) / CH_TS;
+    static const bool rows_off = getenv("MDNVAE_CHAIN_ROWS_OFF") != nullptr;       // tuning knob
+    if (layer_in_saved && !drop && B >= CR_TS * 128 && !rows_off) {
+        static bool rows_attr_set = false;
+        if (!rows_attr_set) {
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(chain_bwd_rows_kernel),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            MV_REQUIRE(e == hipSuccess, (int)e, "mdnvae_decoder_bwd: cannot raise the LDS limit: %s", hipGetErrorString(e));
+            rows_attr_set = true;
+        }
+        const int rtiles = (B + CR_TS - 1) / CR_TS;
+        const size_t rows_lds = sizeof(float) * ((size_t)2 * KP * NP + (size_t)CR_WAVES * CR_ROWS * CR_LD);
+        hipLaunchKernelGGL(chain_bwd_rows_kernel, dim3(rtiles < 1024 ? rtiles : 1024), dim3(256), rows_lds, st, a, wn,
+                           node_grad, xlat_channels ? grad_xlat : nullptr, layer_in, nodes, grad_z, layer_dpre);
+        MV_LAUNCH_CHECK("chain_bwd_rows_kernel");
+        return 0;
+    }
     if (layer_in_saved && !drop) {
         // the forward pass left every layer's input rows in layer_in: no recomputation
         // few tiles: one workgroup per (tile, channel), partial latent gradients added in channel order

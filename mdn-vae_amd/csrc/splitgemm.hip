@@ -140,15 +140,21 @@ __global__ __launch_bounds__(256) void split_cols_kernel(const float* __restrict
 
 enum { SG_EPI_BIAS_RELU = 0, SG_EPI_PLAIN = 1, SG_EPI_BIAS = 2 };
 
-template <int WM, int EPI>
+// TERMS = 6: all products down to 2^-24 of the result.  TERMS = 3: x1 w1 + x1 w2 + x2 w1 only (what is left
+// out is 2^-16 of |x w| per term at most), the third part of neither operand is staged.
+template <int WM, int EPI, int TERMS>
 __global__ __launch_bounds__(512) void split_gemm_kernel(const char* __restrict__ A, const char* __restrict__ Bop,
                                                          int KS, int ntm, int ntn, int m_valid,
                                                          const float* __restrict__ bias0, const float* __restrict__ bias1,
                                                          float* __restrict__ out0, float* __restrict__ out1, int n_split,
                                                          long ld_out, int n_valid, int accumulate) {
     constexpr int TA = 2 * WM, TB = 8;                   // fragment rows-tiles of A / B per workgroup
-    constexpr int STAGE = (TA + TB) * SG_STEP;
-    constexpr int PIECES = (TA + TB) * 3;
+    constexpr int NPART = TERMS == 6 ? 3 : 2;            // parts of a fragment that take part
+    constexpr int KB = TERMS == 6 ? 1 : 2;               // k steps per barrier: about as many MFMAs either way
+    constexpr int FSTEP = NPART * SG_FRAG;               // one (row tile, k step) in LDS
+    constexpr int KSTAGE = (TA + TB) * FSTEP;            // one k step of all row tiles
+    constexpr int STAGE = KB * KSTAGE;
+    constexpr int PIECES = (TA + TB) * NPART * KB;
     constexpr int PPW = (PIECES + 7) / 8;                // pieces per wave (the last may be missing)
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int lane = threadIdx.x & 63;
@@ -160,22 +166,25 @@ __global__ __launch_bounds__(512) void split_gemm_kernel(const char* __restrict_
     if ((ntiles & 7) == 0) tl = (blockIdx.x & 7) * (ntiles >> 3) + (blockIdx.x >> 3);
     const int tm = tl / ntn, tn = tl - tm * ntn;
 
-    // this wave's staging pieces: piece q = wid + 8 i is part (q % 3) of fragment row-tile (q / 3)
+    // this wave's staging pieces: piece q = wid + 8 i is part (q % NPART) of fragment row-tile
+    // (q / NPART) % (TA + TB) of k step q / (NPART (TA + TB)) of the stage
     const char* src[PPW];
-    int dst[PPW];
+    int dst[PPW], kof[PPW];
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
         const int q = wid + 8 * i;
-        const int t = q / 3, part = q - 3 * t;
+        const int kk = q / (NPART * (TA + TB)), qq = q - kk * NPART * (TA + TB);
+        const int t = qq / NPART, part = qq - NPART * t;
         const bool isA = t < TA;
         const long row_tile = isA ? (long)tm * TA + t : (long)tn * TB + (t - TA);
-        src[i] = (isA ? A : Bop) + row_tile * KS * SG_STEP + part * SG_FRAG + lane * 16;
-        dst[i] = q * SG_FRAG;
+        src[i] = (isA ? A : Bop) + row_tile * KS * SG_STEP + (long)kk * SG_STEP + part * SG_FRAG + lane * 16;
+        dst[i] = kk * KSTAGE + t * FSTEP + part * SG_FRAG;
+        kof[i] = kk;
     }
     auto stage = [&](int buf, int ks) {
 #pragma unroll
         for (int i = 0; i < PPW; ++i) {
-            if (PIECES % 8 == 0 || wid + 8 * i < PIECES)
+            if ((PIECES % 8 == 0 || wid + 8 * i < PIECES) && (KB == 1 || ks + kof[i] < KS))
                 __builtin_amdgcn_global_load_lds(SG_GLOBAL_PTR(src[i] + (long)ks * SG_STEP),
                                                  SG_LDS_PTR(smem + buf * STAGE + dst[i]), 16, 0, 0);
         }
@@ -203,39 +212,45 @@ __global__ __launch_bounds__(512) void split_gemm_kernel(const char* __restrict_
 
     stage(0, 0);
     __syncthreads();
-    for (int ks = 0; ks < KS; ++ks) {
-        const int buf = ks & 1;
-        if (ks + 1 < KS) stage(buf ^ 1, ks + 1);
-        const char* sa = smem + buf * STAGE + (wm * WM) * SG_STEP + lane * 16;
-        const char* sb = smem + buf * STAGE + (TA + wn * 2) * SG_STEP + lane * 16;
-        // B fragments and the first A row tile, then A row tile i + 1 is fetched while the twelve
-        // MFMAs of row tile i run: only the first block of a step waits on LDS
-        sg_frag a[2][3], b[2][3];
+    int buf = 0;
+    for (int ks = 0; ks < KS; ks += KB, buf ^= 1) {
+        if (ks + KB < KS) stage(buf ^ 1, ks + KB);
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int kk = 0; kk < KB; ++kk) {
+            if (KB > 1 && ks + kk >= KS) break;
+            const char* sa = smem + buf * STAGE + kk * KSTAGE + (wm * WM) * FSTEP + lane * 16;
+            const char* sb = smem + buf * STAGE + kk * KSTAGE + (TA + wn * 2) * FSTEP + lane * 16;
+            // B fragments and the first A row tile, then A row tile i + 1 is fetched while the MFMAs of
+            // row tile i run: only the first block of a step waits on LDS
+            sg_frag a[2][NPART], b[2][NPART];
 #pragma unroll
-            for (int s = 0; s < 3; ++s) b[j][s] = *reinterpret_cast<const sg_frag*>(sb + j * SG_STEP + s * SG_FRAG);
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int s = 0; s < 3; ++s) a[0][s] = *reinterpret_cast<const sg_frag*>(sa + s * SG_FRAG);
+                for (int s = 0; s < NPART; ++s) b[j][s] = *reinterpret_cast<const sg_frag*>(sb + j * FSTEP + s * SG_FRAG);
 #pragma unroll
-        for (int i = 0; i < WM; ++i) {
-            if (i + 1 < WM) {
+            for (int s = 0; s < NPART; ++s) a[0][s] = *reinterpret_cast<const sg_frag*>(sa + s * SG_FRAG);
 #pragma unroll
-                for (int s = 0; s < 3; ++s)
-                    a[(i + 1) & 1][s] = *reinterpret_cast<const sg_frag*>(sa + (i + 1) * SG_STEP + s * SG_FRAG);
+            for (int i = 0; i < WM; ++i) {
+                if (i + 1 < WM) {
+#pragma unroll
+                    for (int s = 0; s < NPART; ++s)
+                        a[(i + 1) & 1][s] = *reinterpret_cast<const sg_frag*>(sa + (i + 1) * FSTEP + s * SG_FRAG);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    // smallest terms first
+                    if (TERMS == 6) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i & 1][0], b[j][NPART - 1], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i & 1][1], b[j][1], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i & 1][NPART - 1], b[j][0], acc[i][j], 0, 0, 0);
+                    }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i & 1][0], b[j][1], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i & 1][1], b[j][0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i & 1][0], b[j][0], acc[i][j], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                // smallest terms first
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i & 1][0], b[j][2], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i & 1][1], b[j][1], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i & 1][2], b[j][0], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i & 1][0], b[j][1], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i & 1][1], b[j][0], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i & 1][0], b[j][0], acc[i][j], 0, 0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
     }
@@ -312,7 +327,8 @@ int mdnvae_split_cols(const float* src, long Kd, long R, long ld, long row_tile0
 
 int mdnvae_split_gemm(const void* a, const void* b, long M, long N, long K, long m_valid, long n_valid,
                       const float* bias0, const float* bias1, int relu, int accumulate, float* out0, float* out1,
-                      long n_split, long ld_out, int tile_m, void* stream) {
+                      long n_split, long ld_out, int tile_m, int terms, void* stream) {
+    MV_REQUIRE(terms == 6 || terms == 3, E_ARG, "mdnvae_split_gemm: terms must be 6 (every product down to 2^-24) or 3");
     MV_REQUIRE(M >= 1 && N >= 1 && K >= 16 && m_valid >= 0 && m_valid <= M, E_ARG, "mdnvae_split_gemm: bad shape");
     MV_REQUIRE(n_valid >= 0 && n_valid <= n_split, E_ARG, "mdnvae_split_gemm: n_valid counts columns of one output (at most n_split)");
     MV_REQUIRE(!(relu && accumulate), E_ARG, "mdnvae_split_gemm: the bias + ReLU epilogue does not accumulate");
@@ -333,16 +349,21 @@ int mdnvae_split_gemm(const void* a, const void* b, long M, long N, long K, long
     hipStream_t st = (hipStream_t)stream;
 #define SG_LAUNCH(WM, EPI)                                                                                          \
     do {                                                                                                            \
-        const size_t lds = 2 * (size_t)(2 * WM + 8) * SG_STEP;                                                      \
+        if (terms == 6) SG_LAUNCH_T(WM, EPI, 6);                                                                    \
+        else SG_LAUNCH_T(WM, EPI, 3);                                                                               \
+    } while (0)
+#define SG_LAUNCH_T(WM, EPI, TERMS)                                                                                 \
+    do {                                                                                                            \
+        const size_t lds = 2 * (size_t)(2 * WM + 8) * (TERMS == 6 ? 3 : 4) * SG_FRAG;                               \
         static bool raised = false;                                                                                 \
         if (!raised) {                                                                                              \
-            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(split_gemm_kernel<WM, EPI>),     \
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(split_gemm_kernel<WM, EPI, TERMS>), \
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);       \
             MV_REQUIRE(e == hipSuccess, (int)e, "mdnvae_split_gemm: cannot raise the LDS limit: %s",                \
                        hipGetErrorString(e));                                                                       \
             raised = true;                                                                                          \
         }                                                                                                           \
-        hipLaunchKernelGGL((split_gemm_kernel<WM, EPI>), dim3((unsigned)(ntm * ntn)), dim3(512), lds, st,           \
+        hipLaunchKernelGGL((split_gemm_kernel<WM, EPI, TERMS>), dim3((unsigned)(ntm * ntn)), dim3(512), lds, st,    \
                            (const char*)a, (const char*)b, KS, (int)ntm, (int)ntn, (int)m_valid, bias0, bias1,      \
                            out0, out1 ? out1 : out0, (int)n_split, ld_out, (int)n_valid, accumulate);               \
     } while (0)
@@ -356,6 +377,7 @@ int mdnvae_split_gemm(const void* a, const void* b, long M, long N, long K, long
         else SG_LAUNCH(2, SG_EPI_PLAIN);
     }
 #undef SG_LAUNCH
+#undef SG_LAUNCH_T
     MV_LAUNCH_CHECK("split_gemm_kernel");
     return 0;
 }

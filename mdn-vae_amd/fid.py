@@ -264,7 +264,7 @@ def _newton_schulz_f32(y64, d):
 
     def product(a_op, b_op, out):                  # out = a . b^T = a . b for the symmetric matrices here
         call("mdnvae_split_gemm", a_op.data_ptr(), b_op.data_ptr(), ld, ld, kp, d, ld, None, None, 0, 0, ptr(out), None, ld, ld,
-             256, stream())
+             256, 6, stream())
 
     prev, last_delta, iters = None, None, 0
     for iters in range(1, _FAST_MAX_ITERS + 1):

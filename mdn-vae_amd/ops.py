@@ -1,5 +1,7 @@
 """Autograd wrappers over the C ABI: each op's forward and backward are hand-written HIP
 kernels; nothing here computes on the host or falls back to eager PyTorch arithmetic."""
+import os
+
 import torch
 
 from . import _lib
@@ -261,6 +263,13 @@ def _split_linear_ok(x, weight, bias):
 
 
 SPLIT_LINEAR = True
+# bf16 products per multiply-add in the weight-gradient products: 6 keeps every term down to 2^-24 (one
+# fp32 rounding); 3 keeps x1 w1 + x1 w2 + x2 w1 and drops terms of relative size <= 2^-16 each - about
+# 1e-5 of the gradient's norm, inside the 1e-4 the gradients are held to, at half the matrix-core work.  A
+# weight gradient feeds the optimiser only: nothing downstream amplifies its error, unlike an activation's.
+SPLIT_WGRAD_TERMS = int(os.environ.get("MDNVAE_SPLIT_WGRAD_TERMS", "3"))
+if SPLIT_WGRAD_TERMS not in (3, 6):
+    raise RuntimeError("MDNVAE_SPLIT_WGRAD_TERMS must be 3 or 6")
 
 
 def _split_linear_fwd(x, weight, bias, act):
@@ -275,7 +284,7 @@ def _split_linear_fwd(x, weight, bias, act):
     call("mdnvae_split_rows", ptr(x, "x"), B, K, K, 0, xa.data_ptr(), stream())
     y = torch.empty(B, n_out, dtype=torch.float32, device=dev)
     call("mdnvae_split_gemm", xa.data_ptr(), wb.data_ptr(), Mp, Np, Kp, B, n_out, ptr(bias, "bias"), None,
-         int(act == ACTS["relu"]), 0, ptr(y), None, Np, n_out, 128, stream())
+         int(act == ACTS["relu"]), 0, ptr(y), None, Np, n_out, 128, 6, stream())
     if act not in (ACTS[None], ACTS["relu"]):
         call("mdnvae_bias_act", ptr(y), None, B, n_out, act, stream())
     return y
@@ -293,8 +302,7 @@ def _split_linear_dgrad(gpre, weight):
     wb[(n_in + 31) // 32 * (Kp // 16) * 3072:].zero_()
     call("mdnvae_split_cols", ptr(weight, "weight"), n_out, n_in, n_in, 0, wb.data_ptr(), stream())
     gx = torch.empty(B, n_in, dtype=torch.float32, device=dev)
-    call("mdnvae_split_gemm", ga.data_ptr(), wb.data_ptr(), Mp, Np, Kp, B, n_in, None, None, 0, 0, ptr(gx), None, Np, n_in, 128,
-         stream())
+    call("mdnvae_split_gemm", ga.data_ptr(), wb.data_ptr(), Mp, Np, Kp, B, n_in, None, None, 0, 0, ptr(gx), None, Np, n_in, 128, 6, stream())
     return gx
 
 
@@ -313,7 +321,7 @@ def _split_linear_wgrad(gpre, x, param):
     target = _grad_target(param)
     out = target if target is not None else torch.empty(n_out, n_in, dtype=torch.float32, device=dev)
     call("mdnvae_split_gemm", pa.data_ptr(), xb.data_ptr(), Mp, Np, Kp, n_out, n_in, None, None, 0, int(target is not None),
-         ptr(out), None, Np, n_in, 128, stream())
+         ptr(out), None, Np, n_in, 128, SPLIT_WGRAD_TERMS, stream())
     if target is not None:
         _grad_added(param)
         return None
@@ -487,7 +495,7 @@ class _SymLinearPair(torch.autograd.Function):
         y1 = torch.empty(B, H, dtype=torch.float32, device=dev)
         y2 = torch.empty(B, H, dtype=torch.float32, device=dev)
         call("mdnvae_split_gemm", xa.data_ptr(), wb.data_ptr(), Mp, 2 * H, T, B, H, ptr(b1, "bias"), ptr(b2, "bias"), 1, 0,
-             ptr(y1), ptr(y2), H, H, 256, stream())
+             ptr(y1), ptr(y2), H, H, 256, 6, stream())
         ctx.save_for_backward(xt, y1, y2)
         ctx.n_nodes = n_nodes
         ctx.params = (w1, b1, w2, b2)
@@ -515,7 +523,7 @@ class _SymLinearPair(torch.autograd.Function):
             call("mdnvae_split_cols", ptr(xt), B, T, T, 0, xb.data_ptr(), stream())
             gts = [torch.empty(T, H, dtype=torch.float32, device=dev) for _ in range(2)]
             call("mdnvae_split_gemm", xb.data_ptr(), pb.data_ptr(), Tp, 2 * H, Kp, T, H, None, None, 0, 0, ptr(gts[0]),
-                 ptr(gts[1]), H, H, 128, stream())
+                 ptr(gts[1]), H, H, 128, SPLIT_WGRAD_TERMS, stream())
             for i, (param, gt) in enumerate(((w1, gts[0]), (w2, gts[1]))):
                 if not ctx.needs_input_grad[1 + 2 * i]:
                     continue
@@ -563,7 +571,7 @@ class _LinearPair(torch.autograd.Function):
         y1 = torch.empty(B, H, dtype=torch.float32, device=dev)
         y2 = torch.empty(B, H, dtype=torch.float32, device=dev)
         call("mdnvae_split_gemm", xa.data_ptr(), wb.data_ptr(), Mp, 2 * H, Kp, B, H, ptr(b1, "bias"), ptr(b2, "bias"), 1, 0,
-             ptr(y1), ptr(y2), H, H, 256, stream())
+             ptr(y1), ptr(y2), H, H, 256, 6, stream())
         ctx.save_for_backward(x, y1, y2)
         ctx.params = (w1, b1, w2, b2)
         return y1, y2
@@ -594,7 +602,7 @@ class _LinearPair(torch.autograd.Function):
                 target = _grad_target(param)
                 out = target if target is not None else torch.empty(H, D, dtype=torch.float32, device=dev)
                 call("mdnvae_split_gemm", pb.data_ptr(), xb.data_ptr(), H, Np, Kp, H, D, None, None, 0, int(target is not None),
-                     ptr(out), None, Np, D, 128, stream())
+                     ptr(out), None, Np, D, 128, SPLIT_WGRAD_TERMS, stream())
                 if target is not None:
                     _grad_added(param)
                 else:

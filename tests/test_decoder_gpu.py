@@ -109,12 +109,8 @@ def test_rank1_decoder_against_reference_fixture(variant):
     _check_named_grads(fix, model, names=names)
 
 
-@pytest.mark.parametrize("N,L,B,act,use_drop", [(87, 68, 33, "sigmoid", False), (87, 87, 1, "tanh", True),
-                                                (68, 68, 17, "sigmoid", True), (20, 7, 40, "tanh", False)])
-def test_rank1_decoder_shapes_against_oracle(N, L, B, act, use_drop):
-    g = torch.Generator().manual_seed(N * 100 + B)
-    model = M.ConvVAE(decoder="gcn", intercept="diag", final="none", n_nodes=max(N, 64), latent_dim=L, act=act)
-    # rebuild the decoder-side layers for the requested node count (the encoder is not used here)
+def _rank1_model(N, L, act, g):
+    """The rank-1 decoder side of ConvVAE for any node count (the encoder is not used here)."""
     model = M.ConvVAE.__new__(M.ConvVAE)
     torch.nn.Module.__init__(model)
     model.n_nodes, model.latent_dim, model.act = N, L, act
@@ -129,7 +125,14 @@ def test_rank1_decoder_shapes_against_oracle(N, L, B, act, use_drop):
     mask = (torch.rand(N, N, generator=g) < 0.4).float()
     mask.fill_diagonal_(1.0)
     model.set_mask([mask] * 5)
-    model = model.to(DEV)
+    return model.to(DEV), mask
+
+
+@pytest.mark.parametrize("N,L,B,act,use_drop", [(87, 68, 33, "sigmoid", False), (87, 87, 1, "tanh", True),
+                                                (68, 68, 17, "sigmoid", True), (20, 7, 40, "tanh", False)])
+def test_rank1_decoder_shapes_against_oracle(N, L, B, act, use_drop):
+    g = torch.Generator().manual_seed(N * 100 + B)
+    model, mask = _rank1_model(N, L, act, g)
     z = torch.randn(B, L, generator=g)
     cot = torch.randn(B, N * N, generator=g)
     cotx = torch.randn(B, N, generator=g)
@@ -320,4 +323,35 @@ def test_large_batch_chain_forward_matches_the_small_batch_kernel(n_nodes):
     assert _rel(big[0], torch.cat([lo[0], hi[0]])) <= OUT_RTOL
     assert _rel(big[1], torch.cat([lo[1], hi[1]])) <= GRAD_RTOL
     for gb, gl, gh in zip(big[2], lo[2], hi[2]):          # parameter gradients: the halves add up to the whole
+        assert _rel(gb, gl + gh) <= GRAD_RTOL
+
+
+@pytest.mark.parametrize("N,L,act", [(87, 68, "tanh"), (30, 7, "sigmoid")])
+def test_large_batch_rank1_decoder_matches_the_small_batch_kernels(N, L, act):
+    """The two-layer chains with x_latent (the latent gradient then has a second source) through the
+    large-batch kernels, forward and backward, against the same rows in two halves through the others."""
+    g = torch.Generator().manual_seed(N)
+    model, _ = _rank1_model(N, L, act, g)
+    B = 8192 + 21
+    z = torch.randn(B, L, generator=g).to(DEV)
+    cot = (torch.randn(B, N * N, generator=g) * 0.1).to(DEV)
+    cotx = torch.randn(B, N, generator=g).to(DEV)
+    spec = model._chain_spec()
+    params = []
+    for a, b in model._names:
+        params += [getattr(model, a).weight, getattr(model, a).bias, getattr(model, b).weight, getattr(model, b).bias]
+
+    def run(lo, hi):
+        zz = z[lo:hi].clone().requires_grad_(True)
+        for p in model.parameters():
+            p.grad = None
+        recon, xl = M.ops.chain_decoder(zz, spec, params, model.fcintercept.weight, model.fcintercept.bias, None)
+        ((recon * cot[lo:hi]).sum() + (xl * cotx[lo:hi]).sum()).backward()
+        return recon.detach(), xl.detach(), zz.grad.detach(), [p.grad.detach().clone() for p in model.parameters()]
+
+    half = B // 2
+    big, lo, hi = run(0, B), run(0, half), run(half, B)
+    for i, bar in ((0, OUT_RTOL), (1, OUT_RTOL), (2, GRAD_RTOL)):
+        assert _rel(big[i], torch.cat([lo[i], hi[i]])) <= bar, i
+    for gb, gl, gh in zip(big[3], lo[3], hi[3]):
         assert _rel(gb, gl + gh) <= GRAD_RTOL

@@ -56,26 +56,37 @@ def test_split_product_against_float64(Mrows, N, K, tile):
         out0 = torch.full((Mrows, half), float("nan"), device=DEV)
         out1 = torch.full((Mrows, N - half), float("nan"), device=DEV) if half < N else None
         call("mdnvae_split_gemm", oa.data_ptr(), ob.data_ptr(), Mp, N, Kp, Mrows, half, None, None, 0, 0, ptr(out0), ptr(out1),
-             half, half, tile, stream())
+             half, half, tile, 6, stream())
         got = torch.cat([out0] + ([out1] if out1 is not None else []), dim=1).double().cpu()
         assert torch.isfinite(got).all()
         assert float(((got - want).abs() / mag).max()) <= 1e-6, how        # fp32-accumulation level, entry by entry
         assert float((got - want).abs().max() / want.abs().max()) <= 1e-5
+        # three-term form (a1 b1 + a1 b2 + a2 b1): what it leaves out is at most 3 * 2^-16 of |a b| per product
+        # (a bf16 part is within 2^-8 of what it rounds), a third of that in the root mean square
+        call("mdnvae_split_gemm", oa.data_ptr(), ob.data_ptr(), Mp, N, Kp, Mrows, half, None, None, 0, 0, ptr(out0), ptr(out1),
+             half, half, tile, 3, stream())
+        got3 = torch.cat([out0] + ([out1] if out1 is not None else []), dim=1).double().cpu()
+        assert float(((got3 - want).abs() / mag).max()) <= 3 * 2.0 ** -16 + 1e-6, how
+        assert float((got3 - want).norm() / want.norm()) <= 3e-5, how      # gradients are held to 1e-4
     # bias + ReLU epilogue
     bd_ = bias.to(DEV)
     out0 = torch.empty(Mrows, half, device=DEV)
     out1 = torch.empty(Mrows, N - half, device=DEV) if half < N else None
     call("mdnvae_split_gemm", oa.data_ptr(), ob.data_ptr(), Mp, N, Kp, Mrows, half, ptr(bd_[:half].contiguous()),
-         ptr(bd_[half:].contiguous()) if half < N else None, 1, 0, ptr(out0), ptr(out1), half, half, tile, stream())
+         ptr(bd_[half:].contiguous()) if half < N else None, 1, 0, ptr(out0), ptr(out1), half, half, tile, 6, stream())
     got = torch.cat([out0] + ([out1] if out1 is not None else []), dim=1).double().cpu()
     want_r = torch.relu(want + bias.double())
     assert float((got - want_r).abs().max() / want_r.abs().max()) <= 1e-5
 
 
+@pytest.mark.parametrize("terms", [3, 6])
 @pytest.mark.parametrize("B,n", [(1024, 68), (1500, 87)])
-def test_first_layer_pair_against_float64_and_the_library_path(B, n):
+def test_first_layer_pair_against_float64_and_the_library_path(B, n, terms, monkeypatch):
     """ops.sym_linear_pair (one split product for both layers, forward and weight gradients) against
-    float64 on the full N*N inputs and against ops.sym_linear_act (library fp32 GEMMs)."""
+    float64 on the full N*N inputs and against ops.sym_linear_act (library fp32 GEMMs).  With six terms the
+    weight gradients are as good as the fp32 library's; with three (the default) they are held to 5e-5 of
+    the largest entry, half the gradient bar."""
+    monkeypatch.setattr(ops, "SPLIT_WGRAD_TERMS", terms)
     torch.manual_seed(B)
     H, D = 1024, n * n
     x = M.data.synthetic_sc(B, n, seed=3, device=DEV)
@@ -105,7 +116,10 @@ def test_first_layer_pair_against_float64_and_the_library_path(B, n):
         err = float((g_.double().cpu() - w_).abs().max() / w_.abs().max())
         err_lib = float((l_.double().cpu() - w_).abs().max() / w_.abs().max())
         assert err <= bar, (name, err)
-        assert err <= max(4 * err_lib, 1e-6), (name, err, err_lib)      # no worse than the fp32 library GEMM
+        if name.startswith("gw") and terms == 3:
+            assert err <= 5e-5, (name, err)
+        else:
+            assert err <= max(4 * err_lib, 1e-6), (name, err, err_lib)  # no worse than the fp32 library GEMM
 
 
 @pytest.mark.parametrize("Mrows,N,K", [(300, 333, 77), (513, 7569, 1000)])
@@ -123,8 +137,7 @@ def test_split_product_of_unaligned_tensors(Mrows, N, K):
     call("mdnvae_split_rows", ptr(bd), N, K, K, 0, ob.data_ptr(), stream())
     base = torch.randn(Mrows, N, generator=g)
     out = base.to(DEV)
-    call("mdnvae_split_gemm", oa.data_ptr(), ob.data_ptr(), Mp, Np, Kp, Mrows, N, None, None, 0, 1, ptr(out), None, Np, N, 128,
-         stream())
+    call("mdnvae_split_gemm", oa.data_ptr(), ob.data_ptr(), Mp, Np, Kp, Mrows, N, None, None, 0, 1, ptr(out), None, Np, N, 128, 6, stream())
     got = out.double().cpu() - base.double()
     assert float((got - want).abs().max() / want.abs().max()) <= 1e-5
     # the column-split form of the same tensors: operand rows = columns of the [K, rows] transposes
@@ -134,8 +147,7 @@ def test_split_product_of_unaligned_tensors(Mrows, N, K):
     call("mdnvae_split_cols", ptr(at), K, Mrows, Mrows, 0, oa2.data_ptr(), stream())
     call("mdnvae_split_cols", ptr(bt), K, N, N, 0, ob2.data_ptr(), stream())
     out2 = torch.full((Mrows, N), float("nan"), device=DEV)
-    call("mdnvae_split_gemm", oa2.data_ptr(), ob2.data_ptr(), Mp, Np, Kp, Mrows, N, None, None, 0, 0, ptr(out2), None, Np, N, 128,
-         stream())
+    call("mdnvae_split_gemm", oa2.data_ptr(), ob2.data_ptr(), Mp, Np, Kp, Mrows, N, None, None, 0, 0, ptr(out2), None, Np, N, 128, 6, stream())
     assert float((out2.double().cpu() - want).abs().max() / want.abs().max()) <= 1e-5
 
 
@@ -174,7 +186,10 @@ def test_full_first_layer_pair_against_float64_and_the_library_path(B, n):
         err = float((g_.double().cpu() - w_).abs().max() / w_.abs().max())
         err_lib = float((l_.double().cpu() - w_).abs().max() / w_.abs().max())
         assert err <= bar, (name, err)
-        assert err <= max(4 * err_lib, 1e-6), (name, err, err_lib)
+        if name.startswith("gw") and ops.SPLIT_WGRAD_TERMS == 3:
+            assert err <= 5e-5, (name, err)                             # three-term weight gradient
+        else:
+            assert err <= max(4 * err_lib, 1e-6), (name, err, err_lib)
 
 
 @pytest.mark.parametrize("act", [None, "sigmoid", "relu"])

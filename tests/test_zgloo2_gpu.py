@@ -60,10 +60,18 @@ def _train(kind, lo, hi, **trainer_kw):
     kind = "mdn" if kind == "mdn_split" else kind
     trainer = M.Trainer(model, "mdn" if kind == "mdn" else "poisson_log", **trainer_kw)
     losses = []
-    for s in range(STEPS):
-        xb = x[lo:hi] * (1.0 + 0.05 * s)
-        extra = (adjacency, traits[lo:hi]) if kind == "mdn" else (adjacency,)
-        losses.append(float(trainer.step((xb,) + extra, xb, eps=eps[s, lo:hi]).item()))
+    # the question here is whether two ranks take the single-process step, so the first-layer weight
+    # gradients run with all six part products: the three-term default leaves 1e-5 of rounding in them,
+    # which differs between one product over the whole batch and two over its halves, and Adam's first
+    # steps turn any difference in a near-zero gradient entry into a move of +-lr
+    terms, M.ops.SPLIT_WGRAD_TERMS = M.ops.SPLIT_WGRAD_TERMS, 6
+    try:
+        for s in range(STEPS):
+            xb = x[lo:hi] * (1.0 + 0.05 * s)
+            extra = (adjacency, traits[lo:hi]) if kind == "mdn" else (adjacency,)
+            losses.append(float(trainer.step((xb,) + extra, xb, eps=eps[s, lo:hi]).item()))
+    finally:
+        M.ops.SPLIT_WGRAD_TERMS = terms
     model.check_inputs()
     torch.cuda.synchronize()
     return losses, {k: v.detach().cpu().clone() for k, v in model.named_parameters()}, trainer

@@ -53,9 +53,9 @@ int main(int argc, char** argv) {
     RC(mdnvae_split_rows(w, H, T, T, 0, wb, 0));
     RC(mdnvae_split_cols(x, B, T, T, 0, xb, 0));
     RC(mdnvae_split_cols(p, B, H, H, 0, pb, 0));
-    RC(mdnvae_split_gemm(xa, wb, Bp, H, T, B, 1024, bias, bias + 1024, 1, 0, y0, y1, 1024, 1024, 256, 0));
+    RC(mdnvae_split_gemm(xa, wb, Bp, H, T, B, 1024, bias, bias + 1024, 1, 0, y0, y1, 1024, 1024, 256, 6, 0));
     const long Kw = (B + 15) / 16 * 16;
-    RC(mdnvae_split_gemm(xb, pb, T, H, Kw, T, 1024, nullptr, nullptr, 0, 0, g0, g1, 1024, 1024, 128, 0));
+    RC(mdnvae_split_gemm(xb, pb, T, H, Kw, T, 1024, nullptr, nullptr, 0, 0, g0, g1, 1024, 1024, 128, 6, 0));
     CK(hipDeviceSynchronize());
     std::vector<float> hy0(B * 1024), hy1(B * 1024), hg0(T * 1024), hg1(T * 1024);
     CK(hipMemcpy(hy0.data(), y0, hy0.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(hy1.data(), y1, hy1.size() * 4, hipMemcpyDeviceToHost));
@@ -91,9 +91,9 @@ int main(int argc, char** argv) {
     ms = time_ms([&] { mdnvae_split_cols(p, B, H, H, 0, pb, 0); });
     printf("split_cols p      : %.4f ms  (%.0f GB/s)\n", ms, (B * H * 10.0) / ms / 1e6);
     for (int tile : {256, 128}) {
-        ms = time_ms([&] { mdnvae_split_gemm(xa, wb, Bp, H, T, B, 1024, bias, bias + 1024, 1, 0, y0, y1, 1024, 1024, tile, 0); });
+        ms = time_ms([&] { mdnvae_split_gemm(xa, wb, Bp, H, T, B, 1024, bias, bias + 1024, 1, 0, y0, y1, 1024, 1024, tile, 6, 0); });
         printf("forward  tile %d : %.4f ms  fp32-equivalent %.1f TFLOP/s, bf16 MFMA %.0f TFLOP/s\n", tile, ms, fl / ms / 1e9, 6 * fl / ms / 1e9);
-        ms = time_ms([&] { mdnvae_split_gemm(xb, pb, T, H, Kw, T, 1024, nullptr, nullptr, 0, 0, g0, g1, 1024, 1024, tile, 0); });
+        ms = time_ms([&] { mdnvae_split_gemm(xb, pb, T, H, Kw, T, 1024, nullptr, nullptr, 0, 0, g0, g1, 1024, 1024, tile, 6, 0); });
         printf("gradient tile %d : %.4f ms  fp32-equivalent %.1f TFLOP/s, bf16 MFMA %.0f TFLOP/s\n", tile, ms, fl / ms / 1e9, 6 * fl / ms / 1e9);
     }
     return 0;
