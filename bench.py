@@ -218,6 +218,8 @@ ABI_TAGS.update({
     # (src, R, K, ld, ...) / (src, Kd, R, ld, ...): the fp32 source in, three bf16 parts out
     "mdnvae_split_rows": ("split_rows_kernel", lambda a: 10.0 * a[1] * a[2]),
     "mdnvae_split_cols": ("split_cols_kernel", lambda a: 10.0 * a[1] * a[2]),
+    # (src, gate, Kd, R, ld, ones_row, parts, ...): the source (and its gate) in, `parts` bf16 parts out
+    "mdnvae_split_cols_gated": ("split_cols_kernel", lambda a: (4.0 + (4.0 if a[1] is not None else 0.0) + 2.0 * a[6]) * a[2] * a[3]),
     # (y, grad_y, grad_pre, n, act): two reads, one write
     "mdnvae_act_bwd": ("act_bwd_kernel", lambda a: 12.0 * a[3]),
     "mdnvae_tri_fold": ("tri_pack_kernel<fold>", lambda a: 4.0 * a[1] * (a[2] * a[2] + a[2] * (a[2] + 1) // 2)),

@@ -252,6 +252,13 @@ int mdnvae_split_rows(const float* src, long R, long K, long ld, long row_tile0,
 /* operand[row_tile0 * 32 + c][r] = src[r][c] for src [Kd][ld] fp32, c < R: the transposed operand (of
  * k extent Kd rounded up to 16, zero filled) that a weight-gradient product takes. */
 int mdnvae_split_cols(const float* src, long Kd, long R, long ld, long row_tile0, void* out, void* stream);
+/* The same with the ReLU backward of the producing layer folded in (function/MM_Gate.py:157-158: F.relu of
+ * fc11 / fc12, whose autograd multiplies the output gradient by output > 0): gate [Kd][ld] or NULL - an
+ * entry of src counts only where its gate is positive.  ones_row != 0: operand row R (the one after the
+ * last source column) is 1 for k < Kd, so row R of a product with this operand is the column sum of the
+ * other one (a bias gradient).  parts (1..3): how many bf16 parts are written (2 for a three-term product). */
+int mdnvae_split_cols_gated(const float* src, const float* gate, long Kd, long R, long ld, int ones_row, int parts,
+                            long row_tile0, void* out, void* stream);
 /* out[m][n] = sum_k a[m][k] b[n][k] (+ bias[n] when biases are given, then ReLU when relu != 0) for m < m_valid: columns
  * n < n_split go to out0 (bias0), the others to out1 (bias1) at column n - n_split; row stride ld_out.
  * M a multiple of tile_m (128 or 256), N and n_split multiples of 256, K of 16.  Only rows < m_valid and, of

@@ -37,7 +37,7 @@ __device__ __forceinline__ void sg_split(float x, __bf16 (&b)[3]) {
     b[2] = (__bf16)r2;
 }
 
-__device__ __forceinline__ void sg_emit(const float (&v)[8], char* dst) {
+__device__ __forceinline__ void sg_emit(const float (&v)[8], char* dst, int parts = 3) {
     sg_frag p[3];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -48,7 +48,8 @@ __device__ __forceinline__ void sg_emit(const float (&v)[8], char* dst) {
         p[2][e] = b[2];
     }
 #pragma unroll
-    for (int s = 0; s < 3; ++s) *reinterpret_cast<sg_frag*>(dst + s * SG_FRAG) = p[s];
+    for (int s = 0; s < 3; ++s)
+        if (s < parts) *reinterpret_cast<sg_frag*>(dst + s * SG_FRAG) = p[s];
 }
 
 // src [R][ld] fp32, K columns used -> tiled parts, operand row = src row, k = src column (ceil(K/16) k
@@ -94,9 +95,14 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict
 // src [Kd][ld] fp32, R columns used -> tiled parts with operand row = src COLUMN and k = src row (the
 // transposed operand of a weight-gradient product).  One workgroup: 64 src rows x 32 src columns
 // through LDS; k beyond Kd is written as zeros (the tiled operand holds ceil(Kd/16) steps).
+// gate (same shape and row stride as src, or NULL): an entry counts only where its gate is positive - the
+// ReLU backward of a layer whose outputs are the gate, done while its output gradient is split.  ones_col:
+// operand row R (one past the source's columns) is all ones over k < Kd, so that the product's row R is
+// the column sum of the other operand (a bias gradient).  parts: how many of the three parts are written.
 template <bool VEC>
-__global__ __launch_bounds__(256) void split_cols_kernel(const float* __restrict__ src, int Kd, int R, long ld,
-                                                         int row_tile0, int KS, char* __restrict__ out) {
+__global__ __launch_bounds__(256) void split_cols_kernel(const float* __restrict__ src, const float* __restrict__ gate,
+                                                         int Kd, int R, long ld, int ones_col, int parts, int row_tile0,
+                                                         int KS, char* __restrict__ out) {
     __shared__ float tile[64][33];
     const int rt = blockIdx.x, kb = blockIdx.y * 64;
     {
@@ -106,12 +112,26 @@ __global__ __launch_bounds__(256) void split_cols_kernel(const float* __restrict
             const int kk = kb + pass * 32 + rr, col = rt * 32 + c4;
             sg_v4 a = {0.0f, 0.0f, 0.0f, 0.0f};
             if (kk < Kd) {
-                if (VEC && col + 3 < R) a = *reinterpret_cast<const sg_v4*>(src + (long)kk * ld + col);
-                else {
-                    if (col + 3 < R) a.w = src[(long)kk * ld + col + 3];
-                    if (col < R) a.x = src[(long)kk * ld + col];
-                    if (col + 1 < R) a.y = src[(long)kk * ld + col + 1];
-                    if (col + 2 < R) a.z = src[(long)kk * ld + col + 2];
+                if (VEC && col + 3 < R) {
+                    a = *reinterpret_cast<const sg_v4*>(src + (long)kk * ld + col);
+                    if (gate) {
+                        const sg_v4 y = *reinterpret_cast<const sg_v4*>(gate + (long)kk * ld + col);
+                        a.x = y.x > 0.0f ? a.x : 0.0f;
+                        a.y = y.y > 0.0f ? a.y : 0.0f;
+                        a.z = y.z > 0.0f ? a.z : 0.0f;
+                        a.w = y.w > 0.0f ? a.w : 0.0f;
+                    }
+                } else {
+                    float* av = reinterpret_cast<float*>(&a);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (col + e < R) {
+                            const float v = src[(long)kk * ld + col + e];
+                            av[e] = (gate && !(gate[(long)kk * ld + col + e] > 0.0f)) ? 0.0f : v;
+                        } else if (ones_col && col + e == R) {
+                            av[e] = 1.0f;
+                        }
+                    }
                 }
             }
             tile[pass * 32 + rr][c4] = a.x;
@@ -127,7 +147,7 @@ __global__ __launch_bounds__(256) void split_cols_kernel(const float* __restrict
     float v[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = tile[q * 8 + e][r];
-    sg_emit(v, out + ((long)(row_tile0 + rt) * KS + ks) * SG_STEP + h * 512 + r * 16);
+    sg_emit(v, out + ((long)(row_tile0 + rt) * KS + ks) * SG_STEP + h * 512 + r * 16, parts);
 }
 
 // ---- the product ----
@@ -307,22 +327,28 @@ int mdnvae_split_rows(const float* src, long R, long K, long ld, long row_tile0,
     return 0;
 }
 
-int mdnvae_split_cols(const float* src, long Kd, long R, long ld, long row_tile0, void* out, void* stream) {
+int mdnvae_split_cols_gated(const float* src, const float* gate, long Kd, long R, long ld, int ones_row, int parts,
+                            long row_tile0, void* out, void* stream) {
     MV_REQUIRE(R >= 0 && Kd >= 0 && ld >= R && row_tile0 >= 0, E_ARG, "mdnvae_split_cols: bad shape");
+    MV_REQUIRE(parts >= 1 && parts <= 3, E_ARG, "mdnvae_split_cols: parts must be 1, 2 or 3");
     if (R == 0 || Kd == 0) return 0;
     MV_REQUIRE(src && out, E_ARG, "mdnvae_split_cols: null pointer");
     MV_REQUIRE(aligned16(out), E_ALIGN, "mdnvae_split_cols: the operand must be 16-byte aligned");
-    const long rt = (R + 31) / 32, kb = (Kd + 63) / 64, KS = (Kd + 15) / 16;
+    const long rt = (R + (ones_row ? 1 : 0) + 31) / 32, kb = (Kd + 63) / 64, KS = (Kd + 15) / 16;
     MV_REQUIRE(rt <= 0x7fffffffL && kb <= 65535, E_SHAPE, "mdnvae_split_cols: shape too large for one launch");
-    const bool vec = ld % 4 == 0 && aligned16(src);
+    const bool vec = ld % 4 == 0 && aligned16(src) && (!gate || aligned16(gate));
     if (vec)
         hipLaunchKernelGGL(split_cols_kernel<true>, dim3((unsigned)rt, (unsigned)kb), dim3(256), 0, (hipStream_t)stream, src,
-                           (int)Kd, (int)R, ld, (int)row_tile0, (int)KS, (char*)out);
+                           gate, (int)Kd, (int)R, ld, ones_row ? 1 : 0, parts, (int)row_tile0, (int)KS, (char*)out);
     else
         hipLaunchKernelGGL(split_cols_kernel<false>, dim3((unsigned)rt, (unsigned)kb), dim3(256), 0, (hipStream_t)stream, src,
-                           (int)Kd, (int)R, ld, (int)row_tile0, (int)KS, (char*)out);
+                           gate, (int)Kd, (int)R, ld, ones_row ? 1 : 0, parts, (int)row_tile0, (int)KS, (char*)out);
     MV_LAUNCH_CHECK("split_cols_kernel");
     return 0;
+}
+
+int mdnvae_split_cols(const float* src, long Kd, long R, long ld, long row_tile0, void* out, void* stream) {
+    return mdnvae_split_cols_gated(src, nullptr, Kd, R, ld, 0, 3, row_tile0, out, stream);
 }
 
 int mdnvae_split_gemm(const void* a, const void* b, long M, long N, long K, long m_valid, long n_valid,

@@ -507,38 +507,45 @@ class _SymLinearPair(torch.autograd.Function):
         w1, b1, w2, b2 = ctx.params
         B, T = xt.shape
         H, n, dev = y1.shape[1], ctx.n_nodes, xt.device
-        gpre = []
-        for y, g in ((y1, g1), (y2, g2)):
-            gp = torch.empty_like(y)
-            call("mdnvae_act_bwd", ptr(y), ptr(_c(g)), ptr(gp), gp.numel(), ACTS["relu"], stream())
-            gpre.append(gp)
-        gws = [None, None]
-        if ctx.needs_input_grad[1] or ctx.needs_input_grad[3]:
-            Kp = _round_up(B, 16)
-            pb = _split_operand(2 * H, Kp, dev)
-            for i, gp in enumerate(gpre):
-                call("mdnvae_split_cols", ptr(gp), B, H, H, i * (H // 32), pb.data_ptr(), stream())
-            Tp = _round_up(T, 128)
-            xb = _split_operand(Tp, Kp, dev)
-            call("mdnvae_split_cols", ptr(xt), B, T, T, 0, xb.data_ptr(), stream())
-            gts = [torch.empty(T, H, dtype=torch.float32, device=dev) for _ in range(2)]
-            call("mdnvae_split_gemm", xb.data_ptr(), pb.data_ptr(), Tp, 2 * H, Kp, T, H, None, None, 0, 0, ptr(gts[0]),
-                 ptr(gts[1]), H, H, 128, SPLIT_WGRAD_TERMS, stream())
-            for i, (param, gt) in enumerate(((w1, gts[0]), (w2, gts[1]))):
-                if not ctx.needs_input_grad[1 + 2 * i]:
-                    continue
-                target = _grad_target(param)
-                if target is not None and _SINK.folded is not None:
-                    _SINK.folded(param, gt, n)
-                elif target is not None:
-                    call("mdnvae_tri_unfold", ptr(gt), H, n, H, 1, ptr(target), 1, stream())
-                    _grad_added(param)
+        gws, gbs = [None, None], [None, None]
+        if not any(ctx.needs_input_grad[1:5]):
+            return None, None, None, None, None, None
+        # One product gives both folded weight gradients and both bias gradients: its operands are x^T with a
+        # row of ones appended (so that row T of the result is the column sum of grad_pre) and grad_pre^T,
+        # which is split straight from the output gradients with the ReLU gate applied on the way
+        # (grad_pre itself is never written)
+        parts = 2 if SPLIT_WGRAD_TERMS == 3 else 3
+        Kp = _round_up(B, 16)
+        pb = _split_operand(2 * H, Kp, dev)
+        for i, (y, g) in enumerate(((y1, g1), (y2, g2))):
+            call("mdnvae_split_cols_gated", ptr(_c(g)), ptr(y), B, H, H, 0, parts, i * (H // 32), pb.data_ptr(), stream())
+        Tp = _round_up(T + 1, 128)
+        xb = _split_operand(Tp, Kp, dev)
+        call("mdnvae_split_cols_gated", ptr(xt), None, B, T, T, 1, parts, 0, xb.data_ptr(), stream())
+        gts = [torch.empty(T + 1, H, dtype=torch.float32, device=dev) for _ in range(2)]
+        call("mdnvae_split_gemm", xb.data_ptr(), pb.data_ptr(), Tp, 2 * H, Kp, T + 1, H, None, None, 0, 0, ptr(gts[0]),
+             ptr(gts[1]), H, H, 128, SPLIT_WGRAD_TERMS, stream())
+        for i, (param, bias) in enumerate(((w1, b1), (w2, b2))):
+            gt, gb = gts[i][:T], gts[i][T]
+            if ctx.needs_input_grad[2 + 2 * i]:
+                target = _grad_target(bias)
+                if target is not None:
+                    target.add_(gb)
+                    _grad_added(bias)
                 else:
-                    gws[i] = torch.empty(H, n * n, dtype=torch.float32, device=dev)
-                    call("mdnvae_tri_unfold", ptr(gt), H, n, H, 1, ptr(gws[i]), 0, stream())
-        gb1 = _bias_grad(gpre[0], b1) if ctx.needs_input_grad[2] else None
-        gb2 = _bias_grad(gpre[1], b2) if ctx.needs_input_grad[4] else None
-        return None, gws[0], gb1, gws[1], gb2, None
+                    gbs[i] = gb
+            if not ctx.needs_input_grad[1 + 2 * i]:
+                continue
+            target = _grad_target(param)
+            if target is not None and _SINK.folded is not None:
+                _SINK.folded(param, gt, n)
+            elif target is not None:
+                call("mdnvae_tri_unfold", ptr(gt), H, n, H, 1, ptr(target), 1, stream())
+                _grad_added(param)
+            else:
+                gws[i] = torch.empty(H, n * n, dtype=torch.float32, device=dev)
+                call("mdnvae_tri_unfold", ptr(gt), H, n, H, 1, ptr(gws[i]), 0, stream())
+        return None, gws[0], gbs[0], gws[1], gbs[1], None
 
 
 def sym_linear_pair(x_tri, w1, b1, w2, b2, n_nodes):
