@@ -262,7 +262,10 @@ int mdnvae_split_cols_gated(const float* src, const float* gate, long Kd, long R
 /* out[m][n] = sum_k a[m][k] b[n][k] (+ bias[n] when biases are given, then ReLU when relu != 0) for m < m_valid: columns
  * n < n_split go to out0 (bias0), the others to out1 (bias1) at column n - n_split; row stride ld_out.
  * M a multiple of tile_m (128 or 256), N and n_split multiples of 256, K of 16.  Only rows < m_valid and, of
- * each output, columns < n_valid are stored; accumulate = 1 adds to what the output holds (no ReLU then).
+ * each output, columns < n_valid are stored; accumulate = 1 adds to what the output holds (no ReLU then);
+ * accumulate = 2 does so with the k range split over two workgroups per tile that add atomically (for products
+ * with few output tiles and a long k; the output must hold zeros or the value to add to - two addends on top
+ * of it, so the result does not depend on their order).
  * terms = 6: all six bf16 products of the three-part operands (error 2^-24 of |a||b|, one fp32 rounding);
  * terms = 3: a1 b1 + a1 b2 + a2 b1 only (error up to 3 * 2^-16 per product, for weight gradients, which
  * nothing downstream amplifies), at half the matrix-core work. */

@@ -181,10 +181,15 @@ __global__ __launch_bounds__(512) void split_gemm_kernel(const char* __restrict_
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = wid >> 2, wn = wid & 3;
     // tiles of one XCD (blocks g, g+8, ...) are consecutive: they share A row tiles through its L2
-    const int ntiles = ntm * ntn;
+    // accumulate == 2: the k range is split over two workgroups per tile, both add their share atomically
+    const int ksplit = accumulate == 2 ? 2 : 1;
+    const int ntiles = ntm * ntn * ksplit;
     int tl = blockIdx.x;
     if ((ntiles & 7) == 0) tl = (blockIdx.x & 7) * (ntiles >> 3) + (blockIdx.x >> 3);
-    const int tm = tl / ntn, tn = tl - tm * ntn;
+    const int tm = tl / (ntn * ksplit), tns = tl - tm * ntn * ksplit;
+    const int tn = tns / ksplit, sk = tns - tn * ksplit;
+    const int ks_per = ((KS + ksplit - 1) / ksplit + KB - 1) / KB * KB;
+    const int ks_begin = sk * ks_per, ks_end = min(KS, ks_begin + ks_per);
 
     // this wave's staging pieces: piece q = wid + 8 i is part (q % NPART) of fragment row-tile
     // (q / NPART) % (TA + TB) of k step q / (NPART (TA + TB)) of the stage
@@ -204,7 +209,7 @@ __global__ __launch_bounds__(512) void split_gemm_kernel(const char* __restrict_
     auto stage = [&](int buf, int ks) {
 #pragma unroll
         for (int i = 0; i < PPW; ++i) {
-            if ((PIECES % 8 == 0 || wid + 8 * i < PIECES) && (KB == 1 || ks + kof[i] < KS))
+            if ((PIECES % 8 == 0 || wid + 8 * i < PIECES) && (KB == 1 || ks + kof[i] < ks_end))
                 __builtin_amdgcn_global_load_lds(SG_GLOBAL_PTR(src[i] + (long)ks * SG_STEP),
                                                  SG_LDS_PTR(smem + buf * STAGE + dst[i]), 16, 0, 0);
         }
@@ -230,14 +235,14 @@ __global__ __launch_bounds__(512) void split_gemm_kernel(const char* __restrict_
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
-    stage(0, 0);
+    stage(0, ks_begin);
     __syncthreads();
     int buf = 0;
-    for (int ks = 0; ks < KS; ks += KB, buf ^= 1) {
-        if (ks + KB < KS) stage(buf ^ 1, ks + KB);
+    for (int ks = ks_begin; ks < ks_end; ks += KB, buf ^= 1) {
+        if (ks + KB < ks_end) stage(buf ^ 1, ks + KB);
 #pragma unroll
         for (int kk = 0; kk < KB; ++kk) {
-            if (KB > 1 && ks + kk >= KS) break;
+            if (KB > 1 && ks + kk >= ks_end) break;
             const char* sa = smem + buf * STAGE + kk * KSTAGE + (wm * WM) * FSTEP + lane * 16;
             const char* sb = smem + buf * STAGE + kk * KSTAGE + (TA + wn * 2) * FSTEP + lane * 16;
             // B fragments and the first A row tile, then A row tile i + 1 is fetched while the MFMAs of
@@ -279,6 +284,22 @@ __global__ __launch_bounds__(512) void split_gemm_kernel(const char* __restrict_
     // column lane & 31.  A tile that lies wholly inside the valid rows stores without per-row tests.
     // n_valid counts columns of the selected output; accumulate adds to what the output holds
     const bool whole = (tm * TA + wm * WM + WM) * 32 <= m_valid && n_base + 64 <= n_valid && !accumulate;
+    if (accumulate == 2) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n_base + j * 32 + (lane & 31);
+#pragma unroll
+            for (int i = 0; i < WM; ++i) {
+                const int m0 = (tm * TA + wm * WM + i) * 32 + 4 * (lane >> 5);
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int m = m0 + (e & 3) + 8 * (e >> 2);
+                    if (m < m_valid && n < n_valid) unsafeAtomicAdd(out + n + (long)m * ld_out, acc[i][j][e]);
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int n = n_base + j * 32 + (lane & 31);
@@ -357,6 +378,7 @@ int mdnvae_split_gemm(const void* a, const void* b, long M, long N, long K, long
     MV_REQUIRE(terms == 6 || terms == 3, E_ARG, "mdnvae_split_gemm: terms must be 6 (every product down to 2^-24) or 3");
     MV_REQUIRE(M >= 1 && N >= 1 && K >= 16 && m_valid >= 0 && m_valid <= M, E_ARG, "mdnvae_split_gemm: bad shape");
     MV_REQUIRE(n_valid >= 0 && n_valid <= n_split, E_ARG, "mdnvae_split_gemm: n_valid counts columns of one output (at most n_split)");
+    MV_REQUIRE(accumulate >= 0 && accumulate <= 2, E_ARG, "mdnvae_split_gemm: accumulate is 0, 1 or 2");
     MV_REQUIRE(!(relu && accumulate), E_ARG, "mdnvae_split_gemm: the bias + ReLU epilogue does not accumulate");
     MV_REQUIRE(tile_m == 256 || tile_m == 128, E_ARG, "mdnvae_split_gemm: tile_m must be 128 or 256");
     MV_REQUIRE(M % tile_m == 0 && N % 256 == 0 && K % 16 == 0, E_SHAPE,
@@ -389,7 +411,7 @@ int mdnvae_split_gemm(const void* a, const void* b, long M, long N, long K, long
                        hipGetErrorString(e));                                                                       \
             raised = true;                                                                                          \
         }                                                                                                           \
-        hipLaunchKernelGGL((split_gemm_kernel<WM, EPI, TERMS>), dim3((unsigned)(ntm * ntn)), dim3(512), lds, st,    \
+        hipLaunchKernelGGL((split_gemm_kernel<WM, EPI, TERMS>), dim3((unsigned)(ntm * ntn * (accumulate == 2 ? 2 : 1))), dim3(512), lds, st, \
                            (const char*)a, (const char*)b, KS, (int)ntm, (int)ntn, (int)m_valid, bias0, bias1,      \
                            out0, out1 ? out1 : out0, (int)n_split, ld_out, (int)n_valid, accumulate);               \
     } while (0)

@@ -267,6 +267,7 @@ SPLIT_LINEAR = True
 # fp32 rounding); 3 keeps x1 w1 + x1 w2 + x2 w1 and drops terms of relative size <= 2^-16 each - about
 # 1e-5 of the gradient's norm, inside the 1e-4 the gradients are held to, at half the matrix-core work.  A
 # weight gradient feeds the optimiser only: nothing downstream amplifies its error, unlike an activation's.
+SPLIT_WGRAD_KSPLIT = not os.environ.get("MDNVAE_SPLIT_WGRAD_NO_KSPLIT")     # tuning knob
 SPLIT_WGRAD_TERMS = int(os.environ.get("MDNVAE_SPLIT_WGRAD_TERMS", "3"))
 if SPLIT_WGRAD_TERMS not in (3, 6):
     raise RuntimeError("MDNVAE_SPLIT_WGRAD_TERMS must be 3 or 6")
@@ -519,14 +520,21 @@ class _SymLinearPair(torch.autograd.Function):
         pb = _split_operand(2 * H, Kp, dev)
         for i, (y, g) in enumerate(((y1, g1), (y2, g2))):
             call("mdnvae_split_cols_gated", ptr(_c(g)), ptr(y), B, H, H, 0, parts, i * (H // 32), pb.data_ptr(), stream())
-        Tp = _round_up(T + 1, 128)
+        # the row of ones goes where the packed triangle's zero padding starts (one past the end if there is none)
+        t_real = min(n * (n + 1) // 2, T)
+        rows = max(T, t_real + 1)
+        # few output tiles and a long k (the batch): 256-row tiles with the k range split in two keep twice
+        # the fragments in registers per LDS byte read
+        halves = SPLIT_WGRAD_TERMS == 3 and SPLIT_WGRAD_KSPLIT and B >= 4096 and (rows + 255) // 256 * (2 * H // 256) <= 128
+        tile = 256 if halves else 128
+        Tp = _round_up(rows, tile)
         xb = _split_operand(Tp, Kp, dev)
-        call("mdnvae_split_cols_gated", ptr(xt), None, B, T, T, 1, parts, 0, xb.data_ptr(), stream())
-        gts = [torch.empty(T + 1, H, dtype=torch.float32, device=dev) for _ in range(2)]
-        call("mdnvae_split_gemm", xb.data_ptr(), pb.data_ptr(), Tp, 2 * H, Kp, T + 1, H, None, None, 0, 0, ptr(gts[0]),
-             ptr(gts[1]), H, H, 128, SPLIT_WGRAD_TERMS, stream())
+        call("mdnvae_split_cols_gated", ptr(xt), None, B, t_real, T, 1, parts, 0, xb.data_ptr(), stream())
+        gts = [(torch.zeros if halves else torch.empty)(rows, H, dtype=torch.float32, device=dev) for _ in range(2)]
+        call("mdnvae_split_gemm", xb.data_ptr(), pb.data_ptr(), Tp, 2 * H, Kp, t_real + 1, H, None, None, 0,
+             2 if halves else 0, ptr(gts[0]), ptr(gts[1]), H, H, tile, SPLIT_WGRAD_TERMS, stream())
         for i, (param, bias) in enumerate(((w1, b1), (w2, b2))):
-            gt, gb = gts[i][:T], gts[i][T]
+            gt, gb = gts[i][:t_real], gts[i][t_real]
             if ctx.needs_input_grad[2 + 2 * i]:
                 target = _grad_target(bias)
                 if target is not None:
@@ -600,12 +608,13 @@ class _LinearPair(torch.autograd.Function):
             xb = _split_operand(Np, Kp, dev)
             tail = (D + 31) // 32 * (Kp // 16) * 3072          # operand row tiles past D: zero (their columns are not stored)
             xb[tail:].zero_()
-            call("mdnvae_split_cols", ptr(x), B, D, D, 0, xb.data_ptr(), stream())
+            parts = 2 if SPLIT_WGRAD_TERMS == 3 else 3
+            call("mdnvae_split_cols_gated", ptr(x), None, B, D, D, 0, parts, 0, xb.data_ptr(), stream())
             pb = _split_operand(H, Kp, dev)
             for i, (param, gp) in enumerate(((w1, gpre[0]), (w2, gpre[1]))):
                 if not ctx.needs_input_grad[1 + 2 * i]:
                     continue
-                call("mdnvae_split_cols", ptr(gp), B, H, H, 0, pb.data_ptr(), stream())
+                call("mdnvae_split_cols_gated", ptr(gp), None, B, H, H, 0, parts, 0, pb.data_ptr(), stream())
                 target = _grad_target(param)
                 out = target if target is not None else torch.empty(H, D, dtype=torch.float32, device=dev)
                 call("mdnvae_split_gemm", pb.data_ptr(), xb.data_ptr(), H, Np, Kp, H, D, None, None, 0, int(target is not None),
