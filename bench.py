@@ -219,12 +219,15 @@ ABI_TAGS.update({
     "mdnvae_split_rows": ("split_rows_kernel", lambda a: 10.0 * a[1] * a[2]),
     "mdnvae_split_cols": ("split_cols_kernel", lambda a: 10.0 * a[1] * a[2]),
     # (src, gate, Kd, R, ld, ones_row, parts, ...): the source (and its gate) in, `parts` bf16 parts out
+    # (gpre, w, dense, gate, Kd, R, J, parts, ...): grad_pre and the gate in (+ the addend), `parts` bf16 parts out
+    "mdnvae_split_cols_dgrad": ("split_cols_dgrad_kernel",
+                                lambda a: a[4] * (4.0 * a[6] + (4.0 + (4.0 if a[2] is not None else 0.0) + 2.0 * a[7]) * a[5])),
     "mdnvae_split_cols_gated": ("split_cols_kernel", lambda a: (4.0 + (4.0 if a[1] is not None else 0.0) + 2.0 * a[6]) * a[2] * a[3]),
     # (y, grad_y, grad_pre, n, act): two reads, one write
     "mdnvae_act_bwd": ("act_bwd_kernel", lambda a: 12.0 * a[3]),
     "mdnvae_tri_fold": ("tri_pack_kernel<fold>", lambda a: 4.0 * a[1] * (a[2] * a[2] + a[2] * (a[2] + 1) // 2)),
 })
-HBM_TAGS |= {"split_rows_kernel", "split_cols_kernel", "act_bwd_kernel", "tri_pack_kernel<fold>"}
+HBM_TAGS |= {"split_rows_kernel", "split_cols_kernel", "split_cols_dgrad_kernel", "act_bwd_kernel", "tri_pack_kernel<fold>"}
 # bf16 matrix-core work: (a, b, M, N, K, m_valid, ...) executes six bf16 MFMA products per fp32 multiply-add
 BF16_TAGS = {"split_gemm_kernel", "split_gemm_kernel<3 terms>", "conv_bf16_kernel", "conv_wgrad_bf16_kernel"}
 # kernels that reach fp32 accuracy with several bf16 products per multiply: rated in fp32-equivalent

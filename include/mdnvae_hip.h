@@ -259,6 +259,13 @@ int mdnvae_split_cols(const float* src, long Kd, long R, long ld, long row_tile0
  * other one (a bias gradient).  parts (1..3): how many bf16 parts are written (2 for a three-term product). */
 int mdnvae_split_cols_gated(const float* src, const float* gate, long Kd, long R, long ld, int ones_row, int parts,
                             long row_tile0, void* out, void* stream);
+/* The same operand when the output gradient is itself the data gradient of the next dense layer
+ * (function/MM_Gate.py:159-160, fc111 / fc222 on the outputs of fc11 / fc12): operand[row_tile0 * 32 + c][r] =
+ * gate[r][c] > 0 ? (gpre . w)[r][c] + dense[r][c] : 0 with gpre [Kd][J], w [J][R] (the next layer's weight as
+ * stored), dense [Kd][R] or NULL, gate [Kd][R]; J is 64 or 128, R a multiple of 4.  The product runs on the
+ * fp32 matrix cores inside the splitting pass; the [Kd][R] gradient is never written. */
+int mdnvae_split_cols_dgrad(const float* gpre, const float* w, const float* dense, const float* gate, long Kd, long R,
+                            long J, int parts, long row_tile0, void* out, void* stream);
 /* out[m][n] = sum_k a[m][k] b[n][k] (+ bias[n] when biases are given, then ReLU when relu != 0) for m < m_valid: columns
  * n < n_split go to out0 (bias0), the others to out1 (bias1) at column n - n_split; row stride ld_out.
  * M a multiple of tile_m (128 or 256), N and n_split multiples of 256, K of 16.  Only rows < m_valid and, of

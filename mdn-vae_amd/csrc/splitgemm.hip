@@ -150,6 +150,115 @@ __global__ __launch_bounds__(256) void split_cols_kernel(const float* __restrict
     sg_emit(v, out + ((long)(row_tile0 + rt) * KS + ks) * SG_STEP + h * 512 + r * 16, parts);
 }
 
+// The transposed split operand of the gradient of a layer's outputs y = relu(...) when that gradient is itself
+// a product: g [Kd][R] = gpre [Kd][J] . w [J][R] (+ dense [Kd][R] if given), the data gradient of the next
+// dense layer (function/MM_Gate.py:159-160: fc111 / fc222 after fc11 / fc12).  operand[row_tile0 * 32 + c][r] =
+// y[r][c] > 0 ? g[r][c] : 0 - the product, the ReLU gate and the split in one pass, g is never written.
+// One workgroup: 64 rows r x 64 columns c.  The w slice [J][64] sits in LDS; a wave owns 16 rows and forms
+// its 16 x 64 block on the fp32 matrix cores (v_mfma_f32_16x16x4_f32) with its gpre rows in registers:
+// lane (row, g) loads 16-byte pieces, so within a group of 16 j the lane's four values are j = 4 g + e, and
+// the reduction runs in that order on both operands.  The block then crosses to the column-major emit
+// through an LDS tile, where gate and addend are read as 128-byte row segments.
+typedef float sg_f4 __attribute__((ext_vector_type(4)));
+constexpr int DG_LDW = 68;        // row stride of the w slice: 16-byte rows, k groups on different banks
+template <int J>
+__global__ __launch_bounds__(256) void split_cols_dgrad_kernel(const float* __restrict__ gpre, const float* __restrict__ w,
+                                                               const float* __restrict__ dense,
+                                                               const float* __restrict__ gate, int Kd, int R, int parts,
+                                                               int row_tile0, int KS, char* __restrict__ out) {
+    static_assert(J % 16 == 0 && J <= 128, "the inner dimension runs in groups of 16; the w slice must fit static LDS");
+    __shared__ __attribute__((aligned(16))) float wsl[J * DG_LDW];
+    __shared__ float tile[64][65];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int c16 = lane & 15, g = lane >> 4;
+    const int c0 = blockIdx.y * 64;
+    // w[j][c0 .. c0 + 63] -> LDS, 16 bytes per thread and pass; it stays for all the row blocks this
+    // workgroup walks (blockIdx.x, blockIdx.x + gridDim.x, ...)
+    for (int i = t; i < J * 16; i += 256) {
+        const int j = i >> 4, q = (i & 15) * 4;
+        sg_f4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (c0 + q + 3 < R) v = *reinterpret_cast<const sg_f4*>(w + (long)j * R + c0 + q);
+        else {
+            float* vv = reinterpret_cast<float*>(&v);
+            for (int e = 0; e < 4; ++e)
+                if (c0 + q + e < R) vv[e] = w[(long)j * R + c0 + q + e];
+        }
+        *reinterpret_cast<sg_f4*>(wsl + j * DG_LDW + q) = v;
+    }
+    const int nrb = (Kd + 63) / 64;
+    // a wave's 16 rows of gpre (rows past the end: the last row, dropped at the emit)
+    sg_f4 a[J / 16];
+    auto load_a = [&](int rb) {
+        const int row = min(rb * 64 + wave * 16 + c16, Kd - 1);
+#pragma unroll
+        for (int i = 0; i < J / 16; ++i) a[i] = *reinterpret_cast<const sg_f4*>(gpre + (long)row * J + 16 * i + 4 * g);
+    };
+    load_a(blockIdx.x);
+    const int r = t & 31, q = t >> 5;                    // emit: q = (k step within the 64 rows, half)
+    for (int rb = blockIdx.x; rb < nrb; rb += gridDim.x) {
+        const int r0 = rb * 64;
+        // gate and addend of this block's emit: 128-byte row segments, issued before the product
+        float y[2][8], d[2][8];
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int c = c0 + half * 32 + r;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const long at = (long)min(r0 + q * 8 + e, Kd - 1) * R + (c < R ? c : 0);
+                y[half][e] = gate[at];
+                d[half][e] = dense ? dense[at] : 0.0f;
+            }
+        }
+        __syncthreads();                                 // the w slice is in; the previous block's emit is done
+        sg_f4 acc[4];
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) acc[ct] = sg_f4{0.0f, 0.0f, 0.0f, 0.0f};
+        // w values one group of 16 j (16 registers) ahead of the MFMAs that use them
+        float bv[2][16];
+        auto load_b = [&](int i, float (&bb)[16]) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) bb[e * 4 + ct] = wsl[(16 * i + 4 * g + e) * DG_LDW + ct * 16 + c16];
+        };
+        load_b(0, bv[0]);
+#pragma unroll
+        for (int i = 0; i < J / 16; ++i) {
+            if (i + 1 < J / 16) load_b(i + 1, bv[(i + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct)
+                    acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][e], bv[i & 1][e * 4 + ct], acc[ct], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (rb + (int)gridDim.x < nrb) load_a(rb + gridDim.x);       // the next block's rows, under the emit
+        // accumulator register rr of column tile ct: row 4 g + rr of the wave's 16, column 16 ct + c16
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) tile[wave * 16 + 4 * g + rr][ct * 16 + c16] = acc[ct][rr];
+        __syncthreads();
+        const int ks = (r0 >> 4) + (q >> 1), h = q & 1;
+        if (ks < KS) {
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int c = c0 + half * 32 + r;
+                if (c0 + half * 32 < R) {
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float gsum = tile[q * 8 + e][half * 32 + r] + d[half][e];
+                        v[e] = (c < R && r0 + q * 8 + e < Kd && y[half][e] > 0.0f) ? gsum : 0.0f;
+                    }
+                    sg_emit(v, out + ((long)(row_tile0 + blockIdx.y * 2 + half) * KS + ks) * SG_STEP + h * 512 + r * 16, parts);
+                }
+            }
+        }
+    }
+}
+
 // ---- the product ----
 // C [M][N] = sum_k A[m][k] B[n][k] over tiled, split operands.  Workgroup of 8 waves (2 x 4), output
 // tile (2 * WM * 32) x 256, wave tile (WM * 32) x 64; one k step (16) per barrier: the six MFMAs per
@@ -370,6 +479,29 @@ int mdnvae_split_cols_gated(const float* src, const float* gate, long Kd, long R
 
 int mdnvae_split_cols(const float* src, long Kd, long R, long ld, long row_tile0, void* out, void* stream) {
     return mdnvae_split_cols_gated(src, nullptr, Kd, R, ld, 0, 3, row_tile0, out, stream);
+}
+
+int mdnvae_split_cols_dgrad(const float* gpre, const float* w, const float* dense, const float* gate, long Kd, long R,
+                            long J, int parts, long row_tile0, void* out, void* stream) {
+    MV_REQUIRE(R >= 0 && Kd >= 0 && row_tile0 >= 0, E_ARG, "mdnvae_split_cols_dgrad: bad shape");
+    MV_REQUIRE(J == 64 || J == 128, E_SHAPE, "mdnvae_split_cols_dgrad: the inner dimension must be 64 or 128 (got %ld)", J);
+    MV_REQUIRE(parts >= 1 && parts <= 3, E_ARG, "mdnvae_split_cols_dgrad: parts must be 1, 2 or 3");
+    if (R == 0 || Kd == 0) return 0;
+    MV_REQUIRE(gpre && w && gate && out, E_ARG, "mdnvae_split_cols_dgrad: null pointer");
+    MV_REQUIRE(aligned16(out) && aligned16(gpre) && aligned16(w) && R % 4 == 0, E_ALIGN,
+               "mdnvae_split_cols_dgrad: 16-byte aligned operands and a column count that is a multiple of 4");
+    const long nrb = (Kd + 63) / 64, cb = (R + 63) / 64, KS = (Kd + 15) / 16;
+    MV_REQUIRE(cb <= 65535, E_SHAPE, "mdnvae_split_cols_dgrad: shape too large for one launch");
+    // three workgroups per CU, each keeping its slice of w for all the row blocks it walks
+    const long rb = nrb < (768 + cb - 1) / cb ? nrb : (768 + cb - 1) / cb;
+#define DG_LAUNCH(JJ)                                                                                                 \
+    hipLaunchKernelGGL(split_cols_dgrad_kernel<JJ>, dim3((unsigned)rb, (unsigned)cb), dim3(256), 0, (hipStream_t)stream, \
+                       gpre, w, dense, gate, (int)Kd, (int)R, parts, (int)row_tile0, (int)KS, (char*)out)
+    if (J == 64) DG_LAUNCH(64);
+    else DG_LAUNCH(128);
+#undef DG_LAUNCH
+    MV_LAUNCH_CHECK("split_cols_dgrad_kernel");
+    return 0;
 }
 
 int mdnvae_split_gemm(const void* a, const void* b, long M, long N, long K, long m_valid, long n_valid,

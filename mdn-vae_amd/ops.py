@@ -1,6 +1,7 @@
 """Autograd wrappers over the C ABI: each op's forward and backward are hand-written HIP
 kernels; nothing here computes on the host or falls back to eager PyTorch arithmetic."""
 import os
+import weakref
 
 import torch
 
@@ -329,6 +330,27 @@ def _split_linear_wgrad(gpre, x, param):
     return out
 
 
+class _FactoredGrad:
+    """Where the gradient of a tensor may be left as a product instead of being formed: the producer of y
+    (the first-layer pair) registers one per output, the dense layer that consumes y finds it at forward
+    time and, in its backward, hands over (grad_pre, weight) - its data gradient is grad_pre . weight - and
+    returns zeros that occupy no memory.  The producer's backward forms the product inside the pass that
+    needs it anyway (ReLU gate + operand split).  Anything else that flows back into y arrives the usual
+    way and is added."""
+    __slots__ = ("taken", "gpre", "weight", "__weakref__")
+
+    def __init__(self):
+        self.taken, self.gpre, self.weight = False, None, None
+
+
+_FACTORED_SLOTS = weakref.WeakValueDictionary()      # y.data_ptr() -> slot, alive as long as the producer's graph node
+FACTORED_DGRAD = not os.environ.get("MDNVAE_NO_FACTORED_DGRAD")     # tuning knob
+
+
+def _is_free_zeros(t):
+    return t is not None and t.dim() == 2 and t.stride() == (0, 0)
+
+
 class _LinearAct(torch.autograd.Function):
     """act(x @ W^T + b): the product is a rocBLAS GEMM - or, for large layers, the split-bf16 product -
     bias+activation and the backward's elementwise / column-sum parts are HIP kernels."""
@@ -349,6 +371,11 @@ class _LinearAct(torch.autograd.Function):
         ctx.act = act
         ctx.has_bias = bias is not None
         ctx.params = (weight, bias)              # the objects whose .grad a sink may add into
+        slot = _FACTORED_SLOTS.get(x.data_ptr()) if x.dim() == 2 else None
+        ctx.factored = None
+        if slot is not None and not slot.taken and weight.shape[0] in (64, 128) and weight.shape[1] % 4 == 0:
+            slot.taken = True
+            ctx.factored = slot
         return y
 
     @staticmethod
@@ -361,7 +388,10 @@ class _LinearAct(torch.autograd.Function):
         else:
             gpre = gy
         split = ctx.has_bias and _split_linear_ok(x, weight, ctx.params[1])
-        if ctx.needs_input_grad[0]:
+        if ctx.needs_input_grad[0] and ctx.factored is not None:
+            ctx.factored.gpre, ctx.factored.weight = _c(gpre), weight
+            gx = torch.zeros((), dtype=torch.float32, device=gy.device).expand(x.shape)
+        elif ctx.needs_input_grad[0]:
             gx = _split_linear_dgrad(_c(gpre), weight) if split else _library_gemm(gpre, weight)
         else:
             gx = None
@@ -500,6 +530,11 @@ class _SymLinearPair(torch.autograd.Function):
         ctx.save_for_backward(xt, y1, y2)
         ctx.n_nodes = n_nodes
         ctx.params = (w1, b1, w2, b2)
+        ctx.slots = None
+        if FACTORED_DGRAD and any(ctx.needs_input_grad[1:5]):
+            ctx.slots = (_FactoredGrad(), _FactoredGrad())
+            for y, slot in zip((y1, y2), ctx.slots):
+                _FACTORED_SLOTS[y.data_ptr()] = slot
         return y1, y2
 
     @staticmethod
@@ -511,6 +546,7 @@ class _SymLinearPair(torch.autograd.Function):
         gws, gbs = [None, None], [None, None]
         if not any(ctx.needs_input_grad[1:5]):
             return None, None, None, None, None, None
+        slots = ctx.slots or (None, None)
         # One product gives both folded weight gradients and both bias gradients: its operands are x^T with a
         # row of ones appended (so that row T of the result is the column sum of grad_pre) and grad_pre^T,
         # which is split straight from the output gradients with the ReLU gate applied on the way
@@ -518,8 +554,16 @@ class _SymLinearPair(torch.autograd.Function):
         parts = 2 if SPLIT_WGRAD_TERMS == 3 else 3
         Kp = _round_up(B, 16)
         pb = _split_operand(2 * H, Kp, dev)
-        for i, (y, g) in enumerate(((y1, g1), (y2, g2))):
-            call("mdnvae_split_cols_gated", ptr(_c(g)), ptr(y), B, H, H, 0, parts, i * (H // 32), pb.data_ptr(), stream())
+        for i, (y, g, slot) in enumerate(((y1, g1, slots[0]), (y2, g2, slots[1]))):
+            if slot is not None and slot.gpre is not None:
+                # the consuming layer left its data gradient as a product: formed here, under the gate
+                dense = None if _is_free_zeros(g) else _c(g)
+                call("mdnvae_split_cols_dgrad", ptr(slot.gpre), ptr(slot.weight), ptr(dense), ptr(y), B, H,
+                     slot.gpre.shape[1], parts, i * (H // 32), pb.data_ptr(), stream())
+                slot.gpre = slot.weight = None
+            else:
+                call("mdnvae_split_cols_gated", ptr(_c(g)), ptr(y), B, H, H, 0, parts, i * (H // 32), pb.data_ptr(),
+                     stream())
         # the row of ones goes where the packed triangle's zero padding starts (one past the end if there is none)
         t_real = min(n * (n + 1) // 2, T)
         rows = max(T, t_real + 1)

@@ -229,3 +229,52 @@ def test_large_dense_layer_on_the_split_product(act):
     for name, got, ref, bar in checks:
         err = float((got.double().cpu() - ref).abs().max() / ref.abs().max())
         assert err <= bar, (name, err)
+
+
+@pytest.mark.parametrize("B,n,J", [(1024, 68, 128), (1100, 87, 64)])
+def test_next_layer_data_gradient_is_formed_inside_the_operand_split(B, n, J, monkeypatch):
+    """The dense layer after the first-layer pair leaves its data gradient as (grad_pre, weight); the pair's
+    backward forms the product under the ReLU gate while it splits the operand (mdnvae_split_cols_dgrad).
+    Same towers with the protocol switched off must give the same gradients to fp32 rounding, and the
+    fused call must be the one that ran."""
+    torch.manual_seed(B + J)
+    H, D = 1024, n * n
+    x = M.data.synthetic_sc(B, n, seed=5, device=DEV)
+    w = [(torch.randn(H, D) / D ** 0.5).to(DEV).requires_grad_(True) for _ in range(2)]
+    b = [(torch.randn(H) * 0.05).to(DEV).requires_grad_(True) for _ in range(2)]
+    wa = [(torch.randn(J, H) / H ** 0.5).to(DEV).requires_grad_(True) for _ in range(2)]
+    ba = [(torch.randn(J) * 0.05).to(DEV).requires_grad_(True) for _ in range(2)]
+    up = [torch.randn(B, J, device=DEV) for _ in range(2)]
+    extra = torch.randn(B, H, device=DEV) * 0.1              # a second consumer of the first tower's output
+    asym = torch.zeros(1, dtype=torch.int32, device=DEV)
+    xt = ops.tri_pack(x, n, asym)
+    monkeypatch.setattr(ops, "SPLIT_WGRAD_TERMS", 6)
+
+    def run(factored, with_extra):
+        monkeypatch.setattr(ops, "FACTORED_DGRAD", factored)
+        for t in w + b + wa + ba:
+            t.grad = None
+        calls = []
+        orig = ops.call
+
+        def spy(name, *a):
+            calls.append(name)
+            return orig(name, *a)
+
+        monkeypatch.setattr(ops, "call", spy)
+        y = ops.sym_linear_pair(xt, w[0], b[0], w[1], b[1], n)
+        h = [ops.linear_act(y[i], wa[i], ba[i], "relu") for i in range(2)]
+        outs, ups = list(h), list(up)
+        if with_extra:
+            outs.append(y[0])
+            ups.append(extra)
+        torch.autograd.backward(outs, ups)
+        monkeypatch.setattr(ops, "call", orig)
+        return [t.grad.clone() for t in w + b + wa + ba], calls
+
+    for with_extra in (False, True):
+        got, calls = run(True, with_extra)
+        want, calls_plain = run(False, with_extra)
+        assert calls.count("mdnvae_split_cols_dgrad") == 2 and "mdnvae_split_cols_dgrad" not in calls_plain
+        for g_, w_ in zip(got, want):
+            assert float((g_ - w_).abs().max() / w_.abs().max()) <= 2e-6
