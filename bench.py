@@ -36,6 +36,11 @@ PEAK_HBM_GBPS = 8000.0
 TRAFFIC_RATIO = {"loss_stream_kernel": 1.00, "mdn_fwd_kernel": 1.10, "mdn_bwd_stream_kernel": 1.27,
                  "mdn_outer_kernel": 1.03, "tri_pack_kernel": 1.01, "adam_kernel": 1.00}
 
+# fabric-side bytes per launch of the matrix-core kernels, collected the same way at the default workload's shapes
+# (profiles/r02_e_mdn_gate_B16384_counters.csv); keyed by the launch's executed flops so that another shape reports null
+TRAFFIC_BYTES = {("split_gemm_kernel", 12.0 * 16384 * 2048 * 3840): (1207.6 + 208.7) * 1e6,
+                 ("split_gemm_kernel<3 terms>", 6.0 * 3829 * 2048 * 16384): (1454.4 + 66.7) * 1e6}
+
 REHEARSE_EXCHANGE = False
 
 MODELS = {
@@ -332,7 +337,7 @@ def kernel_table(clock, elapsed):
                             frac=rate / peak, launches=r["launches"], avg_ms=per_launch * 1e3,
                             share_of_step=r["seconds"] / elapsed,
                             traffic=(TRAFFIC_RATIO[tag] * r["work"] / max(r["launches"], 1)) if tag in TRAFFIC_RATIO
-                            else None)
+                            else TRAFFIC_BYTES.get((tag, r["work"] / max(r["launches"], 1))))
     return kernels
 
 
