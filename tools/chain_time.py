@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Timing decomposition of the chain decoder's forward kernel (debug knob MDNVAE_CHAIN_DBG)."""
+"""Device time of the chain decoder's forward kernel at a large batch (torch profiler), with and without
+the saved layer inputs a backward pass needs."""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -34,8 +35,6 @@ def time_kernel(grad, iters=20):
     return None, None
 
 
-for dbg in [0]:
-    os.environ["MDNVAE_CHAIN_DBG"] = str(dbg)
-    for grad in (True, False):
-        k, us = time_kernel(grad)
-        print(f"dbg={dbg:2d} save_rows={grad} {k} {us:.1f} us", flush=True)
+for grad in (True, False):
+    k, us = time_kernel(grad)
+    print(f"save_rows={grad} {k} {us:.1f} us", flush=True)
