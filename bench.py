@@ -242,6 +242,19 @@ SPLIT_PRODUCTS = {"conv_bf16x2_kernel": 3, "conv_bf16x3_kernel": 6, "conv_wgrad_
 # 2 * terms per fp32 multiply-add; the three-term form (weight gradients) is rated as a kernel of its own
 ABI_TAGS["mdnvae_split_gemm"] = (lambda a: "split_gemm_kernel" if a[16] == 6 else "split_gemm_kernel<3 terms>",
                                  lambda a: 2.0 * a[16] * a[5] * min(a[3], a[6] * (a[3] // a[13])) * a[4])
+# (a, b, absmax_a, absmax_b, M, N, K, m_valid, n_valid, ..., n_split at 15): three fp16 products per fp32 multiply-add
+ABI_TAGS["mdnvae_split_gemm_f16"] = ("split_gemm_kernel<3 fp16 terms>",
+                                     lambda a: 6.0 * a[7] * min(a[5], a[8] * (a[5] // a[15])) * a[6])
+BF16_TAGS.add("split_gemm_kernel<3 fp16 terms>")          # the fp16 matrix rate equals the bf16 one
+ABI_TAGS.update({
+    # (src, R, K, ld, ...): the fp32 source in, two fp16 parts out; (src, gate, Kd, R, ld, ...) likewise
+    "mdnvae_split_rows_f16": ("split_rows_kernel<fp16>", lambda a: 8.0 * a[1] * a[2]),
+    "mdnvae_split_cols_f16": ("split_cols_kernel<fp16>", lambda a: (8.0 + (4.0 if a[1] is not None else 0.0)) * a[2] * a[3]),
+    "mdnvae_absmax": ("absmax_kernel", lambda a: 4.0 * a[1] * a[2]),
+    "mdnvae_tri_pack_absmax": ("tri_pack_kernel", lambda a: 4.0 * a[1] * (a[2] * a[2] + a[2] * (a[2] + 1) // 2)),
+    "mdnvae_tri_fold_absmax": ("tri_pack_kernel<fold>", lambda a: 4.0 * a[1] * (a[2] * a[2] + a[2] * (a[2] + 1) // 2)),
+})
+HBM_TAGS |= {"split_rows_kernel<fp16>", "split_cols_kernel<fp16>", "absmax_kernel"}
 # matrix-core entry points with a fixed tag (work in flops; kept out of HBM_TAGS)
 ABI_TAGS.update({
     # (layer_in, layer_dpre, B, count, ...): one 96 x 96 x B product per (channel, layer)
@@ -518,9 +531,10 @@ def main():
                        # symmetric input, half the reference's multiply-adds; the like-for-like number without
                        # that shortcut is full_first_layer_value
                        "symmetric_first_layer": bool(args.model in ("mm_gate", "mdn_gate") and not args.full_first_layer),
-                       "first_layer_gemm": "split-bf16 MFMA (fp32-accurate), hand-written"
+                       "first_layer_gemm": ("two-part fp16 MFMA, 3 products (22-bit operands, fp32 accumulation), hand-written"
+                                            if ops.SPLIT_FWD == "f16" else "split-bf16 MFMA (fp32-accurate), hand-written")
                        if args.model in ("mm_gate", "mdn_gate") else "library fp32",
-                       # bf16 products per multiply-add: 6 in the forward product; the weight gradient's count
+                       # bf16 products per multiply-add in the weight gradient
                        # (3 = error about 1e-5 of the gradient's norm, bar 1e-4; MDNVAE_SPLIT_WGRAD_TERMS=6 for all)
                        "first_layer_wgrad_terms": ops.SPLIT_WGRAD_TERMS},
         }

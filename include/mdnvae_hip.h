@@ -280,6 +280,38 @@ int mdnvae_split_gemm(const void* a, const void* b, long M, long N, long K, long
                       const float* bias0, const float* bias1, int relu, int accumulate, float* out0, float* out1,
                       long n_split, long ld_out, int tile_m, int terms, void* stream);
 
+/* ---- the same products from two fp16 parts per operand ----------------------------------------
+ * Again self.fc11 / self.fc12 (function/MM_Gate.py:157-158) and every other large nn.Linear the split product
+ * serves (function/VAE_CNN_NN.py:187, function_FC_SC/SC-FC.py:95-113).  x 2^e = h + l with h = fp16(x 2^e),
+ * l = fp16(x 2^e - h) carries 22 significand bits, and h_a h_b + h_a l_b + l_a h_b is three fp16 matrix-core
+ * products (fp32 accumulation) - half the work of the six bf16 products - with an error of 3 * 2^-22 of
+ * sum |a||b| at most (measured: the level of an fp32 dot product).  fp16 has 30 binades, so each TENSOR is
+ * scaled by the power of two that brings its largest magnitude into [2^14, 2^15); entries more than 2^17
+ * below the tensor's largest lose low-part bits (absolute error below 2^-29 of the largest entry).  The
+ * largest magnitude lives on the device as the bit pattern of a float (`absmax`, one unsigned). */
+/* *absmax = max(*absmax, |floor_value|, largest |src[r][c]|), src [rows][ld], c < cols; reset != 0 clears the
+ * slot first (hipMemsetAsync on the stream).  Several tensors that share a scale are folded into one slot by
+ * consecutive calls with reset = 0. */
+int mdnvae_absmax(const float* src, long rows, long cols, long ld, float floor_value, int reset, unsigned* absmax,
+                  void* stream);
+/* mdnvae_tri_pack / mdnvae_tri_fold that also fold the largest magnitude they write into *absmax (cleared first
+ * when reset != 0), so the fp16 split of their output needs no pass of its own. */
+int mdnvae_tri_pack_absmax(const float* x, long B, int N, int ld, float* out, int* asym, int reset, unsigned* absmax,
+                           void* stream);
+int mdnvae_tri_fold_absmax(const float* w, long H, int N, int ld, float* out, int reset, unsigned* absmax, void* stream);
+/* mdnvae_split_rows / mdnvae_split_cols_gated writing the two fp16 parts of src * 2^e(*absmax); *absmax must
+ * be at least the largest magnitude of everything written into the operand (a row of ones included: give
+ * mdnvae_absmax floor_value = 1). */
+int mdnvae_split_rows_f16(const float* src, long R, long K, long ld, long row_tile0, const unsigned* absmax, void* out,
+                          void* stream);
+int mdnvae_split_cols_f16(const float* src, const float* gate, long Kd, long R, long ld, int ones_row, long row_tile0,
+                          const unsigned* absmax, void* out, void* stream);
+/* mdnvae_split_gemm on two such operands (three products); the epilogue divides by both scales before bias and
+ * ReLU.  Arguments as mdnvae_split_gemm. */
+int mdnvae_split_gemm_f16(const void* a, const void* b, const unsigned* absmax_a, const unsigned* absmax_b, long M, long N,
+                          long K, long m_valid, long n_valid, const float* bias0, const float* bias1, int relu,
+                          int accumulate, float* out0, float* out1, long n_split, long ld_out, int tile_m, void* stream);
+
 /* ---- conv / ResNet encoder ---------------------------------------------------------------
  * The ATen conv2d / instance_norm / relu / max_pool2d calls (and their autograd) of the encoder
  * stack, function/VAE_CNN_NN.py:83-98 (ResidualBlock), :110-137 (ec, max_pool), :155-159 (encode).

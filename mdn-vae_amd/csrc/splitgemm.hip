@@ -52,14 +52,80 @@ __device__ __forceinline__ void sg_emit(const float (&v)[8], char* dst, int part
         if (s < parts) *reinterpret_cast<sg_frag*>(dst + s * SG_FRAG) = p[s];
 }
 
+// ---- two fp16 parts instead of three bf16 parts ----
+// x 2^e = h + l with h = fp16(x 2^e) and l = fp16(x 2^e - h): 22 significand bits in two parts, so
+//     x w ~= h_x h_w + (h_x l_w + l_x h_w)
+// is three fp16 MFMA products (each exact, accumulated in fp32) that leave out l_x l_w <= 2^-22 |x w| and
+// carry each operand to 2^-22 of itself - four times an fp32 rounding - at half the matrix-core work of the
+// six bf16 products.  fp16 spans 30 binades, so every tensor is first multiplied by the power of two that
+// brings its largest magnitude into [2^14, 2^15) (exact; undone in the product's epilogue): an entry keeps
+// its 22 bits as long as it is within 2^-17 of the tensor's largest one, below that its low part thins out
+// and the absolute error stays under 2^-29 of the largest entry.
+typedef _Float16 sg_hfrag __attribute__((ext_vector_type(8)));
+
+// the power of two that brings a magnitude with bit pattern `bits` (the tensor's largest) into [2^14, 2^15)
+__device__ __forceinline__ float sg_pow2_scale(unsigned bits) {
+    const int e = (int)((bits >> 23) & 0xffu);
+    if (e == 0 || e == 255) return 1.0f;                 // all zeros (or subnormal), inf / nan: as it stands
+    const int se = 268 - e;                              // biased exponent of 2^(14 - (e - 127))
+    return __uint_as_float((unsigned)(se < 253 ? se : 253) << 23);
+}
+__device__ __forceinline__ float sg_pow2_unscale(unsigned bits) { return 1.0f / sg_pow2_scale(bits); }
+
+__device__ __forceinline__ void sg_emit_f16(const float (&v)[8], float s, char* dst) {
+    sg_hfrag hi, lo;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float t = v[e] * s;
+        const _Float16 h = (_Float16)t;
+        hi[e] = h;
+        lo[e] = (_Float16)(t - (float)h);
+    }
+    *reinterpret_cast<sg_hfrag*>(dst) = hi;
+    *reinterpret_cast<sg_hfrag*>(dst + SG_FRAG) = lo;
+}
+
+// *amax = max(*amax, largest |src[r][c]|) as a bit pattern (magnitudes order like their bit patterns; a NaN
+// orders above everything and so shows).  Flat over rows of `cols` floats with stride ld.
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ src, long rows, long cols, long ld,
+                                                     float floor_value, unsigned* __restrict__ amax) {
+    __shared__ unsigned part[4];
+    unsigned m = __float_as_uint(fabsf(floor_value));
+    const long n = rows * cols;
+    if (cols == ld && (cols & 3) == 0 && (reinterpret_cast<unsigned long>(src) & 15) == 0) {
+        const sg_v4* s4 = reinterpret_cast<const sg_v4*>(src);
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n / 4; i += (long)gridDim.x * 256) {
+            const sg_v4 v = __builtin_nontemporal_load(s4 + i);
+            m = max(max(m, __float_as_uint(v.x) & 0x7fffffffu), __float_as_uint(v.y) & 0x7fffffffu);
+            m = max(max(m, __float_as_uint(v.z) & 0x7fffffffu), __float_as_uint(v.w) & 0x7fffffffu);
+        }
+    } else {
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+            const long r = i / cols;
+            m = max(m, __float_as_uint(src[r * ld + (i - r * cols)]) & 0x7fffffffu);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        // only workgroups that hold something larger than the slot shows touch it: atomics on one address serialise
+        const unsigned mw = max(max(part[0], part[1]), max(part[2], part[3]));
+        if (mw > __hip_atomic_load(amax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(amax, mw);
+    }
+}
+
 // src [R][ld] fp32, K columns used -> tiled parts, operand row = src row, k = src column (ceil(K/16) k
 // steps, zero beyond K).  One workgroup: 32 rows x 64 columns; a thread owns 8 consecutive columns of one
 // row, which is one 16-byte chunk of each part.  Rows >= R are written as zeros.  VEC: K a multiple of
 // 16, rows 16-byte aligned - two 16-byte loads per thread.  Otherwise the 32 x 64 block goes through LDS:
 // consecutive lanes load consecutive floats, whatever the row stride and alignment.
+// amax != NULL: two fp16 parts of src scaled by the power of two *amax gives, instead of three bf16 parts.
 template <bool VEC>
 __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict__ src, int R, int K, long ld,
-                                                         int row_tile0, int KS, char* __restrict__ out) {
+                                                         int row_tile0, int KS, const unsigned* __restrict__ amax,
+                                                         char* __restrict__ out) {
     __shared__ float tile[VEC ? 1 : 32][VEC ? 1 : 65];
     const int rt = blockIdx.x, r = threadIdx.x >> 3, c = threadIdx.x & 7;
     const int k0 = blockIdx.y * 64 + c * 8;
@@ -89,7 +155,9 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict
         for (int e = 0; e < 8; ++e) v[e] = tile[r][c * 8 + e];
     }
     const int ks = k0 >> 4, h = (k0 >> 3) & 1;
-    sg_emit(v, out + ((long)(row_tile0 + rt) * KS + ks) * SG_STEP + h * 512 + r * 16);
+    char* dst = out + ((long)(row_tile0 + rt) * KS + ks) * SG_STEP + h * 512 + r * 16;
+    if (amax) sg_emit_f16(v, sg_pow2_scale(*amax), dst);
+    else sg_emit(v, dst);
 }
 
 // src [Kd][ld] fp32, R columns used -> tiled parts with operand row = src COLUMN and k = src row (the
@@ -102,7 +170,7 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict
 template <bool VEC>
 __global__ __launch_bounds__(256) void split_cols_kernel(const float* __restrict__ src, const float* __restrict__ gate,
                                                          int Kd, int R, long ld, int ones_col, int parts, int row_tile0,
-                                                         int KS, char* __restrict__ out) {
+                                                         int KS, const unsigned* __restrict__ amax, char* __restrict__ out) {
     __shared__ float tile[64][33];
     const int rt = blockIdx.x, kb = blockIdx.y * 64;
     {
@@ -147,7 +215,9 @@ __global__ __launch_bounds__(256) void split_cols_kernel(const float* __restrict
     float v[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = tile[q * 8 + e][r];
-    sg_emit(v, out + ((long)(row_tile0 + rt) * KS + ks) * SG_STEP + h * 512 + r * 16, parts);
+    char* dst = out + ((long)(row_tile0 + rt) * KS + ks) * SG_STEP + h * 512 + r * 16;
+    if (amax) sg_emit_f16(v, sg_pow2_scale(*amax), dst);
+    else sg_emit(v, dst, parts);
 }
 
 // The transposed split operand of the gradient of a layer's outputs y = relu(...) when that gradient is itself
@@ -271,12 +341,17 @@ enum { SG_EPI_BIAS_RELU = 0, SG_EPI_PLAIN = 1, SG_EPI_BIAS = 2 };
 
 // TERMS = 6: all products down to 2^-24 of the result.  TERMS = 3: x1 w1 + x1 w2 + x2 w1 only (what is left
 // out is 2^-16 of |x w| per term at most), the third part of neither operand is staged.
-template <int WM, int EPI, int TERMS>
+// F16 (with TERMS = 3): the operands hold two fp16 parts of power-of-two scaled tensors (sg_emit_f16) - h h + h l +
+// l h on the fp16 MFMA, the scales undone in the epilogue from the two tensors' largest magnitudes.
+template <int WM, int EPI, int TERMS, bool F16 = false>
 __global__ __launch_bounds__(512) void split_gemm_kernel(const char* __restrict__ A, const char* __restrict__ Bop,
+                                                         const unsigned* __restrict__ amax_a,
+                                                         const unsigned* __restrict__ amax_b,
                                                          int KS, int ntm, int ntn, int m_valid,
                                                          const float* __restrict__ bias0, const float* __restrict__ bias1,
                                                          float* __restrict__ out0, float* __restrict__ out1, int n_split,
                                                          long ld_out, int n_valid, int accumulate) {
+    static_assert(!F16 || TERMS == 3, "two fp16 parts make a three-term product");
     constexpr int TA = 2 * WM, TB = 8;                   // fragment rows-tiles of A / B per workgroup
     constexpr int NPART = TERMS == 6 ? 3 : 2;            // parts of a fragment that take part
     constexpr int KB = TERMS == 6 ? 1 : 2;               // k steps per barrier: about as many MFMAs either way
@@ -336,6 +411,18 @@ __global__ __launch_bounds__(512) void split_gemm_kernel(const char* __restrict_
         bv[1] = n_base + 32 + (lane & 31) < n_valid ? bias[n_base + 32 + (lane & 31)] : 0.0f;
     }
 
+    float unscale_a = 1.0f, unscale_b = 1.0f;
+    if (F16) {
+        unscale_a = sg_pow2_unscale(*amax_a);
+        unscale_b = sg_pow2_unscale(*amax_b);
+    }
+    auto mfma = [](const sg_frag& a, const sg_frag& b, const sg_acc& c) {
+        if constexpr (F16)
+            return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(sg_hfrag, a), __builtin_bit_cast(sg_hfrag, b), c, 0, 0, 0);
+        else
+            return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    };
+
     sg_acc acc[WM][2];
 #pragma unroll
     for (int i = 0; i < WM; ++i)
@@ -375,13 +462,13 @@ __global__ __launch_bounds__(512) void split_gemm_kernel(const char* __restrict_
                 for (int j = 0; j < 2; ++j) {
                     // smallest terms first
                     if (TERMS == 6) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i & 1][0], b[j][NPART - 1], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i & 1][1], b[j][1], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i & 1][NPART - 1], b[j][0], acc[i][j], 0, 0, 0);
+                        acc[i][j] = mfma(a[i & 1][0], b[j][NPART - 1], acc[i][j]);
+                        acc[i][j] = mfma(a[i & 1][1], b[j][1], acc[i][j]);
+                        acc[i][j] = mfma(a[i & 1][NPART - 1], b[j][0], acc[i][j]);
                     }
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i & 1][0], b[j][1], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i & 1][1], b[j][0], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i & 1][0], b[j][0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = mfma(a[i & 1][0], b[j][1], acc[i][j]);
+                    acc[i][j] = mfma(a[i & 1][1], b[j][0], acc[i][j]);
+                    acc[i][j] = mfma(a[i & 1][0], b[j][0], acc[i][j]);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -403,7 +490,8 @@ __global__ __launch_bounds__(512) void split_gemm_kernel(const char* __restrict_
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int m = m0 + (e & 3) + 8 * (e >> 2);
-                    if (m < m_valid && n < n_valid) unsafeAtomicAdd(out + n + (long)m * ld_out, acc[i][j][e]);
+                    if (m < m_valid && n < n_valid)
+                        unsafeAtomicAdd(out + n + (long)m * ld_out, F16 ? acc[i][j][e] * unscale_a * unscale_b : acc[i][j][e]);
                 }
             }
         }
@@ -420,6 +508,7 @@ __global__ __launch_bounds__(512) void split_gemm_kernel(const char* __restrict_
             for (int e = 0; e < 16; ++e) {
                 const int m = m0 + (e & 3) + 8 * (e >> 2);
                 float v = acc[i][j][e];
+                if (F16) v = v * unscale_a * unscale_b;
                 if (EPI == SG_EPI_BIAS_RELU) v = fmaxf(v + bv[j], 0.0f);
                 if (EPI == SG_EPI_BIAS) v += bv[j];
                 if (whole) col[(long)m * ld_out] = v;
@@ -439,7 +528,8 @@ size_t mdnvae_split_operand_bytes(long rows, long k) {
     return (size_t)(rt > 0 ? rt : 0) * (size_t)(ks > 0 ? ks : 0) * SG_STEP;
 }
 
-int mdnvae_split_rows(const float* src, long R, long K, long ld, long row_tile0, void* out, void* stream) {
+static int split_rows_impl(const float* src, long R, long K, long ld, long row_tile0, const unsigned* amax, void* out,
+                           void* stream) {
     MV_REQUIRE(R >= 0 && K >= 0 && ld >= K && row_tile0 >= 0, E_ARG, "mdnvae_split_rows: bad shape");
     if (R == 0 || K == 0) return 0;
     MV_REQUIRE(src && out, E_ARG, "mdnvae_split_rows: null pointer");
@@ -449,16 +539,43 @@ int mdnvae_split_rows(const float* src, long R, long K, long ld, long row_tile0,
     const bool vec = K % 16 == 0 && ld % 4 == 0 && aligned16(src);
     if (vec)
         hipLaunchKernelGGL(split_rows_kernel<true>, dim3((unsigned)rt, (unsigned)kb), dim3(256), 0, (hipStream_t)stream, src,
-                           (int)R, (int)K, ld, (int)row_tile0, (int)KS, (char*)out);
+                           (int)R, (int)K, ld, (int)row_tile0, (int)KS, amax, (char*)out);
     else
         hipLaunchKernelGGL(split_rows_kernel<false>, dim3((unsigned)rt, (unsigned)kb), dim3(256), 0, (hipStream_t)stream, src,
-                           (int)R, (int)K, ld, (int)row_tile0, (int)KS, (char*)out);
+                           (int)R, (int)K, ld, (int)row_tile0, (int)KS, amax, (char*)out);
     MV_LAUNCH_CHECK("split_rows_kernel");
     return 0;
 }
 
-int mdnvae_split_cols_gated(const float* src, const float* gate, long Kd, long R, long ld, int ones_row, int parts,
-                            long row_tile0, void* out, void* stream) {
+int mdnvae_split_rows(const float* src, long R, long K, long ld, long row_tile0, void* out, void* stream) {
+    return split_rows_impl(src, R, K, ld, row_tile0, nullptr, out, stream);
+}
+
+int mdnvae_split_rows_f16(const float* src, long R, long K, long ld, long row_tile0, const unsigned* absmax, void* out,
+                          void* stream) {
+    MV_REQUIRE(absmax, E_ARG, "mdnvae_split_rows_f16: the largest-magnitude slot is NULL");
+    return split_rows_impl(src, R, K, ld, row_tile0, absmax, out, stream);
+}
+
+int mdnvae_absmax(const float* src, long rows, long cols, long ld, float floor_value, int reset, unsigned* absmax,
+                  void* stream) {
+    MV_REQUIRE(rows >= 0 && cols >= 0 && ld >= cols, E_ARG, "mdnvae_absmax: bad shape");
+    MV_REQUIRE(absmax && (src || rows * cols == 0), E_ARG, "mdnvae_absmax: null pointer");
+    if (reset) {
+        const hipError_t e = hipMemsetAsync(absmax, 0, sizeof(unsigned), (hipStream_t)stream);
+        MV_REQUIRE(e == hipSuccess, (int)e, "mdnvae_absmax: cannot clear the slot: %s", hipGetErrorString(e));
+    }
+    const long n = rows * cols;
+    if (n == 0 && floor_value == 0.0f) return 0;
+    const long blocks = n / 4 / 256 / 4 + 1;
+    hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, (hipStream_t)stream, src,
+                       rows, cols, ld, floor_value, absmax);
+    MV_LAUNCH_CHECK("absmax_kernel");
+    return 0;
+}
+
+static int split_cols_impl(const float* src, const float* gate, long Kd, long R, long ld, int ones_row, int parts,
+                           long row_tile0, const unsigned* amax, void* out, void* stream) {
     MV_REQUIRE(R >= 0 && Kd >= 0 && ld >= R && row_tile0 >= 0, E_ARG, "mdnvae_split_cols: bad shape");
     MV_REQUIRE(parts >= 1 && parts <= 3, E_ARG, "mdnvae_split_cols: parts must be 1, 2 or 3");
     if (R == 0 || Kd == 0) return 0;
@@ -469,12 +586,23 @@ int mdnvae_split_cols_gated(const float* src, const float* gate, long Kd, long R
     const bool vec = ld % 4 == 0 && aligned16(src) && (!gate || aligned16(gate));
     if (vec)
         hipLaunchKernelGGL(split_cols_kernel<true>, dim3((unsigned)rt, (unsigned)kb), dim3(256), 0, (hipStream_t)stream, src,
-                           gate, (int)Kd, (int)R, ld, ones_row ? 1 : 0, parts, (int)row_tile0, (int)KS, (char*)out);
+                           gate, (int)Kd, (int)R, ld, ones_row ? 1 : 0, parts, (int)row_tile0, (int)KS, amax, (char*)out);
     else
         hipLaunchKernelGGL(split_cols_kernel<false>, dim3((unsigned)rt, (unsigned)kb), dim3(256), 0, (hipStream_t)stream, src,
-                           gate, (int)Kd, (int)R, ld, ones_row ? 1 : 0, parts, (int)row_tile0, (int)KS, (char*)out);
+                           gate, (int)Kd, (int)R, ld, ones_row ? 1 : 0, parts, (int)row_tile0, (int)KS, amax, (char*)out);
     MV_LAUNCH_CHECK("split_cols_kernel");
     return 0;
+}
+
+int mdnvae_split_cols_gated(const float* src, const float* gate, long Kd, long R, long ld, int ones_row, int parts,
+                            long row_tile0, void* out, void* stream) {
+    return split_cols_impl(src, gate, Kd, R, ld, ones_row, parts, row_tile0, nullptr, out, stream);
+}
+
+int mdnvae_split_cols_f16(const float* src, const float* gate, long Kd, long R, long ld, int ones_row, long row_tile0,
+                          const unsigned* absmax, void* out, void* stream) {
+    MV_REQUIRE(absmax, E_ARG, "mdnvae_split_cols_f16: the largest-magnitude slot is NULL");
+    return split_cols_impl(src, gate, Kd, R, ld, ones_row, 2, row_tile0, absmax, out, stream);
 }
 
 int mdnvae_split_cols(const float* src, long Kd, long R, long ld, long row_tile0, void* out, void* stream) {
@@ -504,9 +632,11 @@ int mdnvae_split_cols_dgrad(const float* gpre, const float* w, const float* dens
     return 0;
 }
 
-int mdnvae_split_gemm(const void* a, const void* b, long M, long N, long K, long m_valid, long n_valid,
-                      const float* bias0, const float* bias1, int relu, int accumulate, float* out0, float* out1,
-                      long n_split, long ld_out, int tile_m, int terms, void* stream) {
+static int split_gemm_impl(const void* a, const void* b, const unsigned* amax_a, const unsigned* amax_b, long M, long N,
+                           long K, long m_valid, long n_valid, const float* bias0, const float* bias1, int relu,
+                           int accumulate, float* out0, float* out1, long n_split, long ld_out, int tile_m, int terms,
+                           void* stream) {
+    const bool f16 = amax_a != nullptr;
     MV_REQUIRE(terms == 6 || terms == 3, E_ARG, "mdnvae_split_gemm: terms must be 6 (every product down to 2^-24) or 3");
     MV_REQUIRE(M >= 1 && N >= 1 && K >= 16 && m_valid >= 0 && m_valid <= M, E_ARG, "mdnvae_split_gemm: bad shape");
     MV_REQUIRE(n_valid >= 0 && n_valid <= n_split, E_ARG, "mdnvae_split_gemm: n_valid counts columns of one output (at most n_split)");
@@ -529,22 +659,23 @@ int mdnvae_split_gemm(const void* a, const void* b, long M, long N, long K, long
     hipStream_t st = (hipStream_t)stream;
 #define SG_LAUNCH(WM, EPI)                                                                                          \
     do {                                                                                                            \
-        if (terms == 6) SG_LAUNCH_T(WM, EPI, 6);                                                                    \
-        else SG_LAUNCH_T(WM, EPI, 3);                                                                               \
+        if (f16) SG_LAUNCH_T(WM, EPI, 3, true);                                                                     \
+        else if (terms == 6) SG_LAUNCH_T(WM, EPI, 6, false);                                                        \
+        else SG_LAUNCH_T(WM, EPI, 3, false);                                                                        \
     } while (0)
-#define SG_LAUNCH_T(WM, EPI, TERMS)                                                                                 \
+#define SG_LAUNCH_T(WM, EPI, TERMS, F16)                                                                               \
     do {                                                                                                            \
         const size_t lds = 2 * (size_t)(2 * WM + 8) * (TERMS == 6 ? 3 : 4) * SG_FRAG;                               \
         static bool raised = false;                                                                                 \
         if (!raised) {                                                                                              \
-            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(split_gemm_kernel<WM, EPI, TERMS>), \
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(split_gemm_kernel<WM, EPI, TERMS, F16>), \
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);       \
             MV_REQUIRE(e == hipSuccess, (int)e, "mdnvae_split_gemm: cannot raise the LDS limit: %s",                \
                        hipGetErrorString(e));                                                                       \
             raised = true;                                                                                          \
         }                                                                                                           \
-        hipLaunchKernelGGL((split_gemm_kernel<WM, EPI, TERMS>), dim3((unsigned)(ntm * ntn * (accumulate == 2 ? 2 : 1))), dim3(512), lds, st, \
-                           (const char*)a, (const char*)b, KS, (int)ntm, (int)ntn, (int)m_valid, bias0, bias1,      \
+        hipLaunchKernelGGL((split_gemm_kernel<WM, EPI, TERMS, F16>), dim3((unsigned)(ntm * ntn * (accumulate == 2 ? 2 : 1))), dim3(512), lds, st, \
+                           (const char*)a, (const char*)b, amax_a, amax_b, KS, (int)ntm, (int)ntn, (int)m_valid, bias0, bias1,      \
                            out0, out1 ? out1 : out0, (int)n_split, ld_out, (int)n_valid, accumulate);               \
     } while (0)
     if (tile_m == 256) {
@@ -560,6 +691,21 @@ int mdnvae_split_gemm(const void* a, const void* b, long M, long N, long K, long
 #undef SG_LAUNCH_T
     MV_LAUNCH_CHECK("split_gemm_kernel");
     return 0;
+}
+
+int mdnvae_split_gemm(const void* a, const void* b, long M, long N, long K, long m_valid, long n_valid,
+                      const float* bias0, const float* bias1, int relu, int accumulate, float* out0, float* out1,
+                      long n_split, long ld_out, int tile_m, int terms, void* stream) {
+    return split_gemm_impl(a, b, nullptr, nullptr, M, N, K, m_valid, n_valid, bias0, bias1, relu, accumulate, out0, out1,
+                           n_split, ld_out, tile_m, terms, stream);
+}
+
+int mdnvae_split_gemm_f16(const void* a, const void* b, const unsigned* absmax_a, const unsigned* absmax_b, long M, long N,
+                          long K, long m_valid, long n_valid, const float* bias0, const float* bias1, int relu,
+                          int accumulate, float* out0, float* out1, long n_split, long ld_out, int tile_m, void* stream) {
+    MV_REQUIRE(absmax_a && absmax_b, E_ARG, "mdnvae_split_gemm_f16: a largest-magnitude slot is NULL");
+    return split_gemm_impl(a, b, absmax_a, absmax_b, M, N, K, m_valid, n_valid, bias0, bias1, relu, accumulate, out0, out1,
+                           n_split, ld_out, tile_m, 3, stream);
 }
 
 }  // extern "C"

@@ -22,9 +22,13 @@ __device__ __forceinline__ int tri_index(int i, int j, int N) { return i * N - (
 // measured there and bought nothing: the pass is bound by its global traffic).
 //   FOLD = false: out[t] = m[i][j], *asym |= (m[i][j] != m[j][i])
 //   FOLD = true : out[t] = m[i][j] + m[j][i] (i < j), m[i][i]
+//   amax != NULL: *amax = max(*amax, bit pattern of the largest |out| written) - the scale of the
+//   two-part fp16 operand split that reads `out` next.  One atomic per wave, and only from waves
+//   that hold something larger than what the slot already shows.
 template <bool FOLD>
 __global__ __launch_bounds__(256) void tri_pack_kernel(const float* __restrict__ src, int N, int T, int ld,
-                                                       float* __restrict__ out, int* __restrict__ asym) {
+                                                       float* __restrict__ out, int* __restrict__ asym,
+                                                       unsigned* __restrict__ amax) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int P = N * N;
     const float* m = src + (long)blockIdx.x * P;
@@ -38,6 +42,7 @@ __global__ __launch_bounds__(256) void tri_pack_kernel(const float* __restrict__
     // busy); the row i of entry t from the root of t = i(2N+1-i)/2, corrected by at most one step
     const float c = (float)(2 * N + 1);
     bool differs = false;
+    unsigned mx = 0;
     for (int t = threadIdx.x; t < ld; t += 256) {
         float v = 0.0f;                                            // padding columns of the row
         if (t < T) {
@@ -51,8 +56,15 @@ __global__ __launch_bounds__(256) void tri_pack_kernel(const float* __restrict__
             else { v = a; differs |= !(a == b); }
         }
         o[t] = v;
+        mx = max(mx, __float_as_uint(v) & 0x7fffffffu);
     }
     if (!FOLD && differs) atomicOr(asym, 1);
+    if (amax) {
+#pragma unroll
+        for (int s = 32; s > 0; s >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, s));
+        if ((threadIdx.x & 63) == 0 && mx > __hip_atomic_load(amax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            atomicMax(amax, mx);
+    }
 }
 
 // gw[h][i*N+j] = g[t(min(i,j), max(i,j)) * stride_t + h * stride_h]: a 64 x 64 tile of (p, h) goes
@@ -101,8 +113,8 @@ using namespace mdnvae;
 
 extern "C" {
 
-static int tri_launch(bool fold, const float* src, long rows, int N, int ld, float* out, int* asym, void* stream,
-                      const char* who) {
+static int tri_launch(bool fold, const float* src, long rows, int N, int ld, float* out, int* asym, unsigned* amax,
+                      void* stream, const char* who) {
     MV_REQUIRE(rows >= 0 && N >= 1, E_ARG, "%s: bad shape", who);
     MV_REQUIRE(N <= 192, E_SHAPE, "%s: N = %d exceeds the LDS-resident matrix limit (192)", who, N);
     MV_REQUIRE(rows <= 0x7fffffffL, E_SHAPE, "%s: too many matrices for one launch", who);
@@ -118,7 +130,7 @@ static int tri_launch(bool fold, const float* src, long rows, int N, int ld, flo
             MV_REQUIRE(e == hipSuccess, (int)e, "%s: cannot raise the LDS limit: %s", who, hipGetErrorString(e));
         }
         hipLaunchKernelGGL(tri_pack_kernel<true>, dim3((unsigned)rows), dim3(256), lds, (hipStream_t)stream, src, N, T,
-                           ld, out, asym);
+                           ld, out, asym, amax);
     } else {
         if (lds > 64 * 1024) {
             const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tri_pack_kernel<false>),
@@ -126,18 +138,44 @@ static int tri_launch(bool fold, const float* src, long rows, int N, int ld, flo
             MV_REQUIRE(e == hipSuccess, (int)e, "%s: cannot raise the LDS limit: %s", who, hipGetErrorString(e));
         }
         hipLaunchKernelGGL(tri_pack_kernel<false>, dim3((unsigned)rows), dim3(256), lds, (hipStream_t)stream, src, N, T,
-                           ld, out, asym);
+                           ld, out, asym, amax);
     }
     MV_LAUNCH_CHECK("tri_pack_kernel");
     return 0;
 }
 
 int mdnvae_tri_pack(const float* x, long B, int N, int ld, float* out, int* asym, void* stream) {
-    return tri_launch(false, x, B, N, ld, out, asym, stream, "mdnvae_tri_pack");
+    return tri_launch(false, x, B, N, ld, out, asym, nullptr, stream, "mdnvae_tri_pack");
 }
 
 int mdnvae_tri_fold(const float* w, long H, int N, int ld, float* out, void* stream) {
-    return tri_launch(true, w, H, N, ld, out, nullptr, stream, "mdnvae_tri_fold");
+    return tri_launch(true, w, H, N, ld, out, nullptr, nullptr, stream, "mdnvae_tri_fold");
+}
+
+static int tri_clear_slot(unsigned* absmax, void* stream, const char* who) {
+    MV_REQUIRE(absmax, E_ARG, "%s: the largest-magnitude slot is NULL", who);
+    const hipError_t e = hipMemsetAsync(absmax, 0, sizeof(unsigned), (hipStream_t)stream);
+    MV_REQUIRE(e == hipSuccess, (int)e, "%s: cannot clear the slot: %s", who, hipGetErrorString(e));
+    return 0;
+}
+
+int mdnvae_tri_pack_absmax(const float* x, long B, int N, int ld, float* out, int* asym, int reset, unsigned* absmax,
+                           void* stream) {
+    MV_REQUIRE(absmax, E_ARG, "mdnvae_tri_pack_absmax: the largest-magnitude slot is NULL");
+    if (reset) {
+        const int rc = tri_clear_slot(absmax, stream, "mdnvae_tri_pack_absmax");
+        if (rc) return rc;
+    }
+    return tri_launch(false, x, B, N, ld, out, asym, absmax, stream, "mdnvae_tri_pack_absmax");
+}
+
+int mdnvae_tri_fold_absmax(const float* w, long H, int N, int ld, float* out, int reset, unsigned* absmax, void* stream) {
+    MV_REQUIRE(absmax, E_ARG, "mdnvae_tri_fold_absmax: the largest-magnitude slot is NULL");
+    if (reset) {
+        const int rc = tri_clear_slot(absmax, stream, "mdnvae_tri_fold_absmax");
+        if (rc) return rc;
+    }
+    return tri_launch(true, w, H, N, ld, out, nullptr, absmax, stream, "mdnvae_tri_fold_absmax");
 }
 
 int mdnvae_tri_unfold(const float* g, long H, int N, long stride_t, long stride_h, float* grad_w, int accumulate,

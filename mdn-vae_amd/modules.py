@@ -370,6 +370,9 @@ class GCNVAE(nn.Module):
         # always the library's fp32 GEMMs
         self.first_layer_gemm = first_layer_gemm
         self.register_buffer("_asym", torch.zeros(1, dtype=torch.int32), persistent=False)
+        # largest magnitude of the packed batch (bit pattern of a float), left by the packing pass for the
+        # operand split of the first-layer product
+        self.register_buffer("_xmax", torch.zeros(1, dtype=torch.int32), persistent=False)
         D = n_nodes * n_nodes
         self.fc11 = Linear(D, 1024)
         self.fc12 = Linear(D, 1024)
@@ -385,10 +388,12 @@ class GCNVAE(nn.Module):
         weights, half the GEMM work for the same sums.  The promise is checked on the device with
         every batch; `check_inputs()` reports a violation."""
         if self.symmetric_input:
-            xt = ops.tri_pack(x, self.n_nodes, self._asym)
-            if self.first_layer_gemm == "split" and xt.shape[0] >= ops.SPLIT_GEMM_MIN_BATCH:
+            split = self.first_layer_gemm == "split" and x.shape[0] >= ops.SPLIT_GEMM_MIN_BATCH
+            xmax = self._xmax if split and ops.SPLIT_FWD == "f16" else None
+            xt = ops.tri_pack(x, self.n_nodes, self._asym, xmax)
+            if split:
                 a11, a12 = ops.sym_linear_pair(xt, self.fc11.weight, self.fc11.bias, self.fc12.weight, self.fc12.bias,
-                                               self.n_nodes)
+                                               self.n_nodes, xmax)
             else:
                 a11 = ops.sym_linear_act(xt, self.fc11.weight, self.fc11.bias, "relu", self.n_nodes)
                 a12 = ops.sym_linear_act(xt, self.fc12.weight, self.fc12.bias, "relu", self.n_nodes)

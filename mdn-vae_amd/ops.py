@@ -274,6 +274,24 @@ if SPLIT_WGRAD_TERMS not in (3, 6):
     raise RuntimeError("MDNVAE_SPLIT_WGRAD_TERMS must be 3 or 6")
 
 
+# Products whose result feeds further layers (forward, data gradient): "f16" = two fp16 parts per operand, three
+# products, each tensor scaled by a power of two taken from its largest magnitude (22-bit operands: an fp32 dot
+# product's accuracy at half the matrix-core work); "bf16" = three bf16 parts, six products.
+SPLIT_FWD = os.environ.get("MDNVAE_SPLIT_FWD", "f16")
+if SPLIT_FWD not in ("f16", "bf16"):
+    raise RuntimeError("MDNVAE_SPLIT_FWD must be f16 or bf16")
+
+
+def _absmax_slots(n, device):
+    """n largest-magnitude slots (bit patterns of floats) on the device; the kernels that fill them clear them."""
+    return torch.empty(n, dtype=torch.int32, device=device)
+
+
+def _absmax(t, slot, reset=True, floor=0.0):
+    rows, cols = (t.shape[0], t.shape[1]) if t.dim() == 2 else (1, t.numel())
+    call("mdnvae_absmax", ptr(t), rows, cols, cols, float(floor), int(reset), slot.data_ptr(), stream())
+
+
 def _split_linear_fwd(x, weight, bias, act):
     B, K = x.shape
     n_out = weight.shape[0]
@@ -281,12 +299,21 @@ def _split_linear_fwd(x, weight, bias, act):
     Kp, Mp, Np = _round_up(K, 16), _round_up(B, 128), _round_up(n_out, 256)
     wb = _split_operand(Np, Kp, dev)
     wb[(n_out + 31) // 32 * (Kp // 16) * 3072:].zero_()
-    call("mdnvae_split_rows", ptr(weight, "weight"), n_out, K, K, 0, wb.data_ptr(), stream())
     xa = _split_operand(Mp, Kp, dev)
-    call("mdnvae_split_rows", ptr(x, "x"), B, K, K, 0, xa.data_ptr(), stream())
     y = torch.empty(B, n_out, dtype=torch.float32, device=dev)
-    call("mdnvae_split_gemm", xa.data_ptr(), wb.data_ptr(), Mp, Np, Kp, B, n_out, ptr(bias, "bias"), None,
-         int(act == ACTS["relu"]), 0, ptr(y), None, Np, n_out, 128, 6, stream())
+    if SPLIT_FWD == "f16":
+        mx = _absmax_slots(2, dev)
+        _absmax(weight, mx[0:1])
+        _absmax(x, mx[1:2])
+        call("mdnvae_split_rows_f16", ptr(weight, "weight"), n_out, K, K, 0, mx[0:1].data_ptr(), wb.data_ptr(), stream())
+        call("mdnvae_split_rows_f16", ptr(x, "x"), B, K, K, 0, mx[1:2].data_ptr(), xa.data_ptr(), stream())
+        call("mdnvae_split_gemm_f16", xa.data_ptr(), wb.data_ptr(), mx[1:2].data_ptr(), mx[0:1].data_ptr(), Mp, Np, Kp, B, n_out,
+             ptr(bias, "bias"), None, int(act == ACTS["relu"]), 0, ptr(y), None, Np, n_out, 128, stream())
+    else:
+        call("mdnvae_split_rows", ptr(weight, "weight"), n_out, K, K, 0, wb.data_ptr(), stream())
+        call("mdnvae_split_rows", ptr(x, "x"), B, K, K, 0, xa.data_ptr(), stream())
+        call("mdnvae_split_gemm", xa.data_ptr(), wb.data_ptr(), Mp, Np, Kp, B, n_out, ptr(bias, "bias"), None,
+             int(act == ACTS["relu"]), 0, ptr(y), None, Np, n_out, 128, 6, stream())
     if act not in (ACTS[None], ACTS["relu"]):
         call("mdnvae_bias_act", ptr(y), None, B, n_out, act, stream())
     return y
@@ -299,11 +326,21 @@ def _split_linear_dgrad(gpre, weight):
     dev = gpre.device
     Kp, Mp, Np = _round_up(n_out, 16), _round_up(B, 128), _round_up(n_in, 256)
     ga = _split_operand(Mp, Kp, dev)
-    call("mdnvae_split_rows", ptr(gpre, "grad_pre"), B, n_out, n_out, 0, ga.data_ptr(), stream())
     wb = _split_operand(Np, Kp, dev)
     wb[(n_in + 31) // 32 * (Kp // 16) * 3072:].zero_()
-    call("mdnvae_split_cols", ptr(weight, "weight"), n_out, n_in, n_in, 0, wb.data_ptr(), stream())
     gx = torch.empty(B, n_in, dtype=torch.float32, device=dev)
+    if SPLIT_FWD == "f16":
+        mx = _absmax_slots(2, dev)
+        _absmax(gpre, mx[0:1])
+        _absmax(weight, mx[1:2])
+        call("mdnvae_split_rows_f16", ptr(gpre, "grad_pre"), B, n_out, n_out, 0, mx[0:1].data_ptr(), ga.data_ptr(), stream())
+        call("mdnvae_split_cols_f16", ptr(weight, "weight"), None, n_out, n_in, n_in, 0, 0, mx[1:2].data_ptr(), wb.data_ptr(),
+             stream())
+        call("mdnvae_split_gemm_f16", ga.data_ptr(), wb.data_ptr(), mx[0:1].data_ptr(), mx[1:2].data_ptr(), Mp, Np, Kp, B, n_in,
+             None, None, 0, 0, ptr(gx), None, Np, n_in, 128, stream())
+        return gx
+    call("mdnvae_split_rows", ptr(gpre, "grad_pre"), B, n_out, n_out, 0, ga.data_ptr(), stream())
+    call("mdnvae_split_cols", ptr(weight, "weight"), n_out, n_in, n_in, 0, wb.data_ptr(), stream())
     call("mdnvae_split_gemm", ga.data_ptr(), wb.data_ptr(), Mp, Np, Kp, B, n_in, None, None, 0, 0, ptr(gx), None, Np, n_in, 128, 6, stream())
     return gx
 
@@ -421,14 +458,19 @@ def linear_act(x, weight, bias=None, act=None):
     return _LinearAct.apply(x, weight, bias, ACTS[act])
 
 
-def tri_pack(x, n_nodes, asym):
+def tri_pack(x, n_nodes, asym, absmax=None):
     """Upper triangles [B, tri_row_stride(N)] of a batch of symmetric matrices x [B, N*N]; `asym` (int32[1]
     on the device) is OR-ed with 1 if a matrix is not symmetric.  The result carries no gradient:
-    the symmetric first layer is for network inputs."""
+    the symmetric first layer is for network inputs.  `absmax` (int32[1] on the device): set to the bit
+    pattern of the largest magnitude packed, which sym_linear_pair(x_absmax=...) takes as the operand's scale."""
     x = _c(x.detach()).reshape(-1, n_nodes * n_nodes)
     ld = tri_row_stride(n_nodes)
     out = torch.empty(x.shape[0], ld, dtype=torch.float32, device=x.device)
-    call("mdnvae_tri_pack", ptr(x, "x"), x.shape[0], n_nodes, ld, ptr(out), asym.data_ptr(), stream())
+    if absmax is not None:
+        call("mdnvae_tri_pack_absmax", ptr(x, "x"), x.shape[0], n_nodes, ld, ptr(out), asym.data_ptr(), 1,
+             absmax.data_ptr(), stream())
+    else:
+        call("mdnvae_tri_pack", ptr(x, "x"), x.shape[0], n_nodes, ld, ptr(out), asym.data_ptr(), stream())
     return out
 
 
@@ -507,7 +549,7 @@ class _SymLinearPair(torch.autograd.Function):
     gradients [T,H] with the same kernel from x^T and grad_pre^T."""
 
     @staticmethod
-    def forward(ctx, xt, w1, b1, w2, b2, n_nodes):
+    def forward(ctx, xt, w1, b1, w2, b2, n_nodes, x_absmax=None):
         w1, w2 = _c(w1), _c(w2)
         B, T = xt.shape
         H = w1.shape[0]
@@ -516,17 +558,30 @@ class _SymLinearPair(torch.autograd.Function):
                                f"{tuple(w2.shape)}), T a multiple of 16 (got {T})")
         dev = xt.device
         wt = torch.empty(2 * H, T, dtype=torch.float32, device=dev)
-        call("mdnvae_tri_fold", ptr(w1, "weight"), H, n_nodes, T, ptr(wt[:H]), stream())
-        call("mdnvae_tri_fold", ptr(w2, "weight"), H, n_nodes, T, ptr(wt[H:]), stream())
         wb = _split_operand(2 * H, T, dev)
-        call("mdnvae_split_rows", ptr(wt), 2 * H, T, T, 0, wb.data_ptr(), stream())
         Mp = _round_up(B, 256)
         xa = _split_operand(Mp, T, dev)
-        call("mdnvae_split_rows", ptr(xt, "x"), B, T, T, 0, xa.data_ptr(), stream())
         y1 = torch.empty(B, H, dtype=torch.float32, device=dev)
         y2 = torch.empty(B, H, dtype=torch.float32, device=dev)
-        call("mdnvae_split_gemm", xa.data_ptr(), wb.data_ptr(), Mp, 2 * H, T, B, H, ptr(b1, "bias"), ptr(b2, "bias"), 1, 0,
-             ptr(y1), ptr(y2), H, H, 256, 6, stream())
+        if SPLIT_FWD == "f16":
+            # the folding pass (and, given x_absmax, the packing pass) leaves the largest magnitude it wrote
+            mx = _absmax_slots(2, dev)
+            wmax, xmax = mx[0:1], (x_absmax if x_absmax is not None else mx[1:2])
+            call("mdnvae_tri_fold_absmax", ptr(w1, "weight"), H, n_nodes, T, ptr(wt[:H]), 1, wmax.data_ptr(), stream())
+            call("mdnvae_tri_fold_absmax", ptr(w2, "weight"), H, n_nodes, T, ptr(wt[H:]), 0, wmax.data_ptr(), stream())
+            if x_absmax is None:
+                _absmax(xt, xmax)
+            call("mdnvae_split_rows_f16", ptr(wt), 2 * H, T, T, 0, wmax.data_ptr(), wb.data_ptr(), stream())
+            call("mdnvae_split_rows_f16", ptr(xt, "x"), B, T, T, 0, xmax.data_ptr(), xa.data_ptr(), stream())
+            call("mdnvae_split_gemm_f16", xa.data_ptr(), wb.data_ptr(), xmax.data_ptr(), wmax.data_ptr(), Mp, 2 * H, T, B, H,
+                 ptr(b1, "bias"), ptr(b2, "bias"), 1, 0, ptr(y1), ptr(y2), H, H, 256, stream())
+        else:
+            call("mdnvae_tri_fold", ptr(w1, "weight"), H, n_nodes, T, ptr(wt[:H]), stream())
+            call("mdnvae_tri_fold", ptr(w2, "weight"), H, n_nodes, T, ptr(wt[H:]), stream())
+            call("mdnvae_split_rows", ptr(wt), 2 * H, T, T, 0, wb.data_ptr(), stream())
+            call("mdnvae_split_rows", ptr(xt, "x"), B, T, T, 0, xa.data_ptr(), stream())
+            call("mdnvae_split_gemm", xa.data_ptr(), wb.data_ptr(), Mp, 2 * H, T, B, H, ptr(b1, "bias"), ptr(b2, "bias"), 1, 0,
+                 ptr(y1), ptr(y2), H, H, 256, 6, stream())
         ctx.save_for_backward(xt, y1, y2)
         ctx.n_nodes = n_nodes
         ctx.params = (w1, b1, w2, b2)
@@ -545,7 +600,7 @@ class _SymLinearPair(torch.autograd.Function):
         H, n, dev = y1.shape[1], ctx.n_nodes, xt.device
         gws, gbs = [None, None], [None, None]
         if not any(ctx.needs_input_grad[1:5]):
-            return None, None, None, None, None, None
+            return None, None, None, None, None, None, None
         slots = ctx.slots or (None, None)
         # One product gives both folded weight gradients and both bias gradients: its operands are x^T with a
         # row of ones appended (so that row T of the result is the column sum of grad_pre) and grad_pre^T,
@@ -597,11 +652,12 @@ class _SymLinearPair(torch.autograd.Function):
             else:
                 gws[i] = torch.empty(H, n * n, dtype=torch.float32, device=dev)
                 call("mdnvae_tri_unfold", ptr(gt), H, n, H, 1, ptr(gws[i]), 0, stream())
-        return None, gws[0], gbs[0], gws[1], gbs[1], None
+        return None, gws[0], gbs[0], gws[1], gbs[1], None, None
 
 
-def sym_linear_pair(x_tri, w1, b1, w2, b2, n_nodes):
-    return _SymLinearPair.apply(x_tri, w1, b1, w2, b2, n_nodes)
+def sym_linear_pair(x_tri, w1, b1, w2, b2, n_nodes, x_absmax=None):
+    """x_absmax: the slot tri_pack(..., absmax=slot) filled for x_tri (saves a pass over x_tri)."""
+    return _SymLinearPair.apply(x_tri, w1, b1, w2, b2, n_nodes, x_absmax)
 
 
 class _LinearPair(torch.autograd.Function):
@@ -622,15 +678,27 @@ class _LinearPair(torch.autograd.Function):
         dev = x.device
         Kp = _round_up(D, 16)
         wb = _split_operand(2 * H, Kp, dev)
-        call("mdnvae_split_rows", ptr(w1, "weight"), H, D, D, 0, wb.data_ptr(), stream())
-        call("mdnvae_split_rows", ptr(w2, "weight"), H, D, D, H // 32, wb.data_ptr(), stream())
         Mp = _round_up(B, 256)
         xa = _split_operand(Mp, Kp, dev)
-        call("mdnvae_split_rows", ptr(x, "x"), B, D, D, 0, xa.data_ptr(), stream())
         y1 = torch.empty(B, H, dtype=torch.float32, device=dev)
         y2 = torch.empty(B, H, dtype=torch.float32, device=dev)
-        call("mdnvae_split_gemm", xa.data_ptr(), wb.data_ptr(), Mp, 2 * H, Kp, B, H, ptr(b1, "bias"), ptr(b2, "bias"), 1, 0,
-             ptr(y1), ptr(y2), H, H, 256, 6, stream())
+        if SPLIT_FWD == "f16":
+            mx = _absmax_slots(2, dev)
+            wmax, xmax = mx[0:1], mx[1:2]
+            _absmax(w1, wmax)
+            _absmax(w2, wmax, reset=False)
+            _absmax(x, xmax)
+            call("mdnvae_split_rows_f16", ptr(w1, "weight"), H, D, D, 0, wmax.data_ptr(), wb.data_ptr(), stream())
+            call("mdnvae_split_rows_f16", ptr(w2, "weight"), H, D, D, H // 32, wmax.data_ptr(), wb.data_ptr(), stream())
+            call("mdnvae_split_rows_f16", ptr(x, "x"), B, D, D, 0, xmax.data_ptr(), xa.data_ptr(), stream())
+            call("mdnvae_split_gemm_f16", xa.data_ptr(), wb.data_ptr(), xmax.data_ptr(), wmax.data_ptr(), Mp, 2 * H, Kp, B, H,
+                 ptr(b1, "bias"), ptr(b2, "bias"), 1, 0, ptr(y1), ptr(y2), H, H, 256, stream())
+        else:
+            call("mdnvae_split_rows", ptr(w1, "weight"), H, D, D, 0, wb.data_ptr(), stream())
+            call("mdnvae_split_rows", ptr(w2, "weight"), H, D, D, H // 32, wb.data_ptr(), stream())
+            call("mdnvae_split_rows", ptr(x, "x"), B, D, D, 0, xa.data_ptr(), stream())
+            call("mdnvae_split_gemm", xa.data_ptr(), wb.data_ptr(), Mp, 2 * H, Kp, B, H, ptr(b1, "bias"), ptr(b2, "bias"), 1, 0,
+                 ptr(y1), ptr(y2), H, H, 256, 6, stream())
         ctx.save_for_backward(x, y1, y2)
         ctx.params = (w1, b1, w2, b2)
         return y1, y2

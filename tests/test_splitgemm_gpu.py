@@ -79,6 +79,91 @@ def test_split_product_against_float64(Mrows, N, K, tile):
     assert float((got - want_r).abs().max() / want_r.abs().max()) <= 1e-5
 
 
+def _amax_slot():
+    return torch.zeros(1, dtype=torch.int32, device=DEV)
+
+
+@pytest.mark.parametrize("scale_a,scale_b", [(1.0, 0.02), (3e-6, 4e3), (7e4, 1e-7)])
+@pytest.mark.parametrize("Mrows,N,K,tile", [(300, 512, 64, 256), (1000, 2048, 2368, 256), (3840, 512, 1000, 128)])
+def test_two_part_fp16_product_against_float64(Mrows, N, K, tile, scale_a, scale_b):
+    """The same product from two fp16 parts per operand (mdnvae_absmax / mdnvae_split_rows_f16 /
+    mdnvae_split_cols_f16 / mdnvae_split_gemm_f16): three fp16 products instead of six bf16 ones.  Tensors of
+    very different magnitudes (the power-of-two scaling must absorb them), a tenth of the entries 30 times
+    larger than the rest; entry by entry against float64 at the bar the six-term product is held to."""
+    g = torch.Generator().manual_seed(Mrows + K)
+    a = torch.randn(Mrows, K, generator=g) * torch.where(torch.rand(Mrows, K, generator=g) < 0.1, 30.0, 1.0) * scale_a
+    b = torch.randn(N, K, generator=g) * scale_b
+    bias = torch.randn(N, generator=g) * 0.1 * scale_a * scale_b * K ** 0.5
+    Kp, Mp = _up(K, 16), _up(Mrows, tile)
+    want = a.double() @ b.double().t()
+    mag = a.double().abs() @ b.double().abs().t()
+    ad, bd = a.to(DEV), b.to(DEV)
+    ma, mb = _amax_slot(), _amax_slot()
+    call("mdnvae_absmax", ptr(ad), Mrows, K, K, 0.0, 1, ma.data_ptr(), stream())
+    call("mdnvae_absmax", ptr(bd), N, K, K, 0.0, 1, mb.data_ptr(), stream())
+    assert ma.view(torch.float32).item() == float(a.abs().max()) and mb.view(torch.float32).item() == float(b.abs().max())
+    half = N // 2 if (N // 2) % 256 == 0 else N
+    for how in ("rows", "cols"):
+        oa, ob = _operand(Mp, Kp), _operand(N, Kp)
+        if how == "rows":
+            call("mdnvae_split_rows_f16", ptr(ad), Mrows, K, K, 0, ma.data_ptr(), oa.data_ptr(), stream())
+            call("mdnvae_split_rows_f16", ptr(bd), N, K, K, 0, mb.data_ptr(), ob.data_ptr(), stream())
+        else:
+            at, bt = ad.t().contiguous(), bd.t().contiguous()
+            call("mdnvae_split_cols_f16", ptr(at), None, K, Mrows, Mrows, 0, 0, ma.data_ptr(), oa.data_ptr(), stream())
+            call("mdnvae_split_cols_f16", ptr(bt), None, K, N, N, 0, 0, mb.data_ptr(), ob.data_ptr(), stream())
+        out0 = torch.full((Mrows, half), float("nan"), device=DEV)
+        out1 = torch.full((Mrows, N - half), float("nan"), device=DEV) if half < N else None
+        call("mdnvae_split_gemm_f16", oa.data_ptr(), ob.data_ptr(), ma.data_ptr(), mb.data_ptr(), Mp, N, Kp, Mrows, half,
+             None, None, 0, 0, ptr(out0), ptr(out1), half, half, tile, stream())
+        got = torch.cat([out0] + ([out1] if out1 is not None else []), dim=1).double().cpu()
+        assert torch.isfinite(got).all()
+        assert float(((got - want).abs() / mag).max()) <= 1e-6, how
+        assert float((got - want).abs().max() / want.abs().max()) <= 1e-5
+    bd_ = bias.to(DEV)
+    out0 = torch.empty(Mrows, half, device=DEV)
+    out1 = torch.empty(Mrows, N - half, device=DEV) if half < N else None
+    call("mdnvae_split_gemm_f16", oa.data_ptr(), ob.data_ptr(), ma.data_ptr(), mb.data_ptr(), Mp, N, Kp, Mrows, half,
+         ptr(bd_[:half].contiguous()), ptr(bd_[half:].contiguous()) if half < N else None, 1, 0, ptr(out0), ptr(out1), half,
+         half, tile, stream())
+    got = torch.cat([out0] + ([out1] if out1 is not None else []), dim=1).double().cpu()
+    want_r = torch.relu(want + bias.double())
+    assert float((got - want_r).abs().max() / want_r.abs().max()) <= 1e-5
+
+
+def test_two_part_fp16_small_entries_and_shared_slots():
+    """Entries far below the tensor's largest one lose low-part bits but never more than 2^-29 of the largest
+    entry in absolute terms; a slot filled by several mdnvae_absmax calls (reset = 0) and a floor value holds
+    the largest of all of them; an all-zero tensor gives zeros."""
+    g = torch.Generator().manual_seed(5)
+    Mrows, N, K = 256, 256, 512
+    a = torch.randn(Mrows, K, generator=g) * torch.logspace(0, -9, K).unsqueeze(0)      # columns span nine decades
+    b = torch.randn(N, K, generator=g)
+    ad, bd = a.to(DEV), b.to(DEV)
+    ma, mb = _amax_slot(), _amax_slot()
+    call("mdnvae_absmax", ptr(ad[:100].contiguous()), 100, K, K, 0.0, 1, ma.data_ptr(), stream())
+    call("mdnvae_absmax", ptr(ad[100:].contiguous()), Mrows - 100, K, K, 0.0, 0, ma.data_ptr(), stream())
+    assert ma.view(torch.float32).item() == float(a.abs().max())
+    call("mdnvae_absmax", ptr(bd), N, K, K, 1e3, 1, mb.data_ptr(), stream())
+    assert mb.view(torch.float32).item() == 1e3
+    oa, ob = _operand(Mrows, K), _operand(N, K)
+    call("mdnvae_split_rows_f16", ptr(ad), Mrows, K, K, 0, ma.data_ptr(), oa.data_ptr(), stream())
+    call("mdnvae_split_rows_f16", ptr(bd), N, K, K, 0, mb.data_ptr(), ob.data_ptr(), stream())
+    out = torch.empty(Mrows, N, device=DEV)
+    call("mdnvae_split_gemm_f16", oa.data_ptr(), ob.data_ptr(), ma.data_ptr(), mb.data_ptr(), Mrows, N, K, Mrows, N, None,
+         None, 0, 0, ptr(out), None, N, N, 128, stream())
+    want = a.double() @ b.double().t()
+    bound = 3 * 2.0 ** -22 * (a.double().abs() @ b.double().abs().t()) + 2.0 ** -28 * (
+        float(a.abs().max()) * b.double().abs().sum(1).unsqueeze(0) + 1e3 * a.double().abs().sum(1).unsqueeze(1))
+    assert bool(((out.double().cpu() - want).abs() <= bound).all())
+    zero = torch.zeros(Mrows, K, device=DEV)
+    call("mdnvae_absmax", ptr(zero), Mrows, K, K, 0.0, 1, ma.data_ptr(), stream())
+    call("mdnvae_split_rows_f16", ptr(zero), Mrows, K, K, 0, ma.data_ptr(), oa.data_ptr(), stream())
+    call("mdnvae_split_gemm_f16", oa.data_ptr(), ob.data_ptr(), ma.data_ptr(), mb.data_ptr(), Mrows, N, K, Mrows, N, None,
+         None, 0, 0, ptr(out), None, N, N, 128, stream())
+    assert float(out.abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("terms", [3, 6])
 @pytest.mark.parametrize("B,n", [(1024, 68), (1500, 87)])
 def test_first_layer_pair_against_float64_and_the_library_path(B, n, terms, monkeypatch):
@@ -104,17 +189,28 @@ def test_first_layer_pair_against_float64_and_the_library_path(B, n, terms, monk
     y_lib = [ops.sym_linear_act(xt, w[i], b[i], "relu", n) for i in range(2)]
     torch.autograd.backward(y_lib, up)
     lib = [t.detach() for t in y_lib] + [t.grad for t in w + b]
+    # float64 reference with each path's ReLU gates taken from its own forward values: a pre-activation within
+    # rounding of zero may land on either side, and one flipped gate moves a gradient entry by a whole term
+    # (checked: the gates differ from float64's only where the float64 pre-activation is below 1e-5)
     x64 = x.double().cpu()
-    w64 = [t.detach().double().cpu().requires_grad_(True) for t in w]
-    b64 = [t.detach().double().cpu().requires_grad_(True) for t in b]
-    y64 = [torch.relu(x64 @ w64[i].t() + b64[i]) for i in range(2)]
-    torch.autograd.backward(y64, [u.double().cpu() for u in up])
-    want = [t.detach() for t in y64] + [t.grad for t in w64 + b64]
+    w64 = [t.detach().double().cpu() for t in w]
+    b64 = [t.detach().double().cpu() for t in b]
+    pre64 = [x64 @ w64[i].t() + b64[i] for i in range(2)]
+
+    def reference(outputs):
+        gate = [(outputs[i].cpu() > 0) for i in range(2)]
+        for i in range(2):
+            flipped = gate[i] != (pre64[i] > 0)
+            assert not flipped.any() or float(pre64[i][flipped].abs().max()) < 1e-5
+        gpre64 = [up[i].double().cpu() * gate[i] for i in range(2)]
+        return ([torch.relu(p_) for p_ in pre64] + [gpre64[i].t() @ x64 for i in range(2)]
+                + [gpre64[i].sum(0) for i in range(2)])
+
     names = ["y1", "y2", "gw1", "gw2", "gb1", "gb2"]
-    for name, g_, l_, w_ in zip(names, got, lib, want):
+    for name, g_, l_, w_, wl_ in zip(names, got, lib, reference(got), reference(lib)):
         bar = 1e-5 if name.startswith("y") else 1e-4
         err = float((g_.double().cpu() - w_).abs().max() / w_.abs().max())
-        err_lib = float((l_.double().cpu() - w_).abs().max() / w_.abs().max())
+        err_lib = float((l_.double().cpu() - wl_).abs().max() / wl_.abs().max())
         assert err <= bar, (name, err)
         if name.startswith("g") and terms == 3:      # weight and bias gradients come out of one product
             assert err <= 5e-5, (name, err)
@@ -217,7 +313,8 @@ def test_large_dense_layer_on_the_split_product(act):
         y.backward(up)
     finally:
         ops.call = orig
-    assert calls.count("mdnvae_split_gemm") == 3                       # forward, data gradient, weight gradient
+    # forward, data gradient, weight gradient (the first two on the two-part fp16 product by default)
+    assert calls.count("mdnvae_split_gemm") + calls.count("mdnvae_split_gemm_f16") == 3
     x64, w64, b64 = (t.detach().double().cpu() for t in (x, w, b))
     pre = x64 @ w64.t() + b64
     want = {None: pre, "sigmoid": torch.sigmoid(pre), "relu": torch.relu(pre)}[act]
