@@ -6,7 +6,7 @@ PKG := mdn-vae_amd
 SRC := $(wildcard $(PKG)/csrc/*.hip) $(wildcard $(PKG)/csrc/*.cpp)
 OBJ := $(patsubst $(PKG)/csrc/%,build/%.o,$(SRC))
 LIB := $(PKG)/lib/libmdnvae_hip.so
-CXXFLAGS := -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Wall -Wno-unused-function -Iinclude
+CXXFLAGS := $(EXTRA) -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Wall -Wno-unused-function -Iinclude
 
 all: $(LIB)
 

@@ -16,6 +16,7 @@
 // conflict-free ds_read_b128 per lane.  Both operands are "k-contiguous" ([M][K] and [N][K]): the
 // forward product takes x [B][T] and the folded weights [H][T]; the weight gradient takes x^T [T][B]
 // and grad_pre^T [H][B], which the column-splitting kernel writes straight from the row-major tensors.
+#include <cstdlib>
 #include "common.h"
 #include "../../include/mdnvae_hip.h"
 
@@ -343,7 +344,11 @@ enum { SG_EPI_BIAS_RELU = 0, SG_EPI_PLAIN = 1, SG_EPI_BIAS = 2 };
 // out is 2^-16 of |x w| per term at most), the third part of neither operand is staged.
 // F16 (with TERMS = 3): the operands hold two fp16 parts of power-of-two scaled tensors (sg_emit_f16) - h h + h l +
 // l h on the fp16 MFMA, the scales undone in the epilogue from the two tensors' largest magnitudes.
-template <int WM, int EPI, int TERMS, bool F16 = false>
+// DEEP (with TERMS = 3): one k step per stage in a ring of four stage buffers, three stages in flight.  A
+// three-term k step is 24 MFMAs per wave (0.35 us): one stage ahead, the next operands (L2 -> LDS, a
+// microsecond and more under load) arrive after the MFMAs that hide them have run out, and every barrier waits
+// for them.  The wait before the barrier is the wave's own counted vmcnt (two younger stages stay in flight).
+template <int WM, int EPI, int TERMS, bool F16 = false, bool DEEP = false>
 __global__ __launch_bounds__(512) void split_gemm_kernel(const char* __restrict__ A, const char* __restrict__ Bop,
                                                          const unsigned* __restrict__ amax_a,
                                                          const unsigned* __restrict__ amax_b,
@@ -352,14 +357,20 @@ __global__ __launch_bounds__(512) void split_gemm_kernel(const char* __restrict_
                                                          float* __restrict__ out0, float* __restrict__ out1, int n_split,
                                                          long ld_out, int n_valid, int accumulate) {
     static_assert(!F16 || TERMS == 3, "two fp16 parts make a three-term product");
+    static_assert(!DEEP || TERMS == 3, "the four-stage ring is sized for two-part operands");
     constexpr int TA = 2 * WM, TB = 8;                   // fragment rows-tiles of A / B per workgroup
     constexpr int NPART = TERMS == 6 ? 3 : 2;            // parts of a fragment that take part
-    constexpr int KB = TERMS == 6 ? 1 : 2;               // k steps per barrier: about as many MFMAs either way
+    constexpr int KB = (TERMS == 6 || DEEP) ? 1 : 2;     // k steps per barrier
     constexpr int FSTEP = NPART * SG_FRAG;               // one (row tile, k step) in LDS
     constexpr int KSTAGE = (TA + TB) * FSTEP;            // one k step of all row tiles
     constexpr int STAGE = KB * KSTAGE;
     constexpr int PIECES = (TA + TB) * NPART * KB;
     constexpr int PPW = (PIECES + 7) / 8;                // pieces per wave (the last may be missing)
+#ifndef SG_NBUF
+#define SG_NBUF 4
+#endif
+    constexpr int NBUF = DEEP ? SG_NBUF : 2;
+    static_assert(!DEEP || PIECES % 8 == 0, "counted waits need the same number of pieces in every wave");
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -431,49 +442,73 @@ __global__ __launch_bounds__(512) void split_gemm_kernel(const char* __restrict_
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
-    stage(0, ks_begin);
-    __syncthreads();
-    int buf = 0;
-    for (int ks = ks_begin; ks < ks_end; ks += KB, buf ^= 1) {
-        if (ks + KB < ks_end) stage(buf ^ 1, ks + KB);
+    // one k step of MFMAs from stage buffer `buf`, k step `kk` of the stage
+    auto compute = [&](int buf, int kk) {
+        const char* sa = smem + buf * STAGE + kk * KSTAGE + (wm * WM) * FSTEP + lane * 16;
+        const char* sb = smem + buf * STAGE + kk * KSTAGE + (TA + wn * 2) * FSTEP + lane * 16;
+        // B fragments and the first A row tile, then A row tile i + 1 is fetched while the MFMAs of
+        // row tile i run: only the first block of a step waits on LDS
+        sg_frag a[2][NPART], b[2][NPART];
 #pragma unroll
-        for (int kk = 0; kk < KB; ++kk) {
-            if (KB > 1 && ks + kk >= ks_end) break;
-            const char* sa = smem + buf * STAGE + kk * KSTAGE + (wm * WM) * FSTEP + lane * 16;
-            const char* sb = smem + buf * STAGE + kk * KSTAGE + (TA + wn * 2) * FSTEP + lane * 16;
-            // B fragments and the first A row tile, then A row tile i + 1 is fetched while the MFMAs of
-            // row tile i run: only the first block of a step waits on LDS
-            sg_frag a[2][NPART], b[2][NPART];
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int s = 0; s < NPART; ++s) b[j][s] = *reinterpret_cast<const sg_frag*>(sb + j * FSTEP + s * SG_FRAG);
 #pragma unroll
-                for (int s = 0; s < NPART; ++s) b[j][s] = *reinterpret_cast<const sg_frag*>(sb + j * FSTEP + s * SG_FRAG);
+        for (int s = 0; s < NPART; ++s) a[0][s] = *reinterpret_cast<const sg_frag*>(sa + s * SG_FRAG);
 #pragma unroll
-            for (int s = 0; s < NPART; ++s) a[0][s] = *reinterpret_cast<const sg_frag*>(sa + s * SG_FRAG);
+        for (int i = 0; i < WM; ++i) {
+            if (i + 1 < WM) {
 #pragma unroll
-            for (int i = 0; i < WM; ++i) {
-                if (i + 1 < WM) {
-#pragma unroll
-                    for (int s = 0; s < NPART; ++s)
-                        a[(i + 1) & 1][s] = *reinterpret_cast<const sg_frag*>(sa + (i + 1) * FSTEP + s * SG_FRAG);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    // smallest terms first
-                    if (TERMS == 6) {
-                        acc[i][j] = mfma(a[i & 1][0], b[j][NPART - 1], acc[i][j]);
-                        acc[i][j] = mfma(a[i & 1][1], b[j][1], acc[i][j]);
-                        acc[i][j] = mfma(a[i & 1][NPART - 1], b[j][0], acc[i][j]);
-                    }
-                    acc[i][j] = mfma(a[i & 1][0], b[j][1], acc[i][j]);
-                    acc[i][j] = mfma(a[i & 1][1], b[j][0], acc[i][j]);
-                    acc[i][j] = mfma(a[i & 1][0], b[j][0], acc[i][j]);
-                }
-                __builtin_amdgcn_sched_barrier(0);
+                for (int s = 0; s < NPART; ++s)
+                    a[(i + 1) & 1][s] = *reinterpret_cast<const sg_frag*>(sa + (i + 1) * FSTEP + s * SG_FRAG);
             }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                // smallest terms first
+                if (TERMS == 6) {
+                    acc[i][j] = mfma(a[i & 1][0], b[j][NPART - 1], acc[i][j]);
+                    acc[i][j] = mfma(a[i & 1][1], b[j][1], acc[i][j]);
+                    acc[i][j] = mfma(a[i & 1][NPART - 1], b[j][0], acc[i][j]);
+                }
+                acc[i][j] = mfma(a[i & 1][0], b[j][1], acc[i][j]);
+                acc[i][j] = mfma(a[i & 1][1], b[j][0], acc[i][j]);
+                acc[i][j] = mfma(a[i & 1][0], b[j][0], acc[i][j]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
+    };
+
+    if constexpr (DEEP) {
+        // stage s of this tile's k range lives in buffer s % 4; past the end the last stage is fetched again
+        // (into a buffer nobody reads any more), so that every wave always has the same number of operations
+        // in flight and one counted wait fits every iteration
+        const int nks = ks_end - ks_begin;
+        if (nks > 0) {
+#pragma unroll
+            for (int s = 0; s < NBUF - 1; ++s) stage(s, ks_begin + min(s, nks - 1));
+        }
+        for (int it = 0; it < nks; ++it) {
+            // own pieces of stage `it` landed (two younger stages may be in flight); after the barrier
+            // everybody's have, and everybody has finished with the buffer of stage it - 1
+            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((NBUF - 2) * PPW) : "memory");
+            stage((it + NBUF - 1) % NBUF, ks_begin + min(it + NBUF - 1, nks - 1));
+            compute(it % NBUF, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // nothing in flight when the LDS goes back
+    } else {
+        stage(0, ks_begin);
         __syncthreads();
+        int buf = 0;
+        for (int ks = ks_begin; ks < ks_end; ks += KB, buf ^= 1) {
+            if (ks + KB < ks_end) stage(buf ^ 1, ks + KB);
+#pragma unroll
+            for (int kk = 0; kk < KB; ++kk) {
+                if (KB > 1 && ks + kk >= ks_end) break;
+                compute(buf, kk);
+            }
+            __syncthreads();
+        }
     }
 
     // epilogue: accumulator register e of a 32 x 32 tile is row (e & 3) + 8 (e >> 2) + 4 (lane >> 5),
@@ -637,6 +672,7 @@ static int split_gemm_impl(const void* a, const void* b, const unsigned* amax_a,
                            int accumulate, float* out0, float* out1, long n_split, long ld_out, int tile_m, int terms,
                            void* stream) {
     const bool f16 = amax_a != nullptr;
+    static const bool deep = getenv("MDNVAE_SG_SHALLOW") == nullptr;      // tuning knob: the two-buffer loop
     MV_REQUIRE(terms == 6 || terms == 3, E_ARG, "mdnvae_split_gemm: terms must be 6 (every product down to 2^-24) or 3");
     MV_REQUIRE(M >= 1 && N >= 1 && K >= 16 && m_valid >= 0 && m_valid <= M, E_ARG, "mdnvae_split_gemm: bad shape");
     MV_REQUIRE(n_valid >= 0 && n_valid <= n_split, E_ARG, "mdnvae_split_gemm: n_valid counts columns of one output (at most n_split)");
@@ -659,22 +695,24 @@ static int split_gemm_impl(const void* a, const void* b, const unsigned* amax_a,
     hipStream_t st = (hipStream_t)stream;
 #define SG_LAUNCH(WM, EPI)                                                                                          \
     do {                                                                                                            \
-        if (f16) SG_LAUNCH_T(WM, EPI, 3, true);                                                                     \
-        else if (terms == 6) SG_LAUNCH_T(WM, EPI, 6, false);                                                        \
-        else SG_LAUNCH_T(WM, EPI, 3, false);                                                                        \
+        if (f16 && deep) SG_LAUNCH_T(WM, EPI, 3, true, true);                                                       \
+        else if (f16) SG_LAUNCH_T(WM, EPI, 3, true, false);                                                         \
+        else if (terms == 6) SG_LAUNCH_T(WM, EPI, 6, false, false);                                                 \
+        else if (deep) SG_LAUNCH_T(WM, EPI, 3, false, true);                                                        \
+        else SG_LAUNCH_T(WM, EPI, 3, false, false);                                                                 \
     } while (0)
-#define SG_LAUNCH_T(WM, EPI, TERMS, F16)                                                                               \
+#define SG_LAUNCH_T(WM, EPI, TERMS, F16, DEEP)                                                                               \
     do {                                                                                                            \
-        const size_t lds = 2 * (size_t)(2 * WM + 8) * (TERMS == 6 ? 3 : 4) * SG_FRAG;                               \
+        const size_t lds = (size_t)(2 * WM + 8) * (TERMS == 6 ? 6 : (DEEP ? 2 * SG_NBUF : 8)) * SG_FRAG;                                   \
         static bool raised = false;                                                                                 \
         if (!raised) {                                                                                              \
-            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(split_gemm_kernel<WM, EPI, TERMS, F16>), \
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(split_gemm_kernel<WM, EPI, TERMS, F16, DEEP>), \
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);       \
             MV_REQUIRE(e == hipSuccess, (int)e, "mdnvae_split_gemm: cannot raise the LDS limit: %s",                \
                        hipGetErrorString(e));                                                                       \
             raised = true;                                                                                          \
         }                                                                                                           \
-        hipLaunchKernelGGL((split_gemm_kernel<WM, EPI, TERMS, F16>), dim3((unsigned)(ntm * ntn * (accumulate == 2 ? 2 : 1))), dim3(512), lds, st, \
+        hipLaunchKernelGGL((split_gemm_kernel<WM, EPI, TERMS, F16, DEEP>), dim3((unsigned)(ntm * ntn * (accumulate == 2 ? 2 : 1))), dim3(512), lds, st, \
                            (const char*)a, (const char*)b, amax_a, amax_b, KS, (int)ntm, (int)ntn, (int)m_valid, bias0, bias1,      \
                            out0, out1 ? out1 : out0, (int)n_split, ld_out, (int)n_valid, accumulate);               \
     } while (0)

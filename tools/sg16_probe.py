@@ -7,6 +7,9 @@ import mdnvae_amd as M  # noqa: E402,F401
 from mdnvae_amd import _lib  # noqa: E402
 from mdnvae_amd._lib import call, ptr, stream  # noqa: E402
 
+import os  # noqa: E402
+if os.environ.get("SG_LIB"):                       # a tuning build of the library
+    _lib.LIB_PATH = os.path.abspath(os.environ["SG_LIB"])
 DEV = "cuda:0"
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
 T, N = 3840, 2048
