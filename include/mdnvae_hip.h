@@ -288,9 +288,12 @@ int mdnvae_split_gemm(const void* a, const void* b, long M, long N, long K, long
  * sum |a||b| at most (measured: the level of an fp32 dot product).  fp16 has 30 binades, so each TENSOR is
  * scaled by the power of two that brings its largest magnitude into [2^14, 2^15); entries more than 2^17
  * below the tensor's largest lose low-part bits (absolute error below 2^-29 of the largest entry).  The
- * largest magnitude lives on the device as the bit pattern of a float (`absmax`, one unsigned). */
-/* *absmax = max(*absmax, |floor_value|, largest |src[r][c]|), src [rows][ld], c < cols; reset != 0 clears the
- * slot first (hipMemsetAsync on the stream).  Several tensors that share a scale are folded into one slot by
+ * largest magnitude lives on the device as bit patterns of floats: `absmax` is an array of
+ * MDNVAE_ABSMAX_SLOTS unsigned partial maxima (the kernels that fill it spread their atomics over the slots,
+ * the kernels that use it take the largest). */
+#define MDNVAE_ABSMAX_SLOTS 64
+/* absmax = max(absmax, |floor_value|, largest |src[r][c]|), src [rows][ld], c < cols; reset != 0 clears the
+ * slots first (hipMemsetAsync on the stream).  Several tensors that share a scale are folded into one array by
  * consecutive calls with reset = 0. */
 int mdnvae_absmax(const float* src, long rows, long cols, long ld, float floor_value, int reset, unsigned* absmax,
                   void* stream);

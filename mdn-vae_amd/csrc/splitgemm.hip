@@ -72,6 +72,15 @@ __device__ __forceinline__ float sg_pow2_scale(unsigned bits) {
     return __uint_as_float((unsigned)(se < 253 ? se : 253) << 23);
 }
 __device__ __forceinline__ float sg_pow2_unscale(unsigned bits) { return 1.0f / sg_pow2_scale(bits); }
+// A tensor's largest magnitude is kept as MDNVAE_ABSMAX_SLOTS partial maxima (the kernels that fill them
+// spread their atomics over the slots); every wave that needs it takes one slot per lane.
+static_assert(MDNVAE_ABSMAX_SLOTS == 64, "one slot per lane");
+__device__ __forceinline__ unsigned sg_absmax(const unsigned* __restrict__ slots) {
+    unsigned m = slots[threadIdx.x & 63];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+    return m;
+}
 
 __device__ __forceinline__ void sg_emit_f16(const float (&v)[8], float s, char* dst) {
     sg_hfrag hi, lo;
@@ -86,7 +95,7 @@ __device__ __forceinline__ void sg_emit_f16(const float (&v)[8], float s, char* 
     *reinterpret_cast<sg_hfrag*>(dst + SG_FRAG) = lo;
 }
 
-// *amax = max(*amax, largest |src[r][c]|) as a bit pattern (magnitudes order like their bit patterns; a NaN
+// amax[blockIdx % 64] = max(itself, largest |src[r][c]| this workgroup saw) as a bit pattern (magnitudes order like their bit patterns; a NaN
 // orders above everything and so shows).  Flat over rows of `cols` floats with stride ld.
 __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ src, long rows, long cols, long ld,
                                                      float floor_value, unsigned* __restrict__ amax) {
@@ -110,11 +119,8 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ s
     for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        // only workgroups that hold something larger than the slot shows touch it: atomics on one address serialise
-        const unsigned mw = max(max(part[0], part[1]), max(part[2], part[3]));
-        if (mw > __hip_atomic_load(amax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(amax, mw);
-    }
+    if (threadIdx.x == 0)
+        atomicMax(amax + (blockIdx.x & (MDNVAE_ABSMAX_SLOTS - 1)), max(max(part[0], part[1]), max(part[2], part[3])));
 }
 
 // src [R][ld] fp32, K columns used -> tiled parts, operand row = src row, k = src column (ceil(K/16) k
@@ -128,6 +134,7 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict
                                                          int row_tile0, int KS, const unsigned* __restrict__ amax,
                                                          char* __restrict__ out) {
     __shared__ float tile[VEC ? 1 : 32][VEC ? 1 : 65];
+    const unsigned scale_bits = amax ? sg_absmax(amax) : 0u;
     const int rt = blockIdx.x, r = threadIdx.x >> 3, c = threadIdx.x & 7;
     const int k0 = blockIdx.y * 64 + c * 8;
     const int row = rt * 32 + r;
@@ -157,7 +164,7 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict
     }
     const int ks = k0 >> 4, h = (k0 >> 3) & 1;
     char* dst = out + ((long)(row_tile0 + rt) * KS + ks) * SG_STEP + h * 512 + r * 16;
-    if (amax) sg_emit_f16(v, sg_pow2_scale(*amax), dst);
+    if (amax) sg_emit_f16(v, sg_pow2_scale(scale_bits), dst);
     else sg_emit(v, dst);
 }
 
@@ -173,6 +180,7 @@ __global__ __launch_bounds__(256) void split_cols_kernel(const float* __restrict
                                                          int Kd, int R, long ld, int ones_col, int parts, int row_tile0,
                                                          int KS, const unsigned* __restrict__ amax, char* __restrict__ out) {
     __shared__ float tile[64][33];
+    const unsigned scale_bits = amax ? sg_absmax(amax) : 0u;
     const int rt = blockIdx.x, kb = blockIdx.y * 64;
     {
         const int rr = threadIdx.x >> 3, c4 = (threadIdx.x & 7) * 4;
@@ -217,7 +225,7 @@ __global__ __launch_bounds__(256) void split_cols_kernel(const float* __restrict
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = tile[q * 8 + e][r];
     char* dst = out + ((long)(row_tile0 + rt) * KS + ks) * SG_STEP + h * 512 + r * 16;
-    if (amax) sg_emit_f16(v, sg_pow2_scale(*amax), dst);
+    if (amax) sg_emit_f16(v, sg_pow2_scale(scale_bits), dst);
     else sg_emit(v, dst, parts);
 }
 
@@ -424,8 +432,8 @@ __global__ __launch_bounds__(512) void split_gemm_kernel(const char* __restrict_
 
     float unscale_a = 1.0f, unscale_b = 1.0f;
     if (F16) {
-        unscale_a = sg_pow2_unscale(*amax_a);
-        unscale_b = sg_pow2_unscale(*amax_b);
+        unscale_a = sg_pow2_unscale(sg_absmax(amax_a));
+        unscale_b = sg_pow2_unscale(sg_absmax(amax_b));
     }
     auto mfma = [](const sg_frag& a, const sg_frag& b, const sg_acc& c) {
         if constexpr (F16)
@@ -597,7 +605,7 @@ int mdnvae_absmax(const float* src, long rows, long cols, long ld, float floor_v
     MV_REQUIRE(rows >= 0 && cols >= 0 && ld >= cols, E_ARG, "mdnvae_absmax: bad shape");
     MV_REQUIRE(absmax && (src || rows * cols == 0), E_ARG, "mdnvae_absmax: null pointer");
     if (reset) {
-        const hipError_t e = hipMemsetAsync(absmax, 0, sizeof(unsigned), (hipStream_t)stream);
+        const hipError_t e = hipMemsetAsync(absmax, 0, MDNVAE_ABSMAX_SLOTS * sizeof(unsigned), (hipStream_t)stream);
         MV_REQUIRE(e == hipSuccess, (int)e, "mdnvae_absmax: cannot clear the slot: %s", hipGetErrorString(e));
     }
     const long n = rows * cols;

@@ -22,14 +22,16 @@ __device__ __forceinline__ int tri_index(int i, int j, int N) { return i * N - (
 // measured there and bought nothing: the pass is bound by its global traffic).
 //   FOLD = false: out[t] = m[i][j], *asym |= (m[i][j] != m[j][i])
 //   FOLD = true : out[t] = m[i][j] + m[j][i] (i < j), m[i][i]
-//   amax != NULL: *amax = max(*amax, bit pattern of the largest |out| written) - the scale of the
-//   two-part fp16 operand split that reads `out` next.  One atomic per wave, and only from waves
-//   that hold something larger than what the slot already shows.
+//   amax != NULL: amax[blockIdx % 64] = max(itself, bit pattern of the largest |out| written) - the scale
+//   of the two-part fp16 operand split that reads `out` next is taken from the largest of the 64 slots.
+//   One atomic without return per workgroup; 64 addresses because atomics on one address serialise
+//   (one slot for all 16384 workgroups of a batch cost 30 us of a 150 us pass).
 template <bool FOLD>
 __global__ __launch_bounds__(256) void tri_pack_kernel(const float* __restrict__ src, int N, int T, int ld,
                                                        float* __restrict__ out, int* __restrict__ asym,
                                                        unsigned* __restrict__ amax) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
+    __shared__ unsigned wave_max[4];
     const int P = N * N;
     const float* m = src + (long)blockIdx.x * P;
     float* o = out + (long)blockIdx.x * ld;
@@ -62,8 +64,11 @@ __global__ __launch_bounds__(256) void tri_pack_kernel(const float* __restrict__
     if (amax) {
 #pragma unroll
         for (int s = 32; s > 0; s >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, s));
-        if ((threadIdx.x & 63) == 0 && mx > __hip_atomic_load(amax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-            atomicMax(amax, mx);
+        if ((threadIdx.x & 63) == 0) wave_max[threadIdx.x >> 6] = mx;
+        __syncthreads();
+        if (threadIdx.x == 0)
+            atomicMax(amax + (blockIdx.x & (MDNVAE_ABSMAX_SLOTS - 1)),
+                      max(max(wave_max[0], wave_max[1]), max(wave_max[2], wave_max[3])));
     }
 }
 
@@ -126,7 +131,7 @@ static int tri_launch(bool fold, const float* src, long rows, int N, int ld, flo
     if (fold) {
         if (lds > 64 * 1024) {
             const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tri_pack_kernel<true>),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);   // static LDS: the wave maxima
             MV_REQUIRE(e == hipSuccess, (int)e, "%s: cannot raise the LDS limit: %s", who, hipGetErrorString(e));
         }
         hipLaunchKernelGGL(tri_pack_kernel<true>, dim3((unsigned)rows), dim3(256), lds, (hipStream_t)stream, src, N, T,
@@ -134,7 +139,7 @@ static int tri_launch(bool fold, const float* src, long rows, int N, int ld, flo
     } else {
         if (lds > 64 * 1024) {
             const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tri_pack_kernel<false>),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);   // static LDS: the wave maxima
             MV_REQUIRE(e == hipSuccess, (int)e, "%s: cannot raise the LDS limit: %s", who, hipGetErrorString(e));
         }
         hipLaunchKernelGGL(tri_pack_kernel<false>, dim3((unsigned)rows), dim3(256), lds, (hipStream_t)stream, src, N, T,
@@ -154,7 +159,7 @@ int mdnvae_tri_fold(const float* w, long H, int N, int ld, float* out, void* str
 
 static int tri_clear_slot(unsigned* absmax, void* stream, const char* who) {
     MV_REQUIRE(absmax, E_ARG, "%s: the largest-magnitude slot is NULL", who);
-    const hipError_t e = hipMemsetAsync(absmax, 0, sizeof(unsigned), (hipStream_t)stream);
+    const hipError_t e = hipMemsetAsync(absmax, 0, MDNVAE_ABSMAX_SLOTS * sizeof(unsigned), (hipStream_t)stream);
     MV_REQUIRE(e == hipSuccess, (int)e, "%s: cannot clear the slot: %s", who, hipGetErrorString(e));
     return 0;
 }

@@ -372,7 +372,7 @@ class GCNVAE(nn.Module):
         self.register_buffer("_asym", torch.zeros(1, dtype=torch.int32), persistent=False)
         # largest magnitude of the packed batch (bit pattern of a float), left by the packing pass for the
         # operand split of the first-layer product
-        self.register_buffer("_xmax", torch.zeros(1, dtype=torch.int32), persistent=False)
+        self.register_buffer("_xmax", torch.zeros(ops.ABSMAX_SLOTS, dtype=torch.int32), persistent=False)
         D = n_nodes * n_nodes
         self.fc11 = Linear(D, 1024)
         self.fc12 = Linear(D, 1024)

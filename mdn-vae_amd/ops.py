@@ -282,9 +282,18 @@ if SPLIT_FWD not in ("f16", "bf16"):
     raise RuntimeError("MDNVAE_SPLIT_FWD must be f16 or bf16")
 
 
+ABSMAX_SLOTS = 64      # MDNVAE_ABSMAX_SLOTS: partial maxima per tensor
+
+
 def _absmax_slots(n, device):
-    """n largest-magnitude slots (bit patterns of floats) on the device; the kernels that fill them clear them."""
-    return torch.empty(n, dtype=torch.int32, device=device)
+    """n largest-magnitude records (ABSMAX_SLOTS bit patterns of floats each) on the device, as a list; the
+    kernels that fill them clear them."""
+    return list(torch.empty(n, ABSMAX_SLOTS, dtype=torch.int32, device=device).unbind(0))
+
+
+def absmax_value(slot):
+    """The magnitude a record holds (a host read: for tests and diagnostics)."""
+    return float(slot.view(torch.float32).max().item())
 
 
 def _absmax(t, slot, reset=True, floor=0.0):
@@ -303,11 +312,11 @@ def _split_linear_fwd(x, weight, bias, act):
     y = torch.empty(B, n_out, dtype=torch.float32, device=dev)
     if SPLIT_FWD == "f16":
         mx = _absmax_slots(2, dev)
-        _absmax(weight, mx[0:1])
-        _absmax(x, mx[1:2])
-        call("mdnvae_split_rows_f16", ptr(weight, "weight"), n_out, K, K, 0, mx[0:1].data_ptr(), wb.data_ptr(), stream())
-        call("mdnvae_split_rows_f16", ptr(x, "x"), B, K, K, 0, mx[1:2].data_ptr(), xa.data_ptr(), stream())
-        call("mdnvae_split_gemm_f16", xa.data_ptr(), wb.data_ptr(), mx[1:2].data_ptr(), mx[0:1].data_ptr(), Mp, Np, Kp, B, n_out,
+        _absmax(weight, mx[0])
+        _absmax(x, mx[1])
+        call("mdnvae_split_rows_f16", ptr(weight, "weight"), n_out, K, K, 0, mx[0].data_ptr(), wb.data_ptr(), stream())
+        call("mdnvae_split_rows_f16", ptr(x, "x"), B, K, K, 0, mx[1].data_ptr(), xa.data_ptr(), stream())
+        call("mdnvae_split_gemm_f16", xa.data_ptr(), wb.data_ptr(), mx[1].data_ptr(), mx[0].data_ptr(), Mp, Np, Kp, B, n_out,
              ptr(bias, "bias"), None, int(act == ACTS["relu"]), 0, ptr(y), None, Np, n_out, 128, stream())
     else:
         call("mdnvae_split_rows", ptr(weight, "weight"), n_out, K, K, 0, wb.data_ptr(), stream())
@@ -331,12 +340,12 @@ def _split_linear_dgrad(gpre, weight):
     gx = torch.empty(B, n_in, dtype=torch.float32, device=dev)
     if SPLIT_FWD == "f16":
         mx = _absmax_slots(2, dev)
-        _absmax(gpre, mx[0:1])
-        _absmax(weight, mx[1:2])
-        call("mdnvae_split_rows_f16", ptr(gpre, "grad_pre"), B, n_out, n_out, 0, mx[0:1].data_ptr(), ga.data_ptr(), stream())
-        call("mdnvae_split_cols_f16", ptr(weight, "weight"), None, n_out, n_in, n_in, 0, 0, mx[1:2].data_ptr(), wb.data_ptr(),
+        _absmax(gpre, mx[0])
+        _absmax(weight, mx[1])
+        call("mdnvae_split_rows_f16", ptr(gpre, "grad_pre"), B, n_out, n_out, 0, mx[0].data_ptr(), ga.data_ptr(), stream())
+        call("mdnvae_split_cols_f16", ptr(weight, "weight"), None, n_out, n_in, n_in, 0, 0, mx[1].data_ptr(), wb.data_ptr(),
              stream())
-        call("mdnvae_split_gemm_f16", ga.data_ptr(), wb.data_ptr(), mx[0:1].data_ptr(), mx[1:2].data_ptr(), Mp, Np, Kp, B, n_in,
+        call("mdnvae_split_gemm_f16", ga.data_ptr(), wb.data_ptr(), mx[0].data_ptr(), mx[1].data_ptr(), Mp, Np, Kp, B, n_in,
              None, None, 0, 0, ptr(gx), None, Np, n_in, 128, stream())
         return gx
     call("mdnvae_split_rows", ptr(gpre, "grad_pre"), B, n_out, n_out, 0, ga.data_ptr(), stream())
@@ -566,7 +575,7 @@ class _SymLinearPair(torch.autograd.Function):
         if SPLIT_FWD == "f16":
             # the folding pass (and, given x_absmax, the packing pass) leaves the largest magnitude it wrote
             mx = _absmax_slots(2, dev)
-            wmax, xmax = mx[0:1], (x_absmax if x_absmax is not None else mx[1:2])
+            wmax, xmax = mx[0], (x_absmax if x_absmax is not None else mx[1])
             call("mdnvae_tri_fold_absmax", ptr(w1, "weight"), H, n_nodes, T, ptr(wt[:H]), 1, wmax.data_ptr(), stream())
             call("mdnvae_tri_fold_absmax", ptr(w2, "weight"), H, n_nodes, T, ptr(wt[H:]), 0, wmax.data_ptr(), stream())
             if x_absmax is None:
@@ -684,7 +693,7 @@ class _LinearPair(torch.autograd.Function):
         y2 = torch.empty(B, H, dtype=torch.float32, device=dev)
         if SPLIT_FWD == "f16":
             mx = _absmax_slots(2, dev)
-            wmax, xmax = mx[0:1], mx[1:2]
+            wmax, xmax = mx[0], mx[1]
             _absmax(w1, wmax)
             _absmax(w2, wmax, reset=False)
             _absmax(x, xmax)

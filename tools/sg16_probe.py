@@ -20,7 +20,7 @@ y1 = torch.empty(B, N // 2, device=DEV)
 y2 = torch.empty(B, N // 2, device=DEV)
 op = lambda r, k: torch.empty(int(_lib.load().mdnvae_split_operand_bytes(r, k)), dtype=torch.uint8, device=DEV)
 xa, wb = op(B, T), op(N, T)
-mx, mw = (torch.zeros(1, dtype=torch.int32, device=DEV) for _ in range(2))
+mx, mw = (torch.zeros(64, dtype=torch.int32, device=DEV) for _ in range(2))
 
 
 def timed(f, n=10):
