@@ -250,11 +250,13 @@ ABI_TAGS.update({
     # (src, R, K, ld, ...): the fp32 source in, two fp16 parts out; (src, gate, Kd, R, ld, ...) likewise
     "mdnvae_split_rows_f16": ("split_rows_kernel<fp16>", lambda a: 8.0 * a[1] * a[2]),
     "mdnvae_split_cols_f16": ("split_cols_kernel<fp16>", lambda a: (8.0 + (4.0 if a[1] is not None else 0.0)) * a[2] * a[3]),
+    # (src, Kd, R, ld, ones_row, parts, ...): the batch in once, two fp16 parts and `parts` bf16 parts out
+    "mdnvae_split_rows_f16_cols": ("split_both_kernel", lambda a: (8.0 + 2.0 * a[5]) * a[1] * a[3]),
     "mdnvae_absmax": ("absmax_kernel", lambda a: 4.0 * a[1] * a[2]),
     "mdnvae_tri_pack_absmax": ("tri_pack_kernel", lambda a: 4.0 * a[1] * (a[2] * a[2] + a[2] * (a[2] + 1) // 2)),
     "mdnvae_tri_fold_absmax": ("tri_pack_kernel<fold>", lambda a: 4.0 * a[1] * (a[2] * a[2] + a[2] * (a[2] + 1) // 2)),
 })
-HBM_TAGS |= {"split_rows_kernel<fp16>", "split_cols_kernel<fp16>", "absmax_kernel"}
+HBM_TAGS |= {"split_rows_kernel<fp16>", "split_cols_kernel<fp16>", "absmax_kernel", "split_both_kernel"}
 # matrix-core entry points with a fixed tag (work in flops; kept out of HBM_TAGS)
 ABI_TAGS.update({
     # (layer_in, layer_dpre, B, count, ...): one 96 x 96 x B product per (channel, layer)

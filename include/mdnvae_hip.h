@@ -309,6 +309,12 @@ int mdnvae_split_rows_f16(const float* src, long R, long K, long ld, long row_ti
                           void* stream);
 int mdnvae_split_cols_f16(const float* src, const float* gate, long Kd, long R, long ld, int ones_row, long row_tile0,
                           const unsigned* absmax, void* out, void* stream);
+/* Both operands a batch src [Kd][ld] takes part in, from one read of it: out_rows = what mdnvae_split_rows_f16(src,
+ * Kd, ld, ld, 0, absmax, ...) writes (the forward product's operand: every column up to ld), out_cols = what
+ * mdnvae_split_cols_gated(src, NULL, Kd, R, ld, ones_row, parts, 0, ...) writes (the weight-gradient product's
+ * operand: columns < R and the row of ones, bf16 parts).  ld a multiple of 16, 16-byte aligned rows. */
+int mdnvae_split_rows_f16_cols(const float* src, long Kd, long R, long ld, int ones_row, int parts, const unsigned* absmax,
+                               void* out_rows, void* out_cols, void* stream);
 /* mdnvae_split_gemm on two such operands (three products); the epilogue divides by both scales before bias and
  * ReLU.  Arguments as mdnvae_split_gemm. */
 int mdnvae_split_gemm_f16(const void* a, const void* b, const unsigned* absmax_a, const unsigned* absmax_b, long M, long N,

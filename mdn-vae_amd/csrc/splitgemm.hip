@@ -229,6 +229,60 @@ __global__ __launch_bounds__(256) void split_cols_kernel(const float* __restrict
     else sg_emit(v, dst, parts);
 }
 
+// Both operands a batch takes part in, from one read of it: src [Kd][ld] (one sample per row) becomes
+//   the forward product's operand (operand row = sample, k = column, all ld columns; two fp16 parts of
+//   src * 2^e(amax), as split_rows_kernel writes them) and
+//   the weight-gradient product's operand (operand row = column c < R, plus the row of ones, k = sample; `parts`
+//   bf16 parts, as split_cols_kernel writes them).
+// One workgroup: 64 samples x 32 columns through LDS.  ld a multiple of 32 columns' worth of tiles (grid.x * 32 >= ld
+// and >= R + ones_col), 16-byte aligned rows.
+__global__ __launch_bounds__(256) void split_both_kernel(const float* __restrict__ src, int Kd, int R, long ld, int ones_col,
+                                                         int parts, int KS_cols, int KS_rows,
+                                                         const unsigned* __restrict__ amax, char* __restrict__ out_rows,
+                                                         char* __restrict__ out_cols) {
+    __shared__ float tile[64][33];
+    const unsigned scale_bits = sg_absmax(amax);
+    const int ct = blockIdx.x, kb = blockIdx.y * 64;
+    {
+        const int rr = threadIdx.x >> 3, c4 = (threadIdx.x & 7) * 4;
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            const int kk = kb + pass * 32 + rr, col = ct * 32 + c4;
+            sg_v4 a = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (kk < Kd && col < ld) a = *reinterpret_cast<const sg_v4*>(src + (long)kk * ld + col);
+            tile[pass * 32 + rr][c4] = a.x;
+            tile[pass * 32 + rr][c4 + 1] = a.y;
+            tile[pass * 32 + rr][c4 + 2] = a.z;
+            tile[pass * 32 + rr][c4 + 3] = a.w;
+        }
+    }
+    __syncthreads();
+    {   // transposed operand: thread = (column r of the tile, eight consecutive samples q)
+        const int r = threadIdx.x & 31, q = threadIdx.x >> 5;
+        const int ks = (kb >> 4) + (q >> 1), h = q & 1, c = ct * 32 + r;
+        if (ks < KS_cols && ct * 32 < R + ones_col) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const bool in_k = kb + q * 8 + e < Kd;
+                v[e] = c < R ? tile[q * 8 + e][r] : ((ones_col && c == R && in_k) ? 1.0f : 0.0f);
+            }
+            sg_emit(v, out_cols + ((long)ct * KS_cols + ks) * SG_STEP + h * 512 + r * 16, parts);
+        }
+    }
+    {   // forward operand: thread = (sample sr of the block, eight consecutive columns pc)
+        const int sr = threadIdx.x >> 2, pc = threadIdx.x & 3;
+        const int sample = kb + sr, k0 = ct * 32 + pc * 8;
+        if (sample < ((Kd + 31) & ~31) && k0 < KS_rows * 16) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = tile[sr][pc * 8 + e];
+            sg_emit_f16(v, sg_pow2_scale(scale_bits),
+                        out_rows + ((long)(sample >> 5) * KS_rows + (k0 >> 4)) * SG_STEP + ((k0 >> 3) & 1) * 512 + (sample & 31) * 16);
+        }
+    }
+}
+
 // The transposed split operand of the gradient of a layer's outputs y = relu(...) when that gradient is itself
 // a product: g [Kd][R] = gpre [Kd][J] . w [J][R] (+ dense [Kd][R] if given), the data gradient of the next
 // dense layer (function/MM_Gate.py:159-160: fc111 / fc222 after fc11 / fc12).  operand[row_tile0 * 32 + c][r] =
@@ -646,6 +700,23 @@ int mdnvae_split_cols_f16(const float* src, const float* gate, long Kd, long R, 
                           const unsigned* absmax, void* out, void* stream) {
     MV_REQUIRE(absmax, E_ARG, "mdnvae_split_cols_f16: the largest-magnitude slot is NULL");
     return split_cols_impl(src, gate, Kd, R, ld, ones_row, 2, row_tile0, absmax, out, stream);
+}
+
+int mdnvae_split_rows_f16_cols(const float* src, long Kd, long R, long ld, int ones_row, int parts, const unsigned* absmax,
+                               void* out_rows, void* out_cols, void* stream) {
+    MV_REQUIRE(Kd >= 0 && R >= 0 && ld >= R, E_ARG, "mdnvae_split_rows_f16_cols: bad shape");
+    MV_REQUIRE(parts >= 1 && parts <= 3, E_ARG, "mdnvae_split_rows_f16_cols: parts must be 1, 2 or 3");
+    if (Kd == 0 || ld == 0) return 0;
+    MV_REQUIRE(src && absmax && out_rows && out_cols, E_ARG, "mdnvae_split_rows_f16_cols: null pointer");
+    MV_REQUIRE(ld % 16 == 0 && aligned16(src) && aligned16(out_rows) && aligned16(out_cols), E_ALIGN,
+               "mdnvae_split_rows_f16_cols: a row stride that is a multiple of 16 floats and 16-byte aligned buffers");
+    const long ctiles = ((ld > R + (ones_row ? 1 : 0) ? ld : R + (ones_row ? 1 : 0)) + 31) / 32, kb = (Kd + 63) / 64;
+    MV_REQUIRE(ctiles <= 0x7fffffffL && kb <= 65535, E_SHAPE, "mdnvae_split_rows_f16_cols: shape too large for one launch");
+    hipLaunchKernelGGL(split_both_kernel, dim3((unsigned)ctiles, (unsigned)kb), dim3(256), 0, (hipStream_t)stream, src, (int)Kd,
+                       (int)R, ld, ones_row ? 1 : 0, parts, (int)((Kd + 15) / 16), (int)(ld / 16), absmax, (char*)out_rows,
+                       (char*)out_cols);
+    MV_LAUNCH_CHECK("split_both_kernel");
+    return 0;
 }
 
 int mdnvae_split_cols(const float* src, long Kd, long R, long ld, long row_tile0, void* out, void* stream) {

@@ -550,6 +550,20 @@ def _round_up(v, m):
     return (v + m - 1) // m * m
 
 
+def _pair_wgrad_shape(B, T, H, n_nodes):
+    """(parts, Kp, t_real, rows, halves, tile, Tp) of the weight-gradient product of the symmetric first-layer pair."""
+    parts = 2 if SPLIT_WGRAD_TERMS == 3 else 3
+    Kp = _round_up(B, 16)
+    # the row of ones goes where the packed triangle's zero padding starts (one past the end if there is none)
+    t_real = min(n_nodes * (n_nodes + 1) // 2, T)
+    rows = max(T, t_real + 1)
+    # few output tiles and a long k (the batch): 256-row tiles with the k range split in two keep twice
+    # the fragments in registers per LDS byte read
+    halves = SPLIT_WGRAD_TERMS == 3 and SPLIT_WGRAD_KSPLIT and B >= 4096 and (rows + 255) // 256 * (2 * H // 256) <= 128
+    tile = 256 if halves else 128
+    return parts, Kp, t_real, rows, halves, tile, _round_up(rows, tile)
+
+
 class _SymLinearPair(torch.autograd.Function):
     """relu(x W1^T + b1), relu(x W2^T + b2) for symmetric x given as packed upper triangles xt [B,T]
     (self.fc11 / self.fc12 of function/MM_Gate.py:157-158, which read the same input): the two folded
@@ -566,6 +580,7 @@ class _SymLinearPair(torch.autograd.Function):
             raise RuntimeError(f"sym_linear_pair: two [H,N*N] weights with biases, H a multiple of 256 (got {tuple(w1.shape)}, "
                                f"{tuple(w2.shape)}), T a multiple of 16 (got {T})")
         dev = xt.device
+        xb = None
         wt = torch.empty(2 * H, T, dtype=torch.float32, device=dev)
         wb = _split_operand(2 * H, T, dev)
         Mp = _round_up(B, 256)
@@ -581,7 +596,14 @@ class _SymLinearPair(torch.autograd.Function):
             if x_absmax is None:
                 _absmax(xt, xmax)
             call("mdnvae_split_rows_f16", ptr(wt), 2 * H, T, T, 0, wmax.data_ptr(), wb.data_ptr(), stream())
-            call("mdnvae_split_rows_f16", ptr(xt, "x"), B, T, T, 0, xmax.data_ptr(), xa.data_ptr(), stream())
+            if any(ctx.needs_input_grad[1:5]) and T % 16 == 0:
+                # the backward's transposed operand of the batch from the same read of it
+                parts, Kp, t_real, rows, halves, tile, Tp = _pair_wgrad_shape(B, T, H, n_nodes)
+                xb = _split_operand(Tp, Kp, dev)
+                call("mdnvae_split_rows_f16_cols", ptr(xt, "x"), B, t_real, T, 1, parts, xmax.data_ptr(), xa.data_ptr(),
+                     xb.data_ptr(), stream())
+            else:
+                call("mdnvae_split_rows_f16", ptr(xt, "x"), B, T, T, 0, xmax.data_ptr(), xa.data_ptr(), stream())
             call("mdnvae_split_gemm_f16", xa.data_ptr(), wb.data_ptr(), xmax.data_ptr(), wmax.data_ptr(), Mp, 2 * H, T, B, H,
                  ptr(b1, "bias"), ptr(b2, "bias"), 1, 0, ptr(y1), ptr(y2), H, H, 256, stream())
         else:
@@ -592,6 +614,7 @@ class _SymLinearPair(torch.autograd.Function):
             call("mdnvae_split_gemm", xa.data_ptr(), wb.data_ptr(), Mp, 2 * H, T, B, H, ptr(b1, "bias"), ptr(b2, "bias"), 1, 0,
                  ptr(y1), ptr(y2), H, H, 256, 6, stream())
         ctx.save_for_backward(xt, y1, y2)
+        ctx.xb = xb
         ctx.n_nodes = n_nodes
         ctx.params = (w1, b1, w2, b2)
         ctx.slots = None
@@ -615,8 +638,7 @@ class _SymLinearPair(torch.autograd.Function):
         # row of ones appended (so that row T of the result is the column sum of grad_pre) and grad_pre^T,
         # which is split straight from the output gradients with the ReLU gate applied on the way
         # (grad_pre itself is never written)
-        parts = 2 if SPLIT_WGRAD_TERMS == 3 else 3
-        Kp = _round_up(B, 16)
+        parts, Kp, t_real, rows, halves, tile, Tp = _pair_wgrad_shape(B, T, H, n)
         pb = _split_operand(2 * H, Kp, dev)
         for i, (y, g, slot) in enumerate(((y1, g1, slots[0]), (y2, g2, slots[1]))):
             if slot is not None and slot.gpre is not None:
@@ -628,16 +650,10 @@ class _SymLinearPair(torch.autograd.Function):
             else:
                 call("mdnvae_split_cols_gated", ptr(_c(g)), ptr(y), B, H, H, 0, parts, i * (H // 32), pb.data_ptr(),
                      stream())
-        # the row of ones goes where the packed triangle's zero padding starts (one past the end if there is none)
-        t_real = min(n * (n + 1) // 2, T)
-        rows = max(T, t_real + 1)
-        # few output tiles and a long k (the batch): 256-row tiles with the k range split in two keep twice
-        # the fragments in registers per LDS byte read
-        halves = SPLIT_WGRAD_TERMS == 3 and SPLIT_WGRAD_KSPLIT and B >= 4096 and (rows + 255) // 256 * (2 * H // 256) <= 128
-        tile = 256 if halves else 128
-        Tp = _round_up(rows, tile)
-        xb = _split_operand(Tp, Kp, dev)
-        call("mdnvae_split_cols_gated", ptr(xt), None, B, t_real, T, 1, parts, 0, xb.data_ptr(), stream())
+        xb, ctx.xb = ctx.xb, None
+        if xb is None:
+            xb = _split_operand(Tp, Kp, dev)
+            call("mdnvae_split_cols_gated", ptr(xt), None, B, t_real, T, 1, parts, 0, xb.data_ptr(), stream())
         gts = [(torch.zeros if halves else torch.empty)(rows, H, dtype=torch.float32, device=dev) for _ in range(2)]
         call("mdnvae_split_gemm", xb.data_ptr(), pb.data_ptr(), Tp, 2 * H, Kp, t_real + 1, H, None, None, 0,
              2 if halves else 0, ptr(gts[0]), ptr(gts[1]), H, H, tile, SPLIT_WGRAD_TERMS, stream())

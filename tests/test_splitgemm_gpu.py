@@ -164,6 +164,27 @@ def test_two_part_fp16_small_entries_and_shared_slots():
     assert float(out.abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("B,R,ld,parts", [(1000, 3828, 3840, 2), (130, 2346, 2368, 3), (64, 40, 48, 2)])
+def test_both_operands_of_a_batch_from_one_pass(B, R, ld, parts):
+    """mdnvae_split_rows_f16_cols writes, byte for byte, what mdnvae_split_rows_f16 and mdnvae_split_cols_gated
+    (with the row of ones) write from the same batch."""
+    g = torch.Generator().manual_seed(B)
+    src = torch.zeros(B, ld)
+    src[:, :R] = torch.rand(B, R, generator=g) * 7.0
+    src = src.to(DEV)
+    mx = _amax_slot()
+    call("mdnvae_absmax", ptr(src), B, ld, ld, 0.0, 1, mx.data_ptr(), stream())
+    rows_a, rows_b = (torch.zeros(int(_lib.load().mdnvae_split_operand_bytes(_up(B, 32), ld)), dtype=torch.uint8, device=DEV)
+                      for _ in range(2))
+    cols_a, cols_b = (torch.zeros(int(_lib.load().mdnvae_split_operand_bytes(_up(R + 1, 32), _up(B, 16))), dtype=torch.uint8,
+                                  device=DEV) for _ in range(2))
+    call("mdnvae_split_rows_f16", ptr(src), B, ld, ld, 0, mx.data_ptr(), rows_a.data_ptr(), stream())
+    call("mdnvae_split_cols_gated", ptr(src), None, B, R, ld, 1, parts, 0, cols_a.data_ptr(), stream())
+    call("mdnvae_split_rows_f16_cols", ptr(src), B, R, ld, 1, parts, mx.data_ptr(), rows_b.data_ptr(), cols_b.data_ptr(), stream())
+    assert torch.equal(rows_a, rows_b)
+    assert torch.equal(cols_a, cols_b)
+
+
 @pytest.mark.parametrize("terms", [3, 6])
 @pytest.mark.parametrize("B,n", [(1024, 68), (1500, 87)])
 def test_first_layer_pair_against_float64_and_the_library_path(B, n, terms, monkeypatch):
