@@ -37,9 +37,11 @@ TRAFFIC_RATIO = {"loss_stream_kernel": 1.00, "mdn_fwd_kernel": 1.10, "mdn_bwd_st
                  "mdn_outer_kernel": 1.03, "tri_pack_kernel": 1.01, "adam_kernel": 1.00}
 
 # fabric-side bytes per launch of the matrix-core kernels, collected the same way at the default workload's shapes
-# (profiles/r02_e_mdn_gate_B16384_counters.csv); keyed by the launch's executed flops so that another shape reports null
+# (profiles/r02_e_mdn_gate_B16384_counters.csv, r02_g_...); keyed by the launch's executed flops so that another shape reports null
 TRAFFIC_BYTES = {("split_gemm_kernel", 12.0 * 16384 * 2048 * 3840): (1207.6 + 208.7) * 1e6,
-                 ("split_gemm_kernel<3 terms>", 6.0 * 3829 * 2048 * 16384): (1454.4 + 66.7) * 1e6}
+                 # profiles/r02_g_mdn_gate_B16384_counters.csv (the four-stage ring)
+                 ("split_gemm_kernel<3 fp16 terms>", 6.0 * 16384 * 2048 * 3840): (755.7 + 134.2) * 1e6,
+                 ("split_gemm_kernel<3 terms>", 6.0 * 3829 * 2048 * 16384): (1443.1 + 62.7) * 1e6}
 
 REHEARSE_EXCHANGE = False
 
