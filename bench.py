@@ -266,6 +266,7 @@ ABI_TAGS.update({
                              lambda a: 2.0 * a[2] * a[3] * ops.DEC_KP * ops.DEC_NP),
     # (grad_pre, x, B, N, M, ...)
     "mdnvae_linear_wgrad": ("tsgemm_partial_kernel+tsgemm_reduce_kernel", lambda a: 2.0 * a[2] * a[3] * a[4]),
+    "mdnvae_linear_wgrad_bias": ("tsgemm_partial_kernel+tsgemm_reduce_kernel", lambda a: 2.0 * a[2] * a[3] * a[4]),
 })
 
 

@@ -218,6 +218,11 @@ int mdnvae_colsum(const float* a, int B, int D, float* workspace, float* out, in
 size_t mdnvae_linear_wgrad_workspace_floats(int B, int N, int M);
 int mdnvae_linear_wgrad(const float* grad_pre, const float* x, int B, int N, int M, float* workspace, float* grad_w,
                         int accumulate, void* stream);
+/* The same launch pair also giving the layer's bias gradient grad_b [N] = column sums of grad_pre (autograd of the
+ * bias of the same F.linear): every lane sums the values it feeds to the matrix cores, the slab sums ride along in
+ * the reduction launch.  accumulate_b != 0: grad_b += the sums.  Same workspace query. */
+int mdnvae_linear_wgrad_bias(const float* grad_pre, const float* x, int B, int N, int M, float* workspace, float* grad_w,
+                             int accumulate, float* grad_b, int accumulate_b, void* stream);
 
 /* ---- first dense layer on symmetric connectomes --------------------------------------------
  * `self.fc11(x.view(-1, N*N))` (function/MM_Gate.py:157-165; function_FC_SC/SC-FC.py:95-104) sums

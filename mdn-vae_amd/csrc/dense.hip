@@ -143,15 +143,17 @@ __global__ __launch_bounds__(256) void narrow_wgrad_partial_kernel(const float* 
             for (int m = 0; m < NL_MAX; ++m) acc[n][m] = __builtin_fmaf(gv[n], xv[m], acc[n][m]);
         }
     }
+    // 72 wave sums: on the DPP path (six VALU operations each; the shuffle form goes through the LDS crossbar
+    // and made this kernel 17 us for a 5 x 4 weight), the total lands in lane 63
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
 #pragma unroll
     for (int n = 0; n < NL_MAX; ++n) {
-        const float sb = wave_sum(accb[n]);
-        if (lane == 0) sm[wid][NL_MAX * NL_MAX + n] = sb;
+        const float sb = wave_sum_dpp(accb[n]);
+        if (lane == 63) sm[wid][NL_MAX * NL_MAX + n] = sb;
 #pragma unroll
         for (int m = 0; m < NL_MAX; ++m) {
-            const float sw = wave_sum(acc[n][m]);
-            if (lane == 0) sm[wid][n * NL_MAX + m] = sw;
+            const float sw = wave_sum_dpp(acc[n][m]);
+            if (lane == 63) sm[wid][n * NL_MAX + m] = sw;
         }
     }
     __syncthreads();
@@ -165,8 +167,18 @@ __global__ __launch_bounds__(128) void narrow_wgrad_final_kernel(const float* __
                                                                  float* __restrict__ gb) {
     const int t = threadIdx.x;
     if (t >= NL_VALS) return;
+    // the partial sums are added in block order; sixteen loads in flight (one at a time, the 64 round trips
+    // of this loop were 16 us)
     float sum = 0.0f;
-    for (int p = 0; p < nparts; ++p) sum += part[(long)p * NL_VALS + t];
+    int p = 0;
+    for (; p + 16 <= nparts; p += 16) {
+        float v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = part[(long)(p + u) * NL_VALS + t];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) sum += v[u];
+    }
+    for (; p < nparts; ++p) sum += part[(long)p * NL_VALS + t];
     if (t < NL_MAX * NL_MAX) {
         const int n = t / NL_MAX, m = t - n * NL_MAX;
         if (n < N && m < M) gw[n * M + m] = accumulate ? gw[n * M + m] + sum : sum;

@@ -52,10 +52,12 @@ __device__ __forceinline__ void ts_commit(const float4 (&cg)[TS_GQ], const float
     }
 }
 
-// grid: (m tiles, n tiles, slabs); part[slab][n][m]
+// grid: (m tiles, n tiles, slabs); part[slab][n][m].  part_b (or NULL): [slab][n] = the slab's column sums of g,
+// the bias gradient of the same layer - every lane adds up the g values it feeds to the matrix cores anyway, the
+// workgroups of the first m tile store them.
 __global__ __launch_bounds__(TS_NT) void tsgemm_partial_kernel(const float* __restrict__ g, const float* __restrict__ x,
                                                                int B, int N, int M, int slab_rows,
-                                                               float* __restrict__ part) {
+                                                               float* __restrict__ part, float* __restrict__ part_b) {
     __shared__ __attribute__((aligned(16))) float gs[2][TS_KC * TS_GLD];
     __shared__ __attribute__((aligned(16))) float xs[2][TS_KC * TS_XLD];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -65,6 +67,7 @@ __global__ __launch_bounds__(TS_NT) void tsgemm_partial_kernel(const float* __re
     f32x16 acc0, acc1;
 #pragma unroll
     for (int j = 0; j < 16; ++j) acc0[j] = acc1[j] = 0.0f;
+    float bsum = 0.0f;
     float4 cg[TS_GQ], cx[TS_XQ];
     ts_fetch(g, x, N, M, b_begin, b_end, n0, m0, cg, cx);
     ts_commit(cg, cx, gs[0], xs[0]);
@@ -79,12 +82,18 @@ __global__ __launch_bounds__(TS_NT) void tsgemm_partial_kernel(const float* __re
 #pragma unroll
         for (int k = 0; k < TS_KC; k += 2) {
             const float av = ga[k * TS_GLD];
+            bsum += av;
             const float b0v = xb[k * TS_XLD], b1v = xb[k * TS_XLD + 32];
             acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0v, acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1v, acc1, 0, 0, 0);
         }
         if (more) ts_commit(cg, cx, gs[cur ^ 1], xs[cur ^ 1]);
         __syncthreads();
+    }
+    if (part_b && blockIdx.x == 0 && wm == 0) {
+        // lanes l32 and l32 + 32 hold the even and the odd samples of column n0 + wn + l32
+        bsum += __shfl_xor(bsum, 32);
+        if (h == 0 && n0 + wn + l32 < N) part_b[(long)blockIdx.z * N + n0 + wn + l32] = bsum;
     }
     float* dst = part + (long)blockIdx.z * N * M;
 #pragma unroll
@@ -100,11 +109,23 @@ __global__ __launch_bounds__(TS_NT) void tsgemm_partial_kernel(const float* __re
 
 // out[e] = sum_s part[s][e]: a workgroup covers 64 quads of e with four groups of lanes that each
 // add every fourth slab (four loads in flight), the four group sums meet in LDS in a fixed order
+// A second, smaller sum (part2, count2, accumulate2, out2: the bias gradient's partial column sums) rides along
+// in the blocks past the first one's: one launch for both.
 __global__ __launch_bounds__(256) void tsgemm_reduce_kernel(const float* __restrict__ part, int slabs, long count,
-                                                            int accumulate, float* __restrict__ out) {
+                                                            int accumulate, float* __restrict__ out, int blocks1,
+                                                            const float* __restrict__ part2, long count2, int accumulate2,
+                                                            float* __restrict__ out2) {
     __shared__ float4 sm[4][64];
     const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
-    const long e4 = (long)blockIdx.x * 64 + col;
+    int blk = blockIdx.x;
+    if (blk >= blocks1) {
+        blk -= blocks1;
+        part = part2;
+        count = count2;
+        accumulate = accumulate2;
+        out = out2;
+    }
+    const long e4 = (long)blk * 64 + col;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     if (e4 * 4 < count) {
         int p = grp;
@@ -251,32 +272,46 @@ using namespace mdnvae;
 
 extern "C" {
 
+// the slabs' partial tiles, then (for the entry point that also gives the bias gradient) their column sums
 size_t mdnvae_linear_wgrad_workspace_floats(int B, int N, int M) {
     if (B < 1 || N < 1 || M < 1) return 0;
-    return (size_t)ts_slabs(B, N, M) * N * M;
+    return (size_t)ts_slabs(B, N, M) * ((size_t)N * M + N);
 }
 
-int mdnvae_linear_wgrad(const float* grad_pre, const float* x, int B, int N, int M, float* workspace, float* grad_w,
-                        int accumulate, void* stream) {
-    MV_REQUIRE(B >= 1 && N >= 1 && M >= 1, E_ARG, "mdnvae_linear_wgrad: empty operand");
-    MV_REQUIRE((N & 3) == 0 && (M & 3) == 0, E_SHAPE,
-               "mdnvae_linear_wgrad: N = %d and M = %d must be multiples of 4 (16-byte rows)", N, M);
-    MV_REQUIRE(grad_pre && x && workspace && grad_w, E_ARG, "mdnvae_linear_wgrad: null pointer");
-    MV_REQUIRE(aligned16(grad_pre) && aligned16(x) && aligned16(workspace) && aligned16(grad_w), E_ALIGN,
-               "mdnvae_linear_wgrad: operands must be 16-byte aligned");
+static int linear_wgrad_impl(const char* fn, const float* grad_pre, const float* x, int B, int N, int M, float* workspace,
+                             float* grad_w, int accumulate, float* grad_b, int accumulate_b, void* stream) {
+    MV_REQUIRE(B >= 1 && N >= 1 && M >= 1, E_ARG, "%s: empty operand", fn);
+    MV_REQUIRE((N & 3) == 0 && (M & 3) == 0, E_SHAPE, "%s: N = %d and M = %d must be multiples of 4 (16-byte rows)", fn, N, M);
+    MV_REQUIRE(grad_pre && x && workspace && grad_w, E_ARG, "%s: null pointer", fn);
+    MV_REQUIRE(aligned16(grad_pre) && aligned16(x) && aligned16(workspace) && aligned16(grad_w) && aligned16(grad_b), E_ALIGN,
+               "%s: operands must be 16-byte aligned", fn);
     const int slabs = ts_slabs(B, N, M);
     const int slab_rows = ((B + slabs - 1) / slabs + TS_KC - 1) / TS_KC * TS_KC;
     const int used = (B + slab_rows - 1) / slab_rows;
     const dim3 grid((M + TS_TM - 1) / TS_TM, (N + TS_TN - 1) / TS_TN, used);
-    MV_REQUIRE(grid.y <= 65535 && grid.z <= 65535, E_SHAPE, "mdnvae_linear_wgrad: shape too large");
+    MV_REQUIRE(grid.y <= 65535 && grid.z <= 65535, E_SHAPE, "%s: shape too large", fn);
+    float* part_b = grad_b ? workspace + (size_t)used * N * M : nullptr;
     hipLaunchKernelGGL(tsgemm_partial_kernel, grid, dim3(TS_NT), 0, (hipStream_t)stream, grad_pre, x, B, N, M, slab_rows,
-                       workspace);
+                       workspace, part_b);
     MV_LAUNCH_CHECK("tsgemm_partial_kernel");
     const long count = (long)N * M;
-    hipLaunchKernelGGL(tsgemm_reduce_kernel, dim3((unsigned)((count / 4 + 63) / 64)), dim3(256), 0, (hipStream_t)stream,
-                       workspace, used, count, accumulate, grad_w);
+    const int blocks1 = (int)((count / 4 + 63) / 64), blocks2 = grad_b ? (N / 4 + 63) / 64 : 0;
+    hipLaunchKernelGGL(tsgemm_reduce_kernel, dim3((unsigned)(blocks1 + blocks2)), dim3(256), 0, (hipStream_t)stream,
+                       workspace, used, count, accumulate, grad_w, blocks1, part_b, (long)N, accumulate_b, grad_b);
     MV_LAUNCH_CHECK("tsgemm_reduce_kernel");
     return 0;
+}
+
+int mdnvae_linear_wgrad(const float* grad_pre, const float* x, int B, int N, int M, float* workspace, float* grad_w,
+                        int accumulate, void* stream) {
+    return linear_wgrad_impl("mdnvae_linear_wgrad", grad_pre, x, B, N, M, workspace, grad_w, accumulate, nullptr, 0, stream);
+}
+
+int mdnvae_linear_wgrad_bias(const float* grad_pre, const float* x, int B, int N, int M, float* workspace, float* grad_w,
+                             int accumulate, float* grad_b, int accumulate_b, void* stream) {
+    MV_REQUIRE(grad_b, E_ARG, "mdnvae_linear_wgrad_bias: grad_b is null");
+    return linear_wgrad_impl("mdnvae_linear_wgrad_bias", grad_pre, x, B, N, M, workspace, grad_w, accumulate, grad_b,
+                             accumulate_b, stream);
 }
 
 size_t mdnvae_decoder_wgrad_workspace_floats(int B, int count) {
@@ -298,8 +333,9 @@ int mdnvae_decoder_wgrad(const float* layer_in, const float* layer_dpre, int B, 
                        layer_dpre, B, slab_rows, workspace);
     MV_LAUNCH_CHECK("panel_wgrad_partial_kernel");
     const long n = (long)count * PW * PW;
-    hipLaunchKernelGGL(tsgemm_reduce_kernel, dim3((unsigned)((n / 4 + 63) / 64)), dim3(256), 0, (hipStream_t)stream,
-                       workspace, used, n, 0, dwt);
+    const int blocks1 = (int)((n / 4 + 63) / 64);
+    hipLaunchKernelGGL(tsgemm_reduce_kernel, dim3((unsigned)blocks1), dim3(256), 0, (hipStream_t)stream, workspace, used, n, 0,
+                       dwt, blocks1, (const float*)nullptr, 0L, 0, (float*)nullptr);
     MV_LAUNCH_CHECK("tsgemm_reduce_kernel");
     return 0;
 }

@@ -222,6 +222,25 @@ def _linear_wgrad(gpre, x, into=None):
     return gw
 
 
+def _linear_wgrad_bias(gpre, x, weight_param, bias_param):
+    """(grad_w, grad_b) of a small dense layer from one launch pair (the bias gradient rides along in the
+    split-over-the-batch weight gradient); None for what went straight into the parameter's .grad."""
+    B, N = gpre.shape
+    M = x.shape[1]
+    ws = torch.empty(_lib.workspace_bytes_f("mdnvae_linear_wgrad_workspace_floats", B, N, M), dtype=torch.float32,
+                     device=x.device)
+    tw, tb = _grad_target(weight_param), _grad_target(bias_param)
+    gw = tw if tw is not None else torch.empty(N, M, dtype=torch.float32, device=x.device)
+    gb = tb if tb is not None else torch.empty(N, dtype=torch.float32, device=x.device)
+    call("mdnvae_linear_wgrad_bias", ptr(gpre, "grad_pre"), ptr(x, "x"), B, N, M, ptr(ws), ptr(gw), int(tw is not None),
+         ptr(gb), int(tb is not None), stream())
+    if tw is not None:
+        _grad_added(weight_param)
+    if tb is not None:
+        _grad_added(bias_param)
+    return (None if tw is not None else gw), (None if tb is not None else gb)
+
+
 NARROW_MAX = 8
 
 
@@ -449,6 +468,10 @@ class _LinearAct(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             if split:
                 gw = _split_linear_wgrad(_c(gpre), x, ctx.params[0])
+            elif (_small_wgrad_ok(x.shape[0], weight.shape[0], weight.shape[1]) and ctx.has_bias and ctx.needs_input_grad[2]
+                  and x.dim() == 2):
+                gw, gb = _linear_wgrad_bias(_c(gpre), x, ctx.params[0], ctx.params[1])
+                return gx, gw, gb, None
             elif _small_wgrad_ok(x.shape[0], weight.shape[0], weight.shape[1]):
                 target = _grad_target(ctx.params[0])
                 if target is not None:

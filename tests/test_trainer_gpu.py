@@ -161,6 +161,20 @@ def test_small_layer_weight_gradient_kernel(B, N, M):
     # reproducible: fixed summation order
     again = ops._linear_wgrad(gp.to(DEV), x.to(DEV))
     assert torch.equal(got, again)
+    # the same launch pair also giving the bias gradient (column sums of grad_pre): same weight gradient bit for
+    # bit, bias gradient against float64; then both added onto what the outputs hold
+    gw, gb = ops._linear_wgrad_bias(gp.to(DEV), x.to(DEV), None, None)
+    assert torch.equal(gw, got)
+    want_b = gp.double().sum(0)
+    assert float((gb.double().cpu() - want_b).abs().max()) <= 1e-5 * float(want_b.abs().max()) + 1e-4
+    w_par = torch.nn.Parameter(torch.zeros(N, M, device=DEV))
+    b_par = torch.nn.Parameter(torch.zeros(N, device=DEV))
+    w_par.grad, b_par.grad = torch.full((N, M), 2.0, device=DEV), torch.full((N,), 3.0, device=DEV)
+    with ops.accumulate_into_grads():
+        none_w, none_b = ops._linear_wgrad_bias(gp.to(DEV), x.to(DEV), w_par, b_par)
+    assert none_w is None and none_b is None
+    assert float((w_par.grad - 2.0 - got).abs().max()) <= 1e-5 * float(want.abs().max())
+    assert float((b_par.grad - 3.0 - gb).abs().max()) <= 1e-5 * float(want_b.abs().max()) + 1e-4
 
 
 @pytest.mark.parametrize("B,N,M,act", [(16384, 5, 4, None), (1000, 8, 8, "tanh"), (257, 1, 1, "relu"), (3, 2, 7, "sigmoid"),
