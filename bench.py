@@ -202,6 +202,8 @@ ABI_TAGS = {
     "mdnvae_mdn_loss_fwd": ("mdn_fwd_kernel", lambda a: 4.0 * a[4] * ((a[5] + 1) * a[6] + 2 * a[9] + 3 * a[5])),
     "mdnvae_mdn_loss_bwd": ("mdn_bwd_stream_kernel", lambda a: 4.0 * a[6] * ((2 * a[7] + 1) * a[8] + 4 * a[11] + 5 * a[7])),
     "mdnvae_mdn_outer_fwdbwd": ("mdn_outer_kernel", _mdn_outer_work),
+    # (workspace, B, loss_out, rows, K, ...): the per-sample pairs and the [B,K] log-sigma rows, one read each
+    "mdnvae_mdn_finalize": ("mdn_finalize_kernel", lambda a: a[1] * (16.0 + 4.0 * (a[4] if a[3] is not None else 0))),
     # (mode, nodes, x, B, R, N, mu, logvar, L, ...): x once, node vectors in, their gradient out, latent rows
     "mdnvae_outer_loss_fwdbwd": ("outer_loss_kernel",
                                  lambda a: 4.0 * a[3] * (a[5] * a[5] + 2 * a[4] * ops.DEC_NP + 4 * a[8])),

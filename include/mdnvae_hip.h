@@ -449,11 +449,18 @@ int mdnvae_mdn_loss_fwd(const float* comp_mean, const float* x, const float* gat
  * workspace of mdnvae_mdn_workspace_bytes(B) bytes.  K <= 8, N <= MDNVAE_DEC_NP-1.
  * x_symmetric != 0: the caller vouches that every x[b] equals its transpose (e.g. mdnvae_tri_pack
  * has checked the same buffer); the pass then needs no row sums and runs at streaming speed.  On
- * input that is not symmetric the loss is still right but grad_nodes is not. */
+ * input that is not symmetric the loss is still right but grad_nodes is not.
+ * loss_out = NULL: the per-sample terms stay in the workspace (two doubles per sample) and
+ * mdnvae_mdn_finalize adds them up later - for a caller that sums several chunks, or times the pass on its own. */
 int mdnvae_mdn_outer_fwdbwd(const float* nodes, const float* x, const float* gate_logits, const float* log_sigma,
                             int B, int K, int N, const float* mu, const float* logvar, int L, float* grad_nodes,
                             float* grad_logits, float* grad_log_sigma_rows, float* grad_mu, float* grad_logvar,
                             float* resp, int x_symmetric, void* workspace, float* loss_out, void* stream);
+/* loss_out[3] = {nll + KL, nll, KL} from the per-sample terms mdnvae_mdn_outer_fwdbwd (or mdnvae_mdn_loss_fwd) left
+ * in `workspace` for B samples: one workgroup, fixed summation order.  grad_log_sigma_rows [B,K] and grad_log_sigma
+ * [K] (both or neither): the same launch adds up the per-sample log-sigma gradients in a second workgroup. */
+int mdnvae_mdn_finalize(const void* workspace, int B, float* loss_out, const float* grad_log_sigma_rows, int K,
+                        float* grad_log_sigma, void* stream);
 /* mdnvae_mdn_outer_fwdbwd without the workspace argument, for callers that cannot allocate device
  * memory (code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc).  It has
  * no counterpart in the reference.  The per-sample partial sums live in a static 1 MiB device array

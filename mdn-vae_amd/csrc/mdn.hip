@@ -152,10 +152,41 @@ __global__ __launch_bounds__(MDN_NT) void mdn_fwd_kernel(const float* __restrict
     }
 }
 
-// out[0] = nll + KL, out[1] = nll, out[2] = KL (fixed summation order)
+// out[0] = nll + KL, out[1] = nll, out[2] = KL (fixed summation order).  A second workgroup, when rows is given,
+// adds up the K columns of rows [B][K] (the per-sample log-sigma gradients) into colsum [K]: thread t takes
+// samples t, t + PAIR_NT, ... (four rows in flight), the threads' sums meet in a fixed order.
 __global__ __launch_bounds__(PAIR_NT) void mdn_finalize_kernel(const double* __restrict__ per_sample, int B,
-                                                           float* __restrict__ out) {
+                                                           float* __restrict__ out, const float* __restrict__ rows, int K,
+                                                           float* __restrict__ colsum) {
     __shared__ double red[PAIR_NT / 64];
+    if (blockIdx.x == 1) {
+        __shared__ float redf[PAIR_NT / 64];
+        float acc[MDN_MAXK];
+#pragma unroll
+        for (int k = 0; k < MDN_MAXK; ++k) acc[k] = 0.0f;
+        int b = threadIdx.x;
+        for (; b + 3 * PAIR_NT < B; b += 4 * PAIR_NT) {
+            float v[4][MDN_MAXK];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int k = 0; k < MDN_MAXK; ++k) v[u][k] = k < K ? rows[(long)(b + u * PAIR_NT) * K + k] : 0.0f;
+#pragma unroll
+            for (int k = 0; k < MDN_MAXK; ++k) acc[k] += (v[0][k] + v[1][k]) + (v[2][k] + v[3][k]);
+        }
+        for (; b < B; b += PAIR_NT)
+#pragma unroll
+            for (int k = 0; k < MDN_MAXK; ++k)
+                if (k < K) acc[k] += rows[(long)b * K + k];
+#pragma unroll
+        for (int k = 0; k < MDN_MAXK; ++k) {
+            if (k < K) {
+                const float t = block_sum<PAIR_NT, float>(acc[k], redf);
+                if (threadIdx.x == 0) colsum[k] = t;
+            }
+        }
+        return;
+    }
     const PairSum t = block_pair_sum(per_sample, B, red);
     if (threadIdx.x == 0) {
         out[0] = (float)(t.a + t.k);
@@ -994,7 +1025,8 @@ int mdnvae_mdn_loss_fwd(const float* comp_mean, const float* x, const float* gat
 #undef CALL
         MV_LAUNCH_CHECK("mdn_fwd_kernel");
     }
-    hipLaunchKernelGGL(mdn_finalize_kernel, dim3(1), dim3(PAIR_NT), 0, st, (const double*)workspace, B, loss_out);
+    hipLaunchKernelGGL(mdn_finalize_kernel, dim3(1), dim3(PAIR_NT), 0, st, (const double*)workspace, B, loss_out,
+                       (const float*)nullptr, 0, (float*)nullptr);
     MV_LAUNCH_CHECK("mdn_finalize_kernel");
     return 0;
 }
@@ -1009,7 +1041,7 @@ static int mdn_outer_launch(const char* fn, const float* nodes, const float* x, 
     MV_REQUIRE(B >= 0 && L >= 0, E_ARG, "%s: bad size", fn);
     MV_REQUIRE(N >= 1 && N <= MO_NP - 1, E_SHAPE, "%s: N = %d outside 1..%d", fn, N, MO_NP - 1);
     MV_REQUIRE(K >= 1 && K <= MDN_MAXK, E_SHAPE, "%s: %d components (1..%d supported)", fn, K, MDN_MAXK);
-    MV_REQUIRE(per_sample && loss_out, E_ARG, "%s: workspace/loss_out is null", fn);
+    MV_REQUIRE(per_sample, E_ARG, "%s: workspace is null", fn);
     if (B > 0) {
         MV_REQUIRE(nodes && x && gate_logits && log_sigma && grad_nodes && grad_logits && grad_log_sigma_rows && resp,
                    E_ARG, "%s: null pointer", fn);
@@ -1044,7 +1076,23 @@ static int mdn_outer_launch(const char* fn, const float* nodes, const float* x, 
 #undef MV_SYM_STREAM
         MV_LAUNCH_CHECK("mdn_outer_kernel");
     }
-    hipLaunchKernelGGL(mdn_finalize_kernel, dim3(1), dim3(PAIR_NT), 0, st, (const double*)per_sample, B, loss_out);
+    if (loss_out) {
+        hipLaunchKernelGGL(mdn_finalize_kernel, dim3(1), dim3(PAIR_NT), 0, st, (const double*)per_sample, B, loss_out,
+                           (const float*)nullptr, 0, (float*)nullptr);
+        MV_LAUNCH_CHECK("mdn_finalize_kernel");
+    }
+    return 0;
+}
+
+int mdnvae_mdn_finalize(const void* workspace, int B, float* loss_out, const float* grad_log_sigma_rows, int K,
+                        float* grad_log_sigma, void* stream) {
+    MV_REQUIRE(B >= 0 && workspace && loss_out, E_ARG, "mdnvae_mdn_finalize: bad argument");
+    MV_REQUIRE((grad_log_sigma_rows == nullptr) == (grad_log_sigma == nullptr), E_ARG,
+               "mdnvae_mdn_finalize: the log-sigma rows and their sum come together");
+    MV_REQUIRE(!grad_log_sigma || (K >= 1 && K <= MDN_MAXK), E_SHAPE, "mdnvae_mdn_finalize: %d components (1..%d supported)", K,
+               MDN_MAXK);
+    hipLaunchKernelGGL(mdn_finalize_kernel, dim3(grad_log_sigma ? 2 : 1), dim3(PAIR_NT), 0, (hipStream_t)stream,
+                       (const double*)workspace, B, loss_out, grad_log_sigma_rows, K, grad_log_sigma);
     MV_LAUNCH_CHECK("mdn_finalize_kernel");
     return 0;
 }
@@ -1067,6 +1115,7 @@ int mdnvae_mdn_outer_fwdbwd_static(const float* nodes, const float* x, const flo
                "mdnvae_mdn_outer_fwdbwd_static: B = %d exceeds the static scratch (at most %d samples per call); "
                "use mdnvae_mdn_outer_fwdbwd with a workspace",
                B, MDN_STATIC_MAX_B);
+    MV_REQUIRE(loss_out, E_ARG, "mdnvae_mdn_outer_fwdbwd_static: loss_out is null");
     double* per_sample = nullptr;
     if (int rc = static_scratch("mdnvae_mdn_outer_fwdbwd_static", &per_sample)) return rc;
     // every sample's pair is written by the sweep before the finalize launch (same stream) reads it,

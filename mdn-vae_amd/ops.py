@@ -1426,9 +1426,15 @@ def _mdn_outer_call(nodes, x, logits, log_sigma, mu, logvar, n_nodes, symmetric_
     ws = torch.empty(_lib.load().mdnvae_mdn_workspace_bytes(B), dtype=torch.uint8, device=dev)
     call("mdnvae_mdn_outer_fwdbwd", ptr(nodes, "nodes"), ptr(x, "x"), ptr(logits, "gate_logits"),
          ptr(log_sigma, "log_sigma"), B, K, n_nodes, ptr(mu, "mu"), ptr(logvar, "logvar"), mu.shape[1], ptr(gnodes),
-         ptr(glogits), ptr(gls_rows), ptr(gmu), ptr(glv), ptr(resp), int(bool(symmetric_x)), ws.data_ptr(), ptr(out),
+         ptr(glogits), ptr(gls_rows), ptr(gmu), ptr(glv), ptr(resp), int(bool(symmetric_x)), ws.data_ptr(), None,
          stream())
-    gls = _colsum(gls_rows) if B > 0 else torch.zeros_like(log_sigma)
+    # the sweep leaves per-sample terms; one launch adds them up and, next to it, the per-sample log-sigma gradients
+    if B > 0:
+        gls = torch.empty_like(log_sigma)
+        call("mdnvae_mdn_finalize", ws.data_ptr(), B, ptr(out), ptr(gls_rows), K, ptr(gls), stream())
+    else:
+        gls = torch.zeros_like(log_sigma)
+        call("mdnvae_mdn_finalize", ws.data_ptr(), 0, ptr(out), None, K, None, stream())
     return out, gnodes, glogits, gls, gmu, glv, resp
 
 
