@@ -62,6 +62,30 @@ def test_shape_limits_of_the_dense_and_optimizer_entry_points_need_no_gpu():
     assert b"N = 96" in lib.mdnvae_last_error()
 
 
+def test_two_part_fp16_and_fused_gradient_entry_points_check_their_arguments_without_a_gpu():
+    lib = _lib.load()
+    # the largest-magnitude record is required wherever fp16 parts are written or read
+    assert lib.mdnvae_absmax(None, 4, 4, 4, 0.0, 1, None, None) < 0 and b"null" in lib.mdnvae_last_error()
+    assert lib.mdnvae_absmax(None, 4, 8, 4, 0.0, 1, None, None) < 0 and b"shape" in lib.mdnvae_last_error()
+    assert lib.mdnvae_split_rows_f16(None, 4, 16, 16, 0, None, None, None) < 0 and b"slot" in lib.mdnvae_last_error()
+    assert lib.mdnvae_split_cols_f16(None, None, 16, 4, 4, 0, 0, None, None, None) < 0 and b"slot" in lib.mdnvae_last_error()
+    assert lib.mdnvae_split_gemm_f16(None, None, None, None, 256, 256, 16, 256, 256, None, None, 0, 0, None, None, 256, 256,
+                                     256, None) < 0 and b"slot" in lib.mdnvae_last_error()
+    assert lib.mdnvae_tri_pack_absmax(None, 4, 87, 3840, None, None, 1, None, None) < 0 and b"slot" in lib.mdnvae_last_error()
+    assert lib.mdnvae_tri_fold_absmax(None, 4, 87, 3840, None, 1, None, None) < 0 and b"slot" in lib.mdnvae_last_error()
+    assert lib.mdnvae_split_rows_f16_cols(None, 64, 40, 48, 1, 4, None, None, None, None) < 0 and b"parts" in lib.mdnvae_last_error()
+    assert lib.mdnvae_split_rows_f16_cols(None, 64, 50, 48, 1, 2, None, None, None, None) < 0 and b"shape" in lib.mdnvae_last_error()
+    # weight + bias gradient of a small layer: the bias gradient is what the entry point is for
+    assert lib.mdnvae_linear_wgrad_bias(None, None, 64, 8, 8, None, None, 0, None, 0, None) < 0
+    assert b"grad_b" in lib.mdnvae_last_error()
+    assert lib.mdnvae_linear_wgrad_workspace_floats(16384, 128, 1024) % 4 == 0
+    # the per-sample terms' sum: rows and their column sums come together
+    ws = ctypes.create_string_buffer(64)
+    out = (ctypes.c_float * 3)()
+    assert lib.mdnvae_mdn_finalize(ws, 4, out, None, 5, out, None) < 0 and b"together" in lib.mdnvae_last_error()
+    assert lib.mdnvae_mdn_finalize(None, 4, out, None, 5, None, None) < 0
+
+
 def test_host_wrappers_refuse_cpu_tensors():
     a = torch.zeros(2, 4)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
