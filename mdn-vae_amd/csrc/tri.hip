@@ -16,7 +16,8 @@ typedef tri_v4 tri_v4u __attribute__((aligned(4)));
 
 __device__ __forceinline__ int tri_index(int i, int j, int N) { return i * N - ((i * (i - 1)) >> 1) + (j - i); }
 
-// One workgroup per matrix (a sample of x, or the weights of one output unit).  The matrix is
+// One workgroup of 512 threads per matrix (a sample of x, or the weights of one output unit; 256 threads: 0.147 ms
+// for 16384 matrices of 87 x 87, 512: 0.123, 1024: 0.141).  The matrix is
 // staged in LDS (16-byte pieces in, 16-byte LDS writes) so that the transposed element comes from
 // LDS (stride N dwords: conflict-free for odd N, eight-way for N = 68 - an odd padded stride was
 // measured there and bought nothing: the pass is bound by its global traffic).
@@ -26,19 +27,23 @@ __device__ __forceinline__ int tri_index(int i, int j, int N) { return i * N - (
 //   of the two-part fp16 operand split that reads `out` next is taken from the largest of the 64 slots.
 //   One atomic without return per workgroup; 64 addresses because atomics on one address serialise
 //   (one slot for all 16384 workgroups of a batch cost 30 us of a 150 us pass).
+#ifndef TRI_NT_N
+#define TRI_NT_N 512
+#endif
+constexpr int TRI_NT = TRI_NT_N;
 template <bool FOLD>
-__global__ __launch_bounds__(256) void tri_pack_kernel(const float* __restrict__ src, int N, int T, int ld,
+__global__ __launch_bounds__(TRI_NT) void tri_pack_kernel(const float* __restrict__ src, int N, int T, int ld,
                                                        float* __restrict__ out, int* __restrict__ asym,
                                                        unsigned* __restrict__ amax) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    __shared__ unsigned wave_max[4];
+    __shared__ unsigned wave_max[TRI_NT / 64];
     const int P = N * N;
     const float* m = src + (long)blockIdx.x * P;
     float* o = out + (long)blockIdx.x * ld;
     const int P4 = P >> 2;
-    for (int q = threadIdx.x; q < P4; q += 256)
+    for (int q = threadIdx.x; q < P4; q += TRI_NT)
         reinterpret_cast<tri_v4*>(sm)[q] = __builtin_nontemporal_load(reinterpret_cast<const tri_v4u*>(m) + q);
-    for (int p = (P4 << 2) + threadIdx.x; p < P; p += 256) sm[p] = m[p];
+    for (int p = (P4 << 2) + threadIdx.x; p < P; p += TRI_NT) sm[p] = m[p];
     __syncthreads();
     // Thread -> entry of the triangle without a square root: rows v and N - 1 - v of the triangle hold N - v and
     // v + 1 entries, N + 1 together, so the triangle is (N + 1) / 2 "double rows" of exactly N + 1 slots (for odd N
@@ -51,7 +56,7 @@ __global__ __launch_bounds__(256) void tri_pack_kernel(const float* __restrict__
     const float inv_w = 1.0f / (float)W;                   // (s + 0.5) / W stays 0.5 / W away from every integer
     bool differs = false;
     unsigned mx = 0;
-    for (int s = threadIdx.x; s < V * W; s += 256) {
+    for (int s = threadIdx.x; s < V * W; s += TRI_NT) {
         const int v = (int)(((float)s + 0.5f) * inv_w), q = s - v * W;
         const bool first = q < N - v;
         const int i = first ? v : N - 1 - v;
@@ -64,16 +69,28 @@ __global__ __launch_bounds__(256) void tri_pack_kernel(const float* __restrict__
         o[tri_index(i, j, N)] = val;
         mx = max(mx, __float_as_uint(val) & 0x7fffffffu);
     }
-    for (int t = T + threadIdx.x; t < ld; t += 256) o[t] = 0.0f;      // padding columns of the row
+    for (int t = T + threadIdx.x; t < ld; t += TRI_NT) o[t] = 0.0f;      // padding columns of the row
     if (!FOLD && differs) atomicOr(asym, 1);
     if (amax) {
-#pragma unroll
-        for (int s = 32; s > 0; s >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, s));
-        if ((threadIdx.x & 63) == 0) wave_max[threadIdx.x >> 6] = mx;
+        // wave maximum on the DPP path (lanes that have no source take 0, the identity here); total in lane 63
+#define TRI_DPP_MAX(ctrl, row_mask) mx = max(mx, (unsigned)__builtin_amdgcn_update_dpp(0, (int)mx, ctrl, row_mask, 0xf, false))
+        TRI_DPP_MAX(0x111, 0xf);
+        TRI_DPP_MAX(0x112, 0xf);
+        TRI_DPP_MAX(0x114, 0xf);
+        TRI_DPP_MAX(0x118, 0xf);
+        TRI_DPP_MAX(0x142, 0xa);
+        TRI_DPP_MAX(0x143, 0xc);
+#undef TRI_DPP_MAX
+        // one atomic per workgroup: they serialise at some 6 ns each whatever the address (one per wave, 131 k
+        // of them for a batch of 16384, took 0.7 ms)
+        if ((threadIdx.x & 63) == 63) wave_max[threadIdx.x >> 6] = mx;
         __syncthreads();
-        if (threadIdx.x == 0)
-            atomicMax(amax + (blockIdx.x & (MDNVAE_ABSMAX_SLOTS - 1)),
-                      max(max(wave_max[0], wave_max[1]), max(wave_max[2], wave_max[3])));
+        if (threadIdx.x == 0) {
+            unsigned mw = wave_max[0];
+#pragma unroll
+            for (int w = 1; w < TRI_NT / 64; ++w) mw = max(mw, wave_max[w]);
+            atomicMax(amax + (blockIdx.x & (MDNVAE_ABSMAX_SLOTS - 1)), mw);
+        }
     }
 }
 
@@ -139,7 +156,7 @@ static int tri_launch(bool fold, const float* src, long rows, int N, int ld, flo
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);   // static LDS: the wave maxima
             MV_REQUIRE(e == hipSuccess, (int)e, "%s: cannot raise the LDS limit: %s", who, hipGetErrorString(e));
         }
-        hipLaunchKernelGGL(tri_pack_kernel<true>, dim3((unsigned)rows), dim3(256), lds, (hipStream_t)stream, src, N, T,
+        hipLaunchKernelGGL(tri_pack_kernel<true>, dim3((unsigned)rows), dim3(TRI_NT), lds, (hipStream_t)stream, src, N, T,
                            ld, out, asym, amax);
     } else {
         if (lds > 64 * 1024) {
@@ -147,7 +164,7 @@ static int tri_launch(bool fold, const float* src, long rows, int N, int ld, flo
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);   // static LDS: the wave maxima
             MV_REQUIRE(e == hipSuccess, (int)e, "%s: cannot raise the LDS limit: %s", who, hipGetErrorString(e));
         }
-        hipLaunchKernelGGL(tri_pack_kernel<false>, dim3((unsigned)rows), dim3(256), lds, (hipStream_t)stream, src, N, T,
+        hipLaunchKernelGGL(tri_pack_kernel<false>, dim3((unsigned)rows), dim3(TRI_NT), lds, (hipStream_t)stream, src, N, T,
                            ld, out, asym, amax);
     }
     MV_LAUNCH_CHECK("tri_pack_kernel");
