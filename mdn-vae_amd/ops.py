@@ -412,6 +412,17 @@ _FACTORED_SLOTS = weakref.WeakValueDictionary()      # y.data_ptr() -> slot, ali
 FACTORED_DGRAD = not os.environ.get("MDNVAE_NO_FACTORED_DGRAD")     # tuning knob
 
 
+_ZERO_SCALARS = {}
+
+
+def _zero_scalar(device):
+    """One zero per device, made once (a fill launch each time otherwise); only ever read, through expanded views."""
+    key = str(device)
+    if key not in _ZERO_SCALARS:
+        _ZERO_SCALARS[key] = torch.zeros((), dtype=torch.float32, device=device)
+    return _ZERO_SCALARS[key]
+
+
 def _is_free_zeros(t):
     return t is not None and t.dim() == 2 and t.stride() == (0, 0)
 
@@ -455,7 +466,7 @@ class _LinearAct(torch.autograd.Function):
         split = ctx.has_bias and _split_linear_ok(x, weight, ctx.params[1])
         if ctx.needs_input_grad[0] and ctx.factored is not None:
             ctx.factored.gpre, ctx.factored.weight = _c(gpre), weight
-            gx = torch.zeros((), dtype=torch.float32, device=gy.device).expand(x.shape)
+            gx = _zero_scalar(gy.device).expand(x.shape)
         elif ctx.needs_input_grad[0]:
             gx = _split_linear_dgrad(_c(gpre), weight) if split else _library_gemm(gpre, weight)
         else:
