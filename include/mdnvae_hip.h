@@ -458,7 +458,7 @@ int mdnvae_mdn_outer_fwdbwd(const float* nodes, const float* x, const float* gat
                             float* resp, int x_symmetric, void* workspace, float* loss_out, void* stream);
 /* loss_out[3] = {nll + KL, nll, KL} from the per-sample terms mdnvae_mdn_outer_fwdbwd (or mdnvae_mdn_loss_fwd) left
  * in `workspace` for B samples: one workgroup, fixed summation order.  grad_log_sigma_rows [B,K] and grad_log_sigma
- * [K] (both or neither): the same launch adds up the per-sample log-sigma gradients in a second workgroup. */
+ * [K] (both or neither): the same launch adds up the per-sample log-sigma gradients, one more workgroup per column. */
 int mdnvae_mdn_finalize(const void* workspace, int B, float* loss_out, const float* grad_log_sigma_rows, int K,
                         float* grad_log_sigma, void* stream);
 /* mdnvae_mdn_outer_fwdbwd without the workspace argument, for callers that cannot allocate device

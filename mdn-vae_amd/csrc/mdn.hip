@@ -152,39 +152,29 @@ __global__ __launch_bounds__(MDN_NT) void mdn_fwd_kernel(const float* __restrict
     }
 }
 
-// out[0] = nll + KL, out[1] = nll, out[2] = KL (fixed summation order).  A second workgroup, when rows is given,
-// adds up the K columns of rows [B][K] (the per-sample log-sigma gradients) into colsum [K]: thread t takes
-// samples t, t + PAIR_NT, ... (four rows in flight), the threads' sums meet in a fixed order.
+// out[0] = nll + KL, out[1] = nll, out[2] = KL (fixed summation order).  K more workgroups, when rows is given,
+// add up the K columns of rows [B][K] (the per-sample log-sigma gradients) into colsum [K]: thread t takes
+// samples t, t + PAIR_NT, ... (four in flight), the threads' sums meet in a fixed order.
 __global__ __launch_bounds__(PAIR_NT) void mdn_finalize_kernel(const double* __restrict__ per_sample, int B,
                                                            float* __restrict__ out, const float* __restrict__ rows, int K,
                                                            float* __restrict__ colsum) {
     __shared__ double red[PAIR_NT / 64];
-    if (blockIdx.x == 1) {
+    if (blockIdx.x >= 1) {
+        // workgroup 1 + k adds up column k (one workgroup for all K columns pulled the whole [B][K] array through
+        // one CU with 20-byte strides: 17 us at B = 16384)
         __shared__ float redf[PAIR_NT / 64];
-        float acc[MDN_MAXK];
-#pragma unroll
-        for (int k = 0; k < MDN_MAXK; ++k) acc[k] = 0.0f;
+        const int k = blockIdx.x - 1;
+        float acc = 0.0f;
         int b = threadIdx.x;
         for (; b + 3 * PAIR_NT < B; b += 4 * PAIR_NT) {
-            float v[4][MDN_MAXK];
+            float v[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
-                for (int k = 0; k < MDN_MAXK; ++k) v[u][k] = k < K ? rows[(long)(b + u * PAIR_NT) * K + k] : 0.0f;
-#pragma unroll
-            for (int k = 0; k < MDN_MAXK; ++k) acc[k] += (v[0][k] + v[1][k]) + (v[2][k] + v[3][k]);
+            for (int u = 0; u < 4; ++u) v[u] = rows[(long)(b + u * PAIR_NT) * K + k];
+            acc += (v[0] + v[1]) + (v[2] + v[3]);
         }
-        for (; b < B; b += PAIR_NT)
-#pragma unroll
-            for (int k = 0; k < MDN_MAXK; ++k)
-                if (k < K) acc[k] += rows[(long)b * K + k];
-#pragma unroll
-        for (int k = 0; k < MDN_MAXK; ++k) {
-            if (k < K) {
-                const float t = block_sum<PAIR_NT, float>(acc[k], redf);
-                if (threadIdx.x == 0) colsum[k] = t;
-            }
-        }
+        for (; b < B; b += PAIR_NT) acc += rows[(long)b * K + k];
+        const float t = block_sum<PAIR_NT, float>(acc, redf);
+        if (threadIdx.x == 0) colsum[k] = t;
         return;
     }
     const PairSum t = block_pair_sum(per_sample, B, red);
@@ -1091,7 +1081,7 @@ int mdnvae_mdn_finalize(const void* workspace, int B, float* loss_out, const flo
                "mdnvae_mdn_finalize: the log-sigma rows and their sum come together");
     MV_REQUIRE(!grad_log_sigma || (K >= 1 && K <= MDN_MAXK), E_SHAPE, "mdnvae_mdn_finalize: %d components (1..%d supported)", K,
                MDN_MAXK);
-    hipLaunchKernelGGL(mdn_finalize_kernel, dim3(grad_log_sigma ? 2 : 1), dim3(PAIR_NT), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(mdn_finalize_kernel, dim3(grad_log_sigma ? 1 + K : 1), dim3(PAIR_NT), 0, (hipStream_t)stream,
                        (const double*)workspace, B, loss_out, grad_log_sigma_rows, K, grad_log_sigma);
     MV_LAUNCH_CHECK("mdn_finalize_kernel");
     return 0;
