@@ -688,7 +688,7 @@ class _SymLinearPair(torch.autograd.Function):
         if xb is None:
             xb = _split_operand(Tp, Kp, dev)
             call("mdnvae_split_cols_gated", ptr(xt), None, B, t_real, T, 1, parts, 0, xb.data_ptr(), stream())
-        gts = [(torch.zeros if halves else torch.empty)(rows, H, dtype=torch.float32, device=dev) for _ in range(2)]
+        gts = list((torch.zeros if halves else torch.empty)(2, rows, H, dtype=torch.float32, device=dev).unbind(0))    # one fill
         call("mdnvae_split_gemm", xb.data_ptr(), pb.data_ptr(), Tp, 2 * H, Kp, t_real + 1, H, None, None, 0,
              2 if halves else 0, ptr(gts[0]), ptr(gts[1]), H, H, tile, SPLIT_WGRAD_TERMS, stream())
         for i, (param, bias) in enumerate(((w1, b1), (w2, b2))):
