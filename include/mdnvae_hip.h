@@ -403,6 +403,67 @@ int mdnvae_maxpool_fwd(const float* x, long nplanes, int H, int W, int K, float*
 int mdnvae_maxpool_bwd(const float* grad_feat, const int* argmax, long nplanes, int H, int W, int K, float* grad_x,
                        void* stream);
 
+/* ---- conv / ResNet encoder on channel-blocked 16-bit operands --------------------------------
+ * The same layers (function/VAE_CNN_NN.py:83-98 ResidualBlock, :110-134 encoder stack; copies at
+ * function/VAE-CNN-GCN.py:80-131, function_FC/VAE_CNN_GCN.py:82-137) with every activation that feeds a
+ * 3x3 convolution kept as   act[part][group-plane][B][PP positions][8 channels]   (16-bit elements):
+ * written once, already padded and rounded, by the normalisation pass that produces it, so that the
+ * convolutions copy their operands straight into LDS (no staging arithmetic).  parts = 1: bf16;
+ * parts = 2: two fp16 parts of value * scale.  Convolutions write fp32 planes out[B][channels][Qr],
+ * Qr = rows * pitch rounded up to 4, over the pitched grid of their input (columns past the plane's
+ * width are scratch).
+ *
+ * kind of product: 0 forward of a stride-1 reflection-pad-1 layer (input: reflected border, pitch W + 2;
+ *   rows = H);  1 forward of a stride-2 pad-1 layer (input: four parity planes with a zero block row /
+ *   column in front, pitch OW + 1; rows = OH);  2 data gradient of a stride-1 layer (input: output
+ *   gradient with a zero border of 2, pitch W + 2; rows = H + 2: the result lives on the reflection-
+ *   padded grid and is folded by mdnvae_cb_norm_bwd);  3 data gradient of a stride-2 layer as a 2x2-tap
+ *   convolution (input: output gradient with a zero row / column behind, pitch OW + 1; rows = OH; the
+ *   result is the four parity planes [B][4 Cin][Qr] of the input gradient).
+ * Cout / Cin are those of the LAYER in every kind.  PP: positions per (group-plane, sample) of the
+ * input, at least Qr + the largest tap offset. */
+size_t mdnvae_cb_packed_bytes(int Cout, int Cin, int kind, int parts);
+/* w [Cout][Cin][3][3] -> MFMA B-operand fragments in the order the product of this kind streams them;
+ * amax (MDNVAE_ABSMAX_SLOTS partial maxima of |w| as bit patterns) is read for parts = 2 only. */
+int mdnvae_cb_pack_weights(const float* w, int Cout, int Cin, int kind, int parts, const unsigned* amax,
+                           void* packed, void* stream);
+int mdnvae_cb_conv(const void* act, long part_stride, const void* packed_w, const float* bias, float* out, int B,
+                   int Cout, int Cin, int kind, int rows, int pitch, int PP, int parts, float out_scale,
+                   void* stream);
+/* stats[plane] = {mean, 1/sqrt(var + 1e-5)} (nn.InstanceNorm2d defaults) over the H x W valid entries of
+ * planes stored with a row pitch (planes of at most 2048 positions). */
+int mdnvae_cb_plane_stats(const float* y, long nplanes, int H, int W, int pitch, long plane_stride, float* stats,
+                          void* stream);
+/* a = [relu]((y - mean) * rstd) (+ skip), function/VAE_CNN_NN.py:113-114,97: written as the next
+ * convolution's operand (mode 0: reflected border of 1, pitch W + 2, for kind 0; mode 1: four parity
+ * planes, pitch (W + 1) / 2 + 1, for kind 1; every one of the PP positions is written) and, when
+ * stream_out is given, as fp32 planes [B][C][H * W] (the residual stream).  skip: [B][C][H * W]. */
+int mdnvae_cb_norm_fwd(const float* y, const float* stats, const float* skip, float* stream_out, void* act,
+                       long part_stride, int B, int C, int H, int W, int pitch_y, long Qy, int relu, int mode,
+                       int PP, int parts, float scale, void* stream);
+/* Backward of the same pass, fused with what comes before it: the gradient w.r.t. the activation is
+ * gathered from the consumer's data gradient (gmode 0: planes on this grid with pitch_g; 1: the
+ * reflection-padded grid of kind 2, folded back; 2: the parity planes of kind 3; 3: none), plus `base`
+ * ([B][C][H * W], the residual stream's gradient) if given; the sum is written to sum_out if given;
+ * then the ReLU mask and the instance-norm backward
+ *     dc = rstd * (dn - mean(dn) - xh * mean(dn * xh)),  xh = (y - mean) * rstd
+ * and the result leaves as the operand of the layer's own data / weight gradient (omode 0: zero
+ * border of 2, pitch W + 2, H + 4 rows, for kind 2;  omode 1: zero row / column behind, pitch W + 1,
+ * for kind 3) or as fp32 planes [B][C][H * W] (omode 2).  gsum [B * C]: plane sums of dc (the
+ * convolution-bias gradient before the sum over the batch). */
+int mdnvae_cb_norm_bwd(const float* g, int gmode, int pitch_g, long Qg, const float* base, float* sum_out,
+                       const float* y, const float* stats, int pitch_y, long Qy, int relu, int B, int C, int H, int W,
+                       int omode, void* dc, long part_stride, int PP, int parts, float scale, float* gsum,
+                       void* stream);
+/* dW [Cout][Cin][3][3] from the channel-blocked output gradient g (as mdnvae_cb_norm_bwd leaves it) and the
+ * layer's channel-blocked input.  planes = 1: stride-1 reflection layer (g: omode 0, act: mode 0, same
+ * pitch); planes = 4: stride-2 layer (g: omode 1, act: mode 1).  [kbeg, kend): the positions of g that
+ * hold output pixels, widened to multiples of 32 (everything else in g is zero). */
+size_t mdnvae_cb_wgrad_workspace_floats(int B, int Cout, int Cin, int planes);
+int mdnvae_cb_wgrad(const void* g, const void* act, float* workspace, float* grad_w, int B, int Cout, int Cin,
+                    int planes, int PPg, int PPa, int kbeg, int kend, int pitch, int parts, float out_scale,
+                    void* stream);
+
 /* ---- optimiser ---------------------------------------------------------------------------
  * torch.optim.Adam(lr=1e-3) of function/VAE_CNN_NN.py:204,219 over one flat buffer of n floats
  * (all parameters / gradients / moments concatenated); step counts from 1; grad_scale multiplies

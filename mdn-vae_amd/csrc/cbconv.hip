@@ -1,0 +1,1060 @@
+// The conv/ResNet encoder of function/VAE_CNN_NN.py:83-98,110-134 (and its copies in function/VAE-CNN-GCN.py,
+// function_FC/VAE_CNN_GCN.py) on 16-bit operands that never pass through a register on their way to the matrix
+// cores.
+//
+// Activations that feed a 3x3 convolution live in a channel-blocked layout
+//     act[part][group-plane][sample][position][8 channels]            (16-bit elements, 16 bytes per position)
+// written once by the pass that produces them (instance norm + ReLU forward, instance-norm backward): already
+// padded (reflected border, zero border, or the four parity planes of a stride-2 layer's input), already rounded
+// (part 0 = bf16) or split (two fp16 parts of the value times a power of two).  A position's 16 bytes are exactly
+// one lane's share of an MFMA A operand (8 consecutive k = 8 channels), positions of one group-plane are contiguous
+// across the whole batch, and a 3x3 tap is a constant offset in positions.  So a convolution is a GEMM whose A tile
+// is a slab of positions copied by LDS-DMA (global_load_lds, 16 bytes per lane) and read back at nine offsets, and
+// whose B tile is a stream of pre-packed weight fragments, also LDS-DMA.  Outputs leave as fp32 planes
+//     out[sample][channel][row * pitch + column]
+// over the same pitched grid as the input positions (columns >= the plane's width are scratch).
+//
+// Stride-2 layers (function/VAE_CNN_NN.py:118,124) read four parity planes (space-to-depth): tap (ky, kx) is plane
+// ((ky+1) & 1, (kx+1) & 1) at block offset (ky > 0, kx > 0), so they run on the stride-1 kernel.  Their data gradient
+// is a 2x2-tap stride-1 convolution of the output gradient that writes the four parity planes of the input gradient.
+#include "common.h"
+#include "../../include/mdnvae_hip.h"
+
+namespace mdnvae {
+
+#define CB_GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+#define CB_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+typedef __bf16 cb_bf8 __attribute__((ext_vector_type(8)));
+typedef _Float16 cb_h8 __attribute__((ext_vector_type(8)));
+typedef float cb_acc16 __attribute__((ext_vector_type(16)));
+typedef float cb_f4 __attribute__((ext_vector_type(4)));
+typedef float cb_f4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef unsigned cb_u4 __attribute__((ext_vector_type(4)));
+typedef unsigned cb_u2 __attribute__((ext_vector_type(2)));
+
+constexpr int CB_MAXTAPS = 9;
+constexpr int CB_NBUF = 4;            // weight stage buffers: three stages in flight
+constexpr int CB_ROWS = 256;          // output rows (positions) per workgroup
+
+struct CbConv {
+    const char* act;        // channel-blocked input, part 0
+    long part_stride;       // bytes between parts
+    const char* w;          // packed weight fragments [N block][chunk][stage][tap][n tile][part][1 KiB]
+    const float* bias;      // [ntot] or null
+    float* out;             // [B][ntot][Qr]
+    int B, PP;              // samples; positions per (group-plane, sample) of the input
+    int nchunk;             // 16-channel chunks of the reduction
+    int Qr;                 // output rows per sample (multiple of 4)
+    int halo;               // largest tap offset in positions
+    int ntot;               // output planes per sample
+    int tap_lds[CB_MAXTAPS + 3];   // byte offset of tap t in the slab: (plane * 2 * slab positions + offset) * 16
+    float out_scale;        // accumulators are multiplied by this (undoes the power-of-two scales of fp16 parts)
+};
+
+template <int N>
+__device__ __forceinline__ void cb_wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// PARTS: 1 = bf16 operands, 2 = two fp16 parts per operand (hh + hl + lh, 2^-22 per product).
+// NGP: group-planes per 16-channel chunk (2: k halves; 8: four parity planes x k halves).  NJ: 64-position blocks per
+// group-plane in the slab.  WGM x WGN waves of WM x WN 32x32 tiles.  TPS taps per stage, SPC stages per chunk.
+//
+// Pipeline: weights of stage s + 3 and (at the first stage of a chunk) the slab of the next chunk are issued right
+// after the barrier of stage s; the wait before each barrier is the wave's own counted vmcnt, so three weight stages
+// and one slab stay in flight across barriers.  Past the end the last stage / chunk is fetched again into buffers
+// nobody reads any more, which keeps the counts the same in every iteration.
+template <int PARTS, int NGP, int NJ, int WGM, int WGN, int WM, int WN, int TPS, int SPC>
+__global__ __launch_bounds__(512) void cb_conv_kernel(CbConv p) {
+    static_assert(WGM * WGN == 8 && WGM * WM * 32 == CB_ROWS, "eight waves cover 256 rows");
+    constexpr int NT = WGN * WN;                              // 32-channel tiles per workgroup
+    constexpr int WSTAGE = TPS * NT * PARTS * 1024;           // bytes of one weight stage
+    constexpr int WPIECES = TPS * NT * PARTS;                 // 1 KiB pieces per weight stage
+    constexpr int WQ = WPIECES / 8, WREM = WPIECES % 8;
+    constexpr int SLABPOS = NJ * 64;
+    constexpr int SLABPART = NGP * SLABPOS * 16;              // bytes of one part of a slab
+    constexpr int SLAB = PARTS * SLABPART;
+    constexpr int SPIECES = PARTS * NGP * NJ;
+    static_assert(SPIECES % 8 == 0, "every wave stages the same number of slab pieces");
+    constexpr int SP = SPIECES / 8;
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    char* wring = smem;                                       // [CB_NBUF][WSTAGE]
+    char* slabs = smem + CB_NBUF * WSTAGE;                    // [2][SLAB]
+
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wid / WGN, wn = wid - wm * WGN;
+    const int h = lane >> 5, l32 = lane & 31;
+
+    // rows of this workgroup: flat over (sample, output row), a tile may end one sample and begin the next
+    const long R0 = (long)blockIdx.x * CB_ROWS;
+    const int s0 = (int)(R0 / p.Qr);
+    const int qa = (int)(R0 - (long)s0 * p.Qr);
+    const int n0 = min(CB_ROWS, p.Qr - qa);                   // rows of sample s0; the rest belong to s0 + 1
+    const int L0 = n0 + p.halo;                               // slab positions of the first segment
+    const int s1off = (s0 + 1 < p.B) ? p.PP : 0;              // where the second segment's positions come from
+
+    // ---- staging plan of this wave ----
+    // slab piece u = wid + 8 i of a chunk: (64-position block j, part, group-plane) with the group-plane running fastest
+    long ssrc[SP];
+    int sdst[SP];
+#pragma unroll
+    for (int i = 0; i < SP; ++i) {
+        const int u = wid + 8 * i;
+        const int j = u / (PARTS * NGP), pg = u - j * (PARTS * NGP);
+        const int part = pg / NGP, gp = pg - part * NGP;
+        const int pos = j * 64 + lane;
+        int src = pos < L0 ? qa + pos : s1off + (pos - L0);
+        src = min(src, 2 * p.PP - 1);
+        ssrc[i] = part * p.part_stride + (((long)gp * p.B + s0) * p.PP + src) * 16;
+        sdst[i] = part * SLABPART + (gp * SLABPOS + j * 64) * 16;
+    }
+    const long chunk_stride = (long)NGP * p.B * p.PP * 16;
+    auto stage_slab = [&](int c, int buf) {
+#pragma unroll
+        for (int i = 0; i < SP; ++i)
+            __builtin_amdgcn_global_load_lds(CB_GLOBAL_PTR(p.act + ssrc[i] + c * chunk_stride),
+                                             CB_LDS_PTR(slabs + buf * SLAB + sdst[i]), 16, 0, 0);
+    };
+    const int nstage = p.nchunk * SPC;
+    const char* wsrc = p.w + (long)blockIdx.y * nstage * WSTAGE + lane * 16;
+    auto stage_w = [&](int s, int buf) {
+#pragma unroll
+        for (int i = 0; i < WQ + (WREM ? 1 : 0); ++i) {
+            if (i < WQ || wid < WREM) {
+                const int q = wid + 8 * i;
+                __builtin_amdgcn_global_load_lds(CB_GLOBAL_PTR(wsrc + (long)s * WSTAGE + q * 1024),
+                                                 CB_LDS_PTR(wring + buf * WSTAGE + q * 1024), 16, 0, 0);
+            }
+        }
+    };
+
+    // per-lane slab address of each row tile (k half folded in)
+    int lane_addr[WM];
+#pragma unroll
+    for (int m = 0; m < WM; ++m) {
+        const int i = (wm * WM + m) * 32 + l32;
+        lane_addr[m] = (h * SLABPOS + (i < n0 ? i : L0 + (i - n0))) * 16;
+    }
+    int taps[TPS * SPC];
+#pragma unroll
+    for (int t = 0; t < TPS * SPC; ++t) taps[t] = p.tap_lds[t];
+
+    // biases of this lane's output channels (loaded now, long landed by the epilogue)
+    float bv[WN];
+#pragma unroll
+    for (int n = 0; n < WN; ++n) {
+        const int ch = (blockIdx.y * NT + wn * WN + n) * 32 + l32;
+        bv[n] = (p.bias && ch < p.ntot) ? p.bias[ch] : 0.0f;
+    }
+
+    cb_acc16 acc[WM][WN];
+#pragma unroll
+    for (int m = 0; m < WM; ++m)
+#pragma unroll
+        for (int n = 0; n < WN; ++n)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[m][n][e] = 0.0f;
+
+    auto mfma = [](const cb_bf8& a, const cb_bf8& b, const cb_acc16& c) {
+        if constexpr (PARTS == 2)
+            return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(cb_h8, a), __builtin_bit_cast(cb_h8, b), c, 0, 0, 0);
+        else
+            return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    };
+
+    // one stage: TPS taps of one chunk
+    auto compute = [&](int r, const char* wb, const char* sl) {
+        cb_bf8 A[2][PARTS][WM], Bv[2][PARTS][WN];
+        auto load_tap = [&](int tt, int slot) {
+#pragma unroll
+            for (int pt = 0; pt < PARTS; ++pt) {
+#pragma unroll
+                for (int n = 0; n < WN; ++n)
+                    Bv[slot][pt][n] = *reinterpret_cast<const cb_bf8*>(wb + ((tt * NT + wn * WN + n) * PARTS + pt) * 1024 + lane * 16);
+#pragma unroll
+                for (int m = 0; m < WM; ++m)
+                    A[slot][pt][m] = *reinterpret_cast<const cb_bf8*>(sl + pt * SLABPART + lane_addr[m] + taps[r * TPS + tt]);
+            }
+        };
+        load_tap(0, 0);
+#pragma unroll
+        for (int tt = 0; tt < TPS; ++tt) {
+            if (tt + 1 < TPS) load_tap(tt + 1, (tt + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int m = 0; m < WM; ++m)
+#pragma unroll
+                for (int n = 0; n < WN; ++n) {
+                    if constexpr (PARTS == 2) {
+                        acc[m][n] = mfma(A[tt & 1][0][m], Bv[tt & 1][1][n], acc[m][n]);
+                        acc[m][n] = mfma(A[tt & 1][1][m], Bv[tt & 1][0][n], acc[m][n]);
+                    }
+                    acc[m][n] = mfma(A[tt & 1][0][m], Bv[tt & 1][0][n], acc[m][n]);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    // prologue: slab of chunk 0, weights of stages 0..2
+    stage_slab(0, 0);
+#pragma unroll
+    for (int s = 0; s < CB_NBUF - 1; ++s) stage_w(min(s, nstage - 1), s);
+
+    int s = 0;
+    for (int c = 0; c < p.nchunk; ++c) {
+#pragma unroll
+        for (int r = 0; r < SPC; ++r, ++s) {
+            // all but the two youngest weight stages (and, at r = 1, 2, the slab issued at r = 0) have landed
+            const bool slab_young = (r == 1 || r == 2);
+            if (WREM && wid < WREM) {
+                if (slab_young) cb_wait_vm<2 * (WQ + 1) + SP>(); else cb_wait_vm<2 * (WQ + 1)>();
+            } else {
+                if (slab_young) cb_wait_vm<2 * WQ + SP>(); else cb_wait_vm<2 * WQ>();
+            }
+            __builtin_amdgcn_s_barrier();
+            if (r == 0) stage_slab(min(c + 1, p.nchunk - 1), (c + 1) & 1);
+            stage_w(min(s + CB_NBUF - 1, nstage - 1), (s + CB_NBUF - 1) % CB_NBUF);
+            compute(r, wring + (s % CB_NBUF) * WSTAGE, slabs + (c & 1) * SLAB);
+        }
+    }
+    cb_wait_vm<0>();                                          // nothing in flight when the LDS goes back
+
+    // epilogue: accumulator registers 4g..4g+3 of a tile are rows 8g + 4h .. + 3 of column l32
+    const long Rend = (long)p.B * p.Qr;
+#pragma unroll
+    for (int n = 0; n < WN; ++n) {
+        const int ch = (blockIdx.y * NT + wn * WN + n) * 32 + l32;
+        if (ch >= p.ntot) continue;
+#pragma unroll
+        for (int m = 0; m < WM; ++m) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int i = (wm * WM + m) * 32 + 8 * g + 4 * h;
+                if (R0 + i >= Rend) continue;
+                const int sg = i >= n0;
+                const int q = sg ? i - n0 : qa + i;
+                cb_f4 o;
+                o.x = acc[m][n][4 * g] * p.out_scale + bv[n];
+                o.y = acc[m][n][4 * g + 1] * p.out_scale + bv[n];
+                o.z = acc[m][n][4 * g + 2] * p.out_scale + bv[n];
+                o.w = acc[m][n][4 * g + 3] * p.out_scale + bv[n];
+                *reinterpret_cast<cb_f4*>(p.out + ((long)(s0 + sg) * p.ntot + ch) * p.Qr + q) = o;
+            }
+        }
+    }
+}
+
+// Weight fragments for cb_conv_kernel from w [Cout][Cin][3][3].
+//   mode 0: forward (rows of the product = output channels, reduction over input channels, tap = ky * 3 + kx)
+//   mode 1: data gradient of a stride-1 layer (rows = input channels, reduction over output channels, taps flipped)
+//   mode 2: data gradient of a stride-2 / pad-1 layer as a 2x2-tap convolution: row = parity plane (py, px) * Cin + ci,
+//           tap (ey, ex); kernel row ky = {py = 0: ey = 0 -> 1;  py = 1: ey = 0 -> 2, ey = 1 -> 0}, same for columns
+// out [N block][chunk][stage][tap in stage][n tile][part][lane][8]: lane = (k half, row in the tile), entry j = reduction
+// index 16 chunk + 8 half + j.  parts = 1: bf16; parts = 2: two fp16 parts of w * scale.
+__global__ __launch_bounds__(256) void cb_pack_weights_kernel(const float* __restrict__ w, int Cout, int Cin, int mode,
+                                                              int nblk, int NT, int nchunk, int SPC, int TPS, int parts,
+                                                              const unsigned* __restrict__ amax, char* __restrict__ out) {
+    const long total = (long)nblk * nchunk * SPC * TPS * NT * parts * 512;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int j = (int)(idx & 7), ln = (int)((idx >> 3) & 63);
+    long r = idx >> 9;
+    const int part = (int)(r % parts); r /= parts;
+    const int n = (int)(r % NT); r /= NT;
+    const int tt = (int)(r % TPS); r /= TPS;
+    const int st = (int)(r % SPC); r /= SPC;
+    const int c = (int)(r % nchunk);
+    const int nb = (int)(r / nchunk);
+    const int tap = st * TPS + tt;
+    const int row = (nb * NT + n) * 32 + (ln & 31);
+    const int k = c * 16 + 8 * (ln >> 5) + j;
+    float v = 0.0f;
+    if (mode == 0) {
+        if (row < Cout && k < Cin) v = w[((long)row * Cin + k) * 9 + tap];
+    } else if (mode == 1) {
+        if (row < Cin && k < Cout) v = w[((long)k * Cin + row) * 9 + (8 - tap)];
+    } else {
+        const int plane = row / Cin, ci = row - plane * Cin;
+        if (plane < 4 && k < Cout) {
+            const int py = plane >> 1, px = plane & 1, ey = tap >> 1, ex = tap & 1;
+            const int ky = py == 0 ? (ey == 0 ? 1 : -1) : (ey == 0 ? 2 : 0);
+            const int kx = px == 0 ? (ex == 0 ? 1 : -1) : (ex == 0 ? 2 : 0);
+            if (ky >= 0 && kx >= 0) v = w[((long)k * Cin + ci) * 9 + ky * 3 + kx];
+        }
+    }
+    if (parts == 1) {
+        reinterpret_cast<__bf16*>(out)[idx] = (__bf16)v;
+    } else {
+        // scale: the power of two that brings the tensor's largest magnitude into [2^14, 2^15)
+        unsigned m = 0;
+        for (int i = 0; i < MDNVAE_ABSMAX_SLOTS; ++i) m = max(m, amax[i]);
+        const int e = (int)((m >> 23) & 0xffu);
+        float sc = 1.0f;
+        if (e != 0 && e != 255) {
+            const int se = 268 - e;
+            sc = __uint_as_float((unsigned)(se < 253 ? se : 253) << 23);
+        }
+        const float t = v * sc;
+        const _Float16 hi = (_Float16)t;
+        reinterpret_cast<_Float16*>(out)[idx] = part == 0 ? hi : (_Float16)(t - (float)hi);
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------
+// elementwise passes between the convolutions
+// ---------------------------------------------------------------------------------------
+constexpr float CB_IN_EPS = 1e-5f;       // nn.InstanceNorm2d default (function/VAE_CNN_NN.py:113)
+
+// stats[plane] = {mean, 1/sqrt(biased var + eps)} of the H x W valid entries of a pitched plane; one wave per plane,
+// two passes over registers (mean first, then squared deviations)
+template <int EPT>
+__global__ __launch_bounds__(256) void cb_plane_stats_kernel(const float* __restrict__ y, long nplanes, int H, int W,
+                                                             int pitch, long plane_stride, float* __restrict__ stats) {
+    const int lane = threadIdx.x & 63;
+    const long plane = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (plane >= nplanes) return;
+    const float* py = y + plane * plane_stride;
+    const int Q = H * pitch;
+    const unsigned mp = (unsigned)(0x100000000ull / (unsigned)pitch) + 1u;
+    float v[EPT];
+    float s = 0.0f;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const int i = lane + 64 * e;
+        const int r = (int)__umulhi((unsigned)i, mp), c = i - r * pitch;
+        const bool ok = i < Q && c < W;
+        v[e] = ok ? py[ok ? i : 0] : __builtin_nanf("");
+        s += ok ? v[e] : 0.0f;
+    }
+    const float n = (float)(H * W);
+    const float mean = wave_sum_all(s) / n;
+    float q = 0.0f;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const float d = v[e] - mean;
+        q += (v[e] == v[e]) ? d * d : 0.0f;
+    }
+    const float var = wave_sum_all(q) / n;
+    if (lane == 0) {
+        stats[2 * plane] = mean;
+        stats[2 * plane + 1] = 1.0f / sqrtf(var + CB_IN_EPS);
+    }
+}
+
+// 8 values of one position -> 16 bytes of part 0 (bf16) or of parts 0 and 1 (fp16 parts of v * scale)
+template <int PARTS>
+__device__ __forceinline__ void cb_store8(const float (&v)[8], float scale, char* dst, long part_stride) {
+    if constexpr (PARTS == 1) {
+        cb_bf8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (__bf16)v[e];
+        *reinterpret_cast<cb_bf8*>(dst) = o;
+    } else {
+        cb_h8 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float t = v[e] * scale;
+            hi[e] = (_Float16)t;
+            lo[e] = (_Float16)(t - (float)hi[e]);
+        }
+        *reinterpret_cast<cb_h8*>(dst) = hi;
+        *reinterpret_cast<cb_h8*>(dst + part_stride) = lo;
+    }
+}
+
+struct CbNormFwd {
+    const float* y;          // raw conv output [B][C][Qy], pitched rows
+    const float* stats;      // [B * C][2]
+    const float* skip;       // residual stream [B][C][H * W] or null
+    float* stream_out;       // skip + norm(y), [B][C][H * W], or null
+    char* act;               // channel-blocked output
+    long part_stride;
+    int B, C, H, W, pitch_y, Qy, relu;
+    int mode;                // 0: reflection border 1, pitch W + 2;  1: four parity planes with a zero block border in front, pitch (W + 1) / 2 + 1
+    int PP;                  // positions per (group-plane, sample)
+    int opitch;              // pitch of the output planes
+    float scale;
+};
+
+// a = [relu](norm(y)) (+ skip), written as the next convolution's operand.  One workgroup per (sample, 8 channels);
+// a thread owns output positions (16 bytes each) and gathers their 8 source values, which consecutive lanes find at
+// consecutive addresses of 8 planes.
+template <int PARTS>
+__global__ __launch_bounds__(256) void cb_norm_fwd_kernel(CbNormFwd p) {
+    const int g8 = blockIdx.x, b = blockIdx.y;
+    const int HW = p.H * p.W;
+    float mean[8], rstd[8];
+    const float* yp[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const long pl = (long)b * p.C + g8 * 8 + e;
+        mean[e] = p.stats[2 * pl];
+        rstd[e] = p.stats[2 * pl + 1];
+        yp[e] = p.y + pl * p.Qy;
+    }
+    const unsigned mop = (unsigned)(0x100000000ull / (unsigned)p.opitch) + 1u;
+    const int nplanes = p.mode == 1 ? 4 : 1;
+    for (int plane = 0; plane < nplanes; ++plane) {
+        // group-plane index: [chunk][plane][k half]
+        const long gp = p.mode == 1 ? (long)(g8 >> 1) * 8 + plane * 2 + (g8 & 1) : g8;
+        char* dst = p.act + ((gp * p.B + b) * p.PP) * 16;
+        for (int pos = threadIdx.x; pos < p.PP; pos += 256) {
+            const int pr = (int)__umulhi((unsigned)pos, mop), pc = pos - pr * p.opitch;
+            int r, c;
+            bool ok, interior = false;
+            if (p.mode == 0) {
+                r = pr - 1; c = pc - 1;
+                ok = pr < p.H + 2 && pc < p.W + 2;
+                interior = ok && r >= 0 && r < p.H && c >= 0 && c < p.W;
+                r = r < 0 ? -r : (r >= p.H ? 2 * (p.H - 1) - r : r);
+                c = c < 0 ? -c : (c >= p.W ? 2 * (p.W - 1) - c : c);
+            } else {
+                r = 2 * (pr - 1) + (plane >> 1); c = 2 * (pc - 1) + (plane & 1);
+                ok = pr >= 1 && pc >= 1 && r < p.H && c < p.W;
+            }
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = 0.0f;
+            if (ok) {
+                const int src = r * p.pitch_y + c;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float t = (yp[e][src] - mean[e]) * rstd[e];
+                    if (p.relu) t = fmaxf(t, 0.0f);
+                    v[e] = t;
+                }
+                if (p.skip) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += p.skip[((long)b * p.C + g8 * 8 + e) * HW + r * p.W + c];
+                }
+                if (p.stream_out && (p.mode == 1 || interior)) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) p.stream_out[((long)b * p.C + g8 * 8 + e) * HW + r * p.W + c] = v[e];
+                }
+            }
+            if (p.act) cb_store8<PARTS>(v, p.scale, dst + (long)pos * 16, p.part_stride);
+        }
+    }
+}
+
+struct CbNormBwd {
+    const float* g;          // gradient w.r.t. this layer's activation, as the consumer's data gradient left it
+    int gmode;               // 0: planes on this layer's grid, pitch_g;  1: reflection-padded grid (H+2) x (W+2) to fold, pitch_g;
+                             // 2: four parity planes [B][4 C][Qg] of a stride-2 consumer, pitch_g;  3: none (base only)
+    int pitch_g; long Qg;
+    const float* base;       // [B][C][H * W] added to the gradient (the residual stream's gradient), or null
+    float* sum_out;          // [B][C][H * W]: base + gradient, or null
+    const float* y;          // raw conv output of this layer [B][C][Qy]
+    const float* stats;
+    int pitch_y; long Qy;
+    int relu;
+    int B, C, H, W;
+    int omode;               // 0: zero border 2 (pitch W + 2, H + 4 rows);  1: zero border behind (pitch W + 1, H + 1 rows);  2: fp32 planes [B][C][H * W]
+    char* dc;                // channel-blocked output (omode 0, 1) or float planes (omode 2)
+    long part_stride;
+    int PP, opitch;
+    float scale;
+    float* gsum;             // [B * C] plane sums of the result (conv bias gradient), or null
+};
+
+__device__ __forceinline__ float cb_fold_gather(const float* __restrict__ gp, int y, int x, int H, int W, int Wp) {
+    const int r1 = (y == 1) ? 0 : ((y == H - 2) ? H + 1 : -1);
+    const int r2 = (y == 1 && y == H - 2) ? H + 1 : -1;
+    const int c1 = (x == 1) ? 0 : ((x == W - 2) ? W + 1 : -1);
+    const int c2 = (x == 1 && x == W - 2) ? W + 1 : -1;
+    const int rows[3] = {y + 1, r1, r2};
+    const int cols[3] = {x + 1, c1, c2};
+    float s = 0.0f;
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int bb = 0; bb < 3; ++bb)
+            if (rows[a] >= 0 && cols[bb] >= 0) s += gp[rows[a] * Wp + cols[bb]];
+    return s;
+}
+
+// dc = rstd * (dn - mean(dn) - xh * mean(dn * xh)),  xh = (y - mean) * rstd,  dn = (base + gathered gradient) * [xh > 0 if relu]
+// One workgroup per (sample, CH channels); a thread owns NPOS output positions, keeps dn and xh of their CH channels in
+// registers between the plane reductions and the write.
+template <int PARTS, int CH, int NPOS>
+__global__ __launch_bounds__(256) void cb_norm_bwd_kernel(CbNormBwd p) {
+    __shared__ float red[4][3 * CH];
+    const int cg = blockIdx.x, b = blockIdx.y;
+    const int HW = p.H * p.W;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ndom = p.omode == 2 ? HW : p.PP;
+    const unsigned mop = (unsigned)(0x100000000ull / (unsigned)p.opitch) + 1u;
+    float dn[NPOS][CH], xh[NPOS][CH];
+    float s1[CH], s2[CH];
+#pragma unroll
+    for (int e = 0; e < CH; ++e) s1[e] = s2[e] = 0.0f;
+    float mean[CH], rstd[CH];
+#pragma unroll
+    for (int e = 0; e < CH; ++e) {
+        const long pl = (long)b * p.C + cg * CH + e;
+        mean[e] = p.stats[2 * pl];
+        rstd[e] = p.stats[2 * pl + 1];
+    }
+#pragma unroll
+    for (int i = 0; i < NPOS; ++i) {
+        const int pos = threadIdx.x + 256 * i;
+        const int pr = (int)__umulhi((unsigned)pos, mop), pc = pos - pr * p.opitch;
+        int r = pr, c = pc;
+        if (p.omode == 0) { r = pr - 2; c = pc - 2; }
+        const bool ok = pos < ndom && r >= 0 && r < p.H && c >= 0 && c < p.W;
+#pragma unroll
+        for (int e = 0; e < CH; ++e) {
+            dn[i][e] = 0.0f;
+            xh[i][e] = 0.0f;
+        }
+        if (ok) {
+#pragma unroll
+            for (int e = 0; e < CH; ++e) {
+                const long pl = (long)b * p.C + cg * CH + e;
+                float gv = 0.0f;
+                if (p.gmode == 0) gv = p.g[pl * p.Qg + r * p.pitch_g + c];
+                else if (p.gmode == 1) gv = cb_fold_gather(p.g + pl * p.Qg, r, c, p.H, p.W, p.pitch_g);
+                else if (p.gmode == 2)
+                    gv = p.g[((long)b * 4 * p.C + ((r & 1) * 2 + (c & 1)) * p.C + cg * CH + e) * p.Qg + (r >> 1) * p.pitch_g + (c >> 1)];
+                if (p.base) gv += p.base[pl * HW + r * p.W + c];
+                if (p.sum_out) p.sum_out[pl * HW + r * p.W + c] = gv;
+                const float x = (p.y[pl * p.Qy + r * p.pitch_y + c] - mean[e]) * rstd[e];
+                if (p.relu && !(x > 0.0f)) gv = 0.0f;
+                dn[i][e] = gv;
+                xh[i][e] = x;
+                s1[e] += gv;
+                s2[e] += gv * x;
+            }
+        }
+    }
+    // plane sums: waves in order, fixed tree inside a wave
+#pragma unroll
+    for (int e = 0; e < CH; ++e) {
+        s1[e] = wave_sum_all(s1[e]);
+        s2[e] = wave_sum_all(s2[e]);
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int e = 0; e < CH; ++e) {
+            red[wave][e] = s1[e];
+            red[wave][CH + e] = s2[e];
+        }
+    }
+    __syncthreads();
+    float m1[CH], m2[CH];
+    const float inv = 1.0f / (float)HW;
+#pragma unroll
+    for (int e = 0; e < CH; ++e) {
+        m1[e] = ((red[0][e] + red[1][e]) + (red[2][e] + red[3][e])) * inv;
+        m2[e] = ((red[0][CH + e] + red[1][CH + e]) + (red[2][CH + e] + red[3][CH + e])) * inv;
+    }
+    float gs[CH];
+#pragma unroll
+    for (int e = 0; e < CH; ++e) gs[e] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NPOS; ++i) {
+        const int pos = threadIdx.x + 256 * i;
+        if (pos >= ndom) continue;
+        const int pr = (int)__umulhi((unsigned)pos, mop), pc = pos - pr * p.opitch;
+        int r = pr, c = pc;
+        if (p.omode == 0) { r = pr - 2; c = pc - 2; }
+        const bool ok = r >= 0 && r < p.H && c >= 0 && c < p.W;
+        float o[CH];
+#pragma unroll
+        for (int e = 0; e < CH; ++e) {
+            o[e] = ok ? rstd[e] * (dn[i][e] - m1[e] - xh[i][e] * m2[e]) : 0.0f;
+            gs[e] += o[e];
+        }
+        if (p.omode == 2) {
+#pragma unroll
+            for (int e = 0; e < CH; ++e)
+                reinterpret_cast<float*>(p.dc)[((long)b * p.C + cg * CH + e) * HW + pos] = o[e];
+        } else {
+            if constexpr (CH == 8) {
+                float o8[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o8[e] = o[e];
+                cb_store8<PARTS>(o8, p.scale, p.dc + (((long)cg * p.B + b) * p.PP + pos) * 16, p.part_stride);
+            }
+        }
+    }
+    if (p.gsum) {
+#pragma unroll
+        for (int e = 0; e < CH; ++e) gs[e] = wave_sum_all(gs[e]);
+        if (lane == 0) {
+#pragma unroll
+            for (int e = 0; e < CH; ++e) red[wave][2 * CH + e] = gs[e];
+        }
+        __syncthreads();
+        if (threadIdx.x < CH) {
+            const int e = threadIdx.x;
+            p.gsum[(long)b * p.C + cg * CH + e] =
+                (red[0][2 * CH + e] + red[1][2 * CH + e]) + (red[2][2 * CH + e] + red[3][2 * CH + e]);
+        }
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------
+// weight gradient
+// ---------------------------------------------------------------------------------------
+// dW[tap][co][ci] = sum over samples and positions k of G[k][co] * act[plane(tap)][k + shift(tap)][ci]: the reduction
+// runs over POSITIONS, which both channel-blocked operands have as their slow index, so both MFMA operands come out of
+// LDS through the transposing read (ds_read_b64_tr_b16: a 16-lane group reads 4 positions x 16 channels and each lane
+// receives 4 consecutive positions of its channel).  G is the output gradient in the zero-bordered layout the
+// instance-norm backward pass writes (zeros wherever there is no output pixel), so border and scratch positions add
+// nothing and a chunk of the reduction is simply 128 consecutive positions; the activation slab of a chunk carries the
+// span of the tap shifts as a halo.  v_mfma_f32_16x16x32: a wave owns 16 output channels x (CIT x 16) input channels
+// x 9 taps.  Workgroup: 8 waves as 4 (co) x 2 (ci) = 64 co x CIT * 32 ci.  Two chunk buffers, the next chunk's LDS-DMA
+// runs under the current chunk's MFMAs.  partial [Z][9][Cout][Cin], summed by conv_wgrad_reduce_kernel.
+typedef short cb_s4 __attribute__((ext_vector_type(4)));
+typedef short cb_s8 __attribute__((ext_vector_type(8)));
+
+struct CbWgrad {
+    const char* g;            // output gradient, channel-blocked [Cout/8][B][PPg][8]
+    const char* act;          // layer input, channel-blocked [group-plane][B][PPa][8]
+    long g_part_stride, a_part_stride;
+    float* partial;
+    int B, Cout, Cin, PPg, PPa;
+    int kbeg, kend;           // positions of G that take part (multiples of 32)
+    int smin;                 // smallest tap shift (activation position = k + shift)
+    int tap_off[9];           // shift(tap) - smin
+    int tap_plane[9];
+    int spg;                  // samples per z group
+    float out_scale;
+};
+
+// A wave owns COT x 16 output channels x 16 input channels x 9 taps (the nine shifted activation fragments of a k step
+// are each used for COT products).  Workgroup: 8 waves as WCO (co) x WCI (ci).  KC positions per chunk; LDS rows of a
+// channel group are KC + 4 (G) and KC + 68 (activations: + up to 64 positions of tap span) positions long: = 4 mod 16, so
+// the four groups a half-wave's transposed read touches fall on different banks.
+template <int PARTS, int NPL, int COT, int WCO, int WCI, int KC>
+__global__ __launch_bounds__(512) void cb_wgrad_kernel(CbWgrad p) {
+    static_assert(PARTS == 1, "fp16 parts of the weight gradient: not built yet");
+    static_assert(WCO * WCI == 8 && KC % 64 == 0, "eight waves; chunks of whole 64-position blocks");
+    constexpr int GSG = KC + 4, GSA = KC + 68;
+    constexpr int GG = WCO * COT * 2;                 // channel groups of the G tile
+    constexpr int GA = WCI * 2;                       // channel groups of the activation tile
+    constexpr int GBUF = GG * GSG * 16;               // bytes: G tile of one chunk
+    constexpr int ABUF = NPL * GA * GSA * 16;
+    constexpr int BUF = GBUF + ABUF;
+    constexpr int GBL = KC / 64, ABL = KC / 64 + 1;   // 64-position blocks per group
+    constexpr int GP = GG * GBL, AP = NPL * GA * ABL; // 1 KiB pieces per chunk
+    constexpr int NP = GP + AP;
+    constexpr int PQ = NP / 8, PREM = NP % 8;
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wa = wid / WCI, wb = wid - wa * WCI;    // co block (COT x 16) / ci tile (16)
+    const int nct = (p.Cin + WCI * 16 - 1) / (WCI * 16);
+    const int tco = blockIdx.x / nct, tci = blockIdx.x - tco * nct;
+    const int co0 = tco * (WCO * COT * 16), ci0 = tci * (WCI * 16);
+    const int b_begin = blockIdx.z * p.spg, b_end = min(p.B, b_begin + p.spg);
+    const int ncs = (p.kend - p.kbeg + KC - 1) / KC;  // chunks per sample
+    const int nchunks = (b_end - b_begin) * ncs;
+    const int ngo = p.Cout >> 3, ngi = p.Cin >> 3;
+
+    // staging plan: piece q = wid + 8 i; q < GP: G (group, block); else activation (plane, group, block)
+    long src0[PQ + 1];
+    int dst[PQ + 1], rel[PQ + 1], isg[PQ + 1];
+#pragma unroll
+    for (int i = 0; i < PQ + 1; ++i) {
+        const int q = wid + 8 * i;
+        src0[i] = 0; dst[i] = 0; rel[i] = 0; isg[i] = 1;
+        if (q < GP) {
+            const int gr = q / GBL, blk = q - gr * GBL;
+            const int grp = min(co0 / 8 + gr, ngo - 1);
+            src0[i] = (long)grp * p.B * p.PPg;
+            dst[i] = (gr * GSG + blk * 64) * 16;
+            rel[i] = blk * 64 + lane;
+        } else if (q < NP) {
+            const int a = q - GP;
+            const int gg = a / ABL, blk = a - gg * ABL;
+            const int pl = gg / GA, gr = gg - pl * GA;
+            const int grp = min(ci0 / 8 + gr, ngi - 1);
+            const long gpi = NPL == 4 ? (long)(grp >> 1) * 8 + pl * 2 + (grp & 1) : grp;
+            src0[i] = gpi * p.B * p.PPa;
+            dst[i] = GBUF + ((pl * GA + gr) * GSA + blk * 64) * 16;
+            rel[i] = blk * 64 + lane + p.smin;
+            isg[i] = 0;
+        }
+    }
+    auto issue = [&](int ci, int buf) {
+        const int b = b_begin + ci / ncs, kc = p.kbeg + (ci % ncs) * KC;
+#pragma unroll
+        for (int i = 0; i < PQ + 1; ++i) {
+            if (i < PQ || wid < PREM) {
+                const int PPx = isg[i] ? p.PPg : p.PPa;
+                const int pos = min(max(kc + rel[i], 0), PPx - 1);
+                const char* base = isg[i] ? p.g : p.act;
+                __builtin_amdgcn_global_load_lds(CB_GLOBAL_PTR(base + (src0[i] + (long)b * PPx + pos) * 16),
+                                                 CB_LDS_PTR(smem + buf * BUF + dst[i]), 16, 0, 0);
+            }
+        }
+    };
+
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    f4 acc[9][COT];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int c = 0; c < COT; ++c) acc[t][c] = f4{0.0f, 0.0f, 0.0f, 0.0f};
+
+    // transposed-read addresses: lane = (k octet q4 = lane >> 4, li = lane & 15): li >> 2 = position within the block of
+    // four, li & 3 = channel quad of the 16 channels
+    const int q4 = lane >> 4, li = lane & 15;
+    const int rq = li >> 2, cq = li & 3;
+    int ga_addr[COT];
+#pragma unroll
+    for (int c = 0; c < COT; ++c)
+        ga_addr[c] = (((wa * COT + c) * 2 + (cq >> 1)) * GSG + 8 * q4 + rq) * 16 + 8 * (cq & 1);
+    const int aa_addr = GBUF + ((wb * 2 + (cq >> 1)) * GSA + 8 * q4 + rq) * 16 + 8 * (cq & 1);
+    int toff[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) toff[t] = (p.tap_plane[t] * GA * GSA + p.tap_off[t]) * 16;
+
+    auto tr = [&](const char* a) {
+        return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) cb_s4*)(a));
+    };
+    auto frag = [&](const char* a) {          // 8 consecutive positions of this lane's channel
+        const cb_s4 lo = tr(a), hi = tr(a + 64);
+        cb_s8 f;
+        f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+        f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+        return __builtin_bit_cast(cb_bf8, f);
+    };
+
+    if (nchunks > 0) issue(0, 0);
+    for (int ci = 0; ci < nchunks; ++ci) {
+        cb_wait_vm<0>();
+        __builtin_amdgcn_s_barrier();       // chunk ci has landed for everybody; everybody is done with the other buffer
+        if (ci + 1 < nchunks) issue(ci + 1, (ci + 1) & 1);
+        const char* buf = smem + (ci & 1) * BUF;
+        const int kc = p.kbeg + (ci % ncs) * KC;
+        const int nks = min(KC, p.kend - kc) >> 5;
+        for (int ks = 0; ks < nks; ++ks) {
+            cb_bf8 A[COT];
+#pragma unroll
+            for (int c = 0; c < COT; ++c) A[c] = frag(buf + ga_addr[c] + ks * 512);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const cb_bf8 Bv = frag(buf + aa_addr + toff[t] + ks * 512);
+#pragma unroll
+                for (int c = 0; c < COT; ++c)
+                    acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[c], Bv, acc[t][c], 0, 0, 0);
+            }
+        }
+    }
+    // acc[t][c][reg]: row (co) = 4 (lane >> 4) + reg, column (ci) = lane & 15
+    float* dstp = p.partial + (long)blockIdx.z * 9 * p.Cout * p.Cin;
+    const int cin = ci0 + wb * 16 + li;
+    if (cin < p.Cin) {
+#pragma unroll
+        for (int c = 0; c < COT; ++c)
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int co = co0 + (wa * COT + c) * 16 + 4 * q4 + r;
+                    if (co < p.Cout) dstp[((long)t * p.Cout + co) * p.Cin + cin] = acc[t][c][r] * p.out_scale;
+                }
+    }
+}
+
+
+// dW[n][c][tap] = sum_z partial[z][tap][n][c]   (fixed order)
+__global__ __launch_bounds__(256) void cb_wgrad_reduce_kernel(const float* __restrict__ partial, int G, int Cout, int Cin,
+                                                              float* __restrict__ dw) {
+    const long total = 9L * Cout * Cin;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+    int z = 0;
+    for (; z + 3 < G; z += 4) {
+        s0 += partial[(long)z * total + idx];
+        s1 += partial[(long)(z + 1) * total + idx];
+        s2 += partial[(long)(z + 2) * total + idx];
+        s3 += partial[(long)(z + 3) * total + idx];
+    }
+    for (; z < G; ++z) s0 += partial[(long)z * total + idx];
+    const int c = (int)(idx % Cin);
+    const long t = idx / Cin;
+    const int n = (int)(t % Cout), tap = (int)(t / Cout);
+    dw[((long)n * Cin + c) * 9 + tap] = (s0 + s1) + (s2 + s3);
+}
+
+// ---------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------
+static int cb_round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// kind of product: 0 forward of a stride-1 reflection-padded layer, 1 forward of a stride-2 layer (four parity planes),
+// 2 data gradient of a stride-1 layer, 3 data gradient of a stride-2 layer (2x2 taps, four parity planes out)
+struct CbShape {
+    int NT, TPS, SPC, NGP, NJ, pmode, nout, kch;
+};
+static bool cb_shape(int kind, int Cout, int Cin, CbShape& sh) {
+    if (kind == 0) { sh = {6, 3, 3, 2, 8, 0, Cout, Cin}; return true; }
+    if (kind == 1 && Cout > 96) { sh = {6, 3, 3, 8, 5, 0, Cout, Cin}; return true; }
+    if (kind == 1) { sh = {3, 3, 3, 8, 6, 0, Cout, Cin}; return true; }
+    if (kind == 2) { sh = {6, 3, 3, 2, 8, 1, Cin, Cout}; return true; }
+    if (kind == 3) { sh = {6, 2, 2, 2, 8, 2, 4 * Cin, Cout}; return true; }
+    return false;
+}
+
+template <int PARTS, int NGP, int NJ, int WGM, int WGN, int WM, int WN, int TPS, int SPC>
+static int cb_launch_conv(const CbConv& a, int nblk, hipStream_t st) {
+    constexpr int NT = WGN * WN;
+    constexpr size_t lds = (size_t)CB_NBUF * TPS * NT * PARTS * 1024 + (size_t)2 * PARTS * NGP * NJ * 64 * 16;
+    static_assert(lds <= 160 * 1024, "stage ring + two slabs must fit the LDS");
+    auto kern = cb_conv_kernel<PARTS, NGP, NJ, WGM, WGN, WM, WN, TPS, SPC>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const long rows = (long)a.B * a.Qr;
+    dim3 grid((unsigned)((rows + CB_ROWS - 1) / CB_ROWS), nblk, 1);
+    hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, a);
+    MV_LAUNCH_CHECK("cb_conv_kernel");
+    return 0;
+}
+
+template <int PARTS, int NPL, int COT, int WCO, int WCI, int KC>
+static int cb_launch_wgrad(const CbWgrad& a, int ntiles, int Gz, hipStream_t st) {
+    constexpr size_t lds = (size_t)2 * ((size_t)WCO * COT * 2 * (KC + 4) * 16 + (size_t)NPL * WCI * 2 * (KC + 68) * 16);
+    static_assert(lds <= 160 * 1024, "two chunk buffers must fit the LDS");
+    auto kern = cb_wgrad_kernel<PARTS, NPL, COT, WCO, WCI, KC>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, dim3(ntiles, 1, Gz), dim3(512), lds, st, a);
+    MV_LAUNCH_CHECK("cb_wgrad_kernel");
+    return 0;
+}
+
+// tile shapes of the weight gradient: one plane: 96 co x 64 ci, chunks of 128 positions; four parity planes: 192 co x
+// 32 ci, chunks of 64 (sixteen group-planes of activations per chunk)
+static void cb_wgrad_tiles(int planes, int Cout, int Cin, int& tco, int& tci) {
+    tco = planes == 4 ? 192 : 96;
+    tci = planes == 4 ? 32 : 64;
+    (void)Cout; (void)Cin;
+}
+static int cb_wgrad_groups(int B, int ntiles) {
+    int G = 256 / ntiles;
+    if (G < 1) G = 1;
+    if (G > B) G = B;
+    return G;
+}
+
+}  // namespace mdnvae
+using namespace mdnvae;
+
+extern "C" {
+
+size_t mdnvae_cb_packed_bytes(int Cout, int Cin, int kind, int parts) {
+    CbShape sh;
+    if (parts < 1 || parts > 2 || !cb_shape(kind, Cout, Cin, sh) || sh.kch % 16 || Cout % 8 || Cin % 8) return 0;
+    const int nblk = (sh.nout + sh.NT * 32 - 1) / (sh.NT * 32);
+    return (size_t)nblk * (sh.kch / 16) * sh.SPC * sh.TPS * sh.NT * parts * 1024;
+}
+
+int mdnvae_cb_pack_weights(const float* w, int Cout, int Cin, int kind, int parts, const unsigned* amax, void* packed,
+                           void* stream) {
+    MV_REQUIRE(w && packed, E_ARG, "mdnvae_cb_pack_weights: null pointer");
+    const size_t bytes = mdnvae_cb_packed_bytes(Cout, Cin, kind, parts);
+    MV_REQUIRE(bytes > 0, E_SHAPE, "mdnvae_cb_pack_weights: unsupported shape (%d -> %d, kind %d, parts %d)", Cin, Cout, kind, parts);
+    MV_REQUIRE(parts == 1 || amax, E_ARG, "mdnvae_cb_pack_weights: two fp16 parts need the tensor's largest magnitude");
+    CbShape sh;
+    cb_shape(kind, Cout, Cin, sh);
+    const int nblk = (sh.nout + sh.NT * 32 - 1) / (sh.NT * 32);
+    const long total = (long)(bytes / 2);
+    hipLaunchKernelGGL(cb_pack_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w,
+                       Cout, Cin, sh.pmode, nblk, sh.NT, sh.kch / 16, sh.SPC, sh.TPS, parts, amax, static_cast<char*>(packed));
+    MV_LAUNCH_CHECK("cb_pack_weights_kernel");
+    return 0;
+}
+
+int mdnvae_cb_conv(const void* act, long part_stride, const void* packed_w, const float* bias, float* out, int B, int Cout,
+                   int Cin, int kind, int rows, int pitch, int PP, int parts, float out_scale, void* stream) {
+    MV_REQUIRE(B >= 0, E_ARG, "mdnvae_cb_conv: negative batch");
+    if (B == 0) return 0;
+    MV_REQUIRE(act && packed_w && out, E_ARG, "mdnvae_cb_conv: null pointer");
+    MV_REQUIRE(parts == 1 || parts == 2, E_ARG, "mdnvae_cb_conv: parts = %d (1 or 2)", parts);
+    CbShape sh;
+    MV_REQUIRE(cb_shape(kind, Cout, Cin, sh) && sh.kch % 16 == 0, E_SHAPE, "mdnvae_cb_conv: unsupported product (%d -> %d, kind %d)",
+               Cin, Cout, kind);
+    MV_REQUIRE(rows >= 1 && pitch >= 2, E_SHAPE, "mdnvae_cb_conv: bad grid %d x %d", rows, pitch);
+    CbConv a{};
+    a.act = static_cast<const char*>(act);
+    a.part_stride = part_stride;
+    a.w = static_cast<const char*>(packed_w);
+    a.bias = bias;
+    a.out = out;
+    a.B = B; a.PP = PP;
+    a.nchunk = sh.kch / 16;
+    a.Qr = cb_round_up(rows * pitch, 4);
+    a.ntot = sh.nout;
+    a.out_scale = out_scale;
+    const int slabpos = sh.NJ * 64;
+    int ntaps = 0;
+    if (kind == 0 || kind == 2) {
+        for (int t = 0; t < 9; ++t) a.tap_lds[ntaps++] = ((t / 3) * pitch + (t % 3)) * 16;
+        a.halo = 2 * pitch + 2;
+    } else if (kind == 1) {
+        for (int t = 0; t < 9; ++t) {
+            const int ky = t / 3, kx = t % 3;
+            const int plane = (ky == 1 ? 0 : 1) * 2 + (kx == 1 ? 0 : 1);
+            a.tap_lds[ntaps++] = (plane * 2 * slabpos + (ky > 0) * pitch + (kx > 0)) * 16;
+        }
+        a.halo = pitch + 1;
+    } else {
+        for (int t = 0; t < 4; ++t) a.tap_lds[ntaps++] = ((t >> 1) * pitch + (t & 1)) * 16;
+        a.halo = pitch + 1;
+    }
+    MV_REQUIRE(a.Qr >= CB_ROWS, E_SHAPE, "mdnvae_cb_conv: %d rows per sample are fewer than the %d-row tile", a.Qr, CB_ROWS);
+    MV_REQUIRE(CB_ROWS + 2 * a.halo <= slabpos, E_SHAPE, "mdnvae_cb_conv: pitch %d needs a slab of %d positions (%d fit)", pitch,
+               CB_ROWS + 2 * a.halo, slabpos);
+    MV_REQUIRE(PP >= a.Qr + a.halo, E_SHAPE, "mdnvae_cb_conv: input planes of %d positions are shorter than %d", PP, a.Qr + a.halo);
+    MV_REQUIRE(parts == 1, E_SHAPE, "mdnvae_cb_conv: two-part operands are not built yet");
+    const int nblk = (sh.nout + sh.NT * 32 - 1) / (sh.NT * 32);
+    hipStream_t st = (hipStream_t)stream;
+    if (kind == 0 || kind == 2) return cb_launch_conv<1, 2, 8, 4, 2, 2, 3, 3, 3>(a, nblk, st);
+    if (kind == 3) return cb_launch_conv<1, 2, 8, 4, 2, 2, 3, 2, 2>(a, nblk, st);
+    if (sh.NT == 6) return cb_launch_conv<1, 8, 5, 4, 2, 2, 3, 3, 3>(a, nblk, st);
+    return cb_launch_conv<1, 8, 6, 8, 1, 1, 3, 3, 3>(a, nblk, st);
+}
+
+int mdnvae_cb_plane_stats(const float* y, long nplanes, int H, int W, int pitch, long plane_stride, float* stats,
+                          void* stream) {
+    MV_REQUIRE(nplanes >= 0 && H >= 1 && W >= 1 && pitch >= W, E_ARG, "mdnvae_cb_plane_stats: bad size");
+    if (nplanes == 0) return 0;
+    MV_REQUIRE(y && stats, E_ARG, "mdnvae_cb_plane_stats: null pointer");
+    const int Q = H * pitch;
+    MV_REQUIRE(Q <= 2048, E_SHAPE, "mdnvae_cb_plane_stats: plane of %d positions exceeds 2048", Q);
+    dim3 grid((unsigned)((nplanes + 3) / 4));
+    hipStream_t st = (hipStream_t)stream;
+    if (Q <= 640) hipLaunchKernelGGL(cb_plane_stats_kernel<10>, grid, dim3(256), 0, st, y, nplanes, H, W, pitch, plane_stride, stats);
+    else hipLaunchKernelGGL(cb_plane_stats_kernel<32>, grid, dim3(256), 0, st, y, nplanes, H, W, pitch, plane_stride, stats);
+    MV_LAUNCH_CHECK("cb_plane_stats_kernel");
+    return 0;
+}
+
+int mdnvae_cb_norm_fwd(const float* y, const float* stats, const float* skip, float* stream_out, void* act,
+                       long part_stride, int B, int C, int H, int W, int pitch_y, long Qy, int relu, int mode, int PP,
+                       int parts, float scale, void* stream) {
+    MV_REQUIRE(B >= 0 && C >= 8 && C % 8 == 0 && H >= 2 && W >= 2, E_SHAPE, "mdnvae_cb_norm_fwd: bad shape");
+    if (B == 0) return 0;
+    MV_REQUIRE(y && stats && (act || stream_out), E_ARG, "mdnvae_cb_norm_fwd: null pointer");
+    MV_REQUIRE(mode == 0 || mode == 1, E_ARG, "mdnvae_cb_norm_fwd: mode %d", mode);
+    MV_REQUIRE(parts == 1 || parts == 2, E_ARG, "mdnvae_cb_norm_fwd: parts = %d", parts);
+    MV_REQUIRE(B <= 65535, E_SHAPE, "mdnvae_cb_norm_fwd: batch %d exceeds the grid limit", B);
+    CbNormFwd a{};
+    a.y = y; a.stats = stats; a.skip = skip; a.stream_out = stream_out;
+    a.act = static_cast<char*>(act);
+    a.part_stride = part_stride;
+    a.B = B; a.C = C; a.H = H; a.W = W; a.pitch_y = pitch_y; a.Qy = (int)Qy; a.relu = relu; a.mode = mode; a.PP = PP;
+    a.opitch = mode == 0 ? W + 2 : (W + 1) / 2 + 1;
+    const int orows = mode == 0 ? H + 2 : (H + 1) / 2 + 1;
+    MV_REQUIRE(PP >= orows * a.opitch, E_SHAPE, "mdnvae_cb_norm_fwd: %d positions per plane are fewer than %d x %d", PP, orows, a.opitch);
+    a.scale = scale;
+    dim3 grid(C / 8, B);
+    if (parts == 1) hipLaunchKernelGGL(cb_norm_fwd_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(cb_norm_fwd_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    MV_LAUNCH_CHECK("cb_norm_fwd_kernel");
+    return 0;
+}
+
+int mdnvae_cb_norm_bwd(const float* g, int gmode, int pitch_g, long Qg, const float* base, float* sum_out, const float* y,
+                       const float* stats, int pitch_y, long Qy, int relu, int B, int C, int H, int W, int omode, void* dc,
+                       long part_stride, int PP, int parts, float scale, float* gsum, void* stream) {
+    MV_REQUIRE(B >= 0 && C >= 1 && H >= 3 && W >= 3, E_SHAPE, "mdnvae_cb_norm_bwd: bad shape");
+    if (B == 0) return 0;
+    MV_REQUIRE(y && stats && dc && (g || gmode == 3), E_ARG, "mdnvae_cb_norm_bwd: null pointer");
+    MV_REQUIRE(gmode >= 0 && gmode <= 3 && omode >= 0 && omode <= 2, E_ARG, "mdnvae_cb_norm_bwd: gmode %d / omode %d", gmode, omode);
+    MV_REQUIRE(gmode != 3 || base, E_ARG, "mdnvae_cb_norm_bwd: no gradient source");
+    MV_REQUIRE(parts == 1 || parts == 2, E_ARG, "mdnvae_cb_norm_bwd: parts = %d", parts);
+    MV_REQUIRE(B <= 65535, E_SHAPE, "mdnvae_cb_norm_bwd: batch %d exceeds the grid limit", B);
+    CbNormBwd a{};
+    a.g = g; a.gmode = gmode; a.pitch_g = pitch_g; a.Qg = Qg; a.base = base; a.sum_out = sum_out;
+    a.y = y; a.stats = stats; a.pitch_y = pitch_y; a.Qy = Qy; a.relu = relu;
+    a.B = B; a.C = C; a.H = H; a.W = W; a.omode = omode;
+    a.dc = static_cast<char*>(dc);
+    a.part_stride = part_stride; a.PP = PP; a.scale = scale; a.gsum = gsum;
+    a.opitch = omode == 0 ? W + 2 : (omode == 1 ? W + 1 : W);
+    hipStream_t st = (hipStream_t)stream;
+    if (omode == 2) {
+        MV_REQUIRE(H * W <= 32 * 256, E_SHAPE, "mdnvae_cb_norm_bwd: plane of %d entries exceeds %d", H * W, 32 * 256);
+        hipLaunchKernelGGL((cb_norm_bwd_kernel<1, 1, 32>), dim3(C, B), dim3(256), 0, st, a);
+    } else {
+        MV_REQUIRE(C % 8 == 0, E_SHAPE, "mdnvae_cb_norm_bwd: %d channels are not a multiple of 8", C);
+        const int orows = omode == 0 ? H + 4 : H + 1;
+        MV_REQUIRE(PP >= orows * a.opitch, E_SHAPE, "mdnvae_cb_norm_bwd: %d positions per plane are fewer than %d x %d", PP, orows, a.opitch);
+        MV_REQUIRE(PP <= 9 * 256, E_SHAPE, "mdnvae_cb_norm_bwd: %d positions per plane exceed %d", PP, 9 * 256);
+        dim3 grid(C / 8, B);
+        if (parts == 1) {
+            if (PP <= 3 * 256) hipLaunchKernelGGL((cb_norm_bwd_kernel<1, 8, 3>), grid, dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((cb_norm_bwd_kernel<1, 8, 9>), grid, dim3(256), 0, st, a);
+        } else {
+            if (PP <= 3 * 256) hipLaunchKernelGGL((cb_norm_bwd_kernel<2, 8, 3>), grid, dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((cb_norm_bwd_kernel<2, 8, 9>), grid, dim3(256), 0, st, a);
+        }
+    }
+    MV_LAUNCH_CHECK("cb_norm_bwd_kernel");
+    return 0;
+}
+
+size_t mdnvae_cb_wgrad_workspace_floats(int B, int Cout, int Cin, int planes) {
+    int tco, tci;
+    cb_wgrad_tiles(planes, Cout, Cin, tco, tci);
+    const int ntiles = ((Cout + tco - 1) / tco) * ((Cin + tci - 1) / tci);
+    return (size_t)cb_wgrad_groups(B, ntiles) * 9 * Cout * Cin;
+}
+
+int mdnvae_cb_wgrad(const void* g, const void* act, float* workspace, float* grad_w, int B, int Cout, int Cin, int planes,
+                    int PPg, int PPa, int kbeg, int kend, int pitch, int parts, float out_scale, void* stream) {
+    MV_REQUIRE(B >= 1, E_ARG, "mdnvae_cb_wgrad: empty batch");
+    MV_REQUIRE(g && act && workspace && grad_w, E_ARG, "mdnvae_cb_wgrad: null pointer");
+    MV_REQUIRE(planes == 1 || planes == 4, E_ARG, "mdnvae_cb_wgrad: planes = %d (1 or 4)", planes);
+    MV_REQUIRE(parts == 1, E_SHAPE, "mdnvae_cb_wgrad: two-part operands are not built yet");
+    MV_REQUIRE(Cout % 8 == 0 && Cin % 8 == 0, E_SHAPE, "mdnvae_cb_wgrad: channel counts must be multiples of 8");
+    MV_REQUIRE(kbeg >= 0 && kbeg % 32 == 0 && kend % 32 == 0 && kend > kbeg && kend <= PPg, E_SHAPE,
+               "mdnvae_cb_wgrad: position range [%d, %d) must be whole 32-position steps inside the %d-position plane", kbeg, kend, PPg);
+    CbWgrad a{};
+    a.g = static_cast<const char*>(g);
+    a.act = static_cast<const char*>(act);
+    a.partial = workspace;
+    a.B = B; a.Cout = Cout; a.Cin = Cin; a.PPg = PPg; a.PPa = PPa; a.kbeg = kbeg; a.kend = kend;
+    a.out_scale = out_scale;
+    int smax;
+    if (planes == 1) {
+        a.smin = -2 * pitch - 2; smax = 0;
+        for (int t = 0; t < 9; ++t) {
+            a.tap_off[t] = (t / 3 - 2) * pitch + (t % 3 - 2) - a.smin;
+            a.tap_plane[t] = 0;
+        }
+    } else {
+        a.smin = 0; smax = pitch + 1;
+        for (int t = 0; t < 9; ++t) {
+            const int ky = t / 3, kx = t % 3;
+            a.tap_off[t] = (ky > 0) * pitch + (kx > 0);
+            a.tap_plane[t] = (ky == 1 ? 0 : 1) * 2 + (kx == 1 ? 0 : 1);
+        }
+    }
+    MV_REQUIRE(smax - a.smin <= 64, E_SHAPE, "mdnvae_cb_wgrad: pitch %d: the taps span %d positions (64 fit)", pitch, smax - a.smin);
+    int tco, tci;
+    cb_wgrad_tiles(planes, Cout, Cin, tco, tci);
+    const int ntiles = ((Cout + tco - 1) / tco) * ((Cin + tci - 1) / tci);
+    const int Gz0 = cb_wgrad_groups(B, ntiles);
+    a.spg = (B + Gz0 - 1) / Gz0;
+    const int Gz = (B + a.spg - 1) / a.spg;
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    if (planes == 1) rc = cb_launch_wgrad<1, 1, 3, 2, 4, 128>(a, ntiles, Gz, st);
+    else rc = cb_launch_wgrad<1, 4, 3, 4, 2, 64>(a, ntiles, Gz, st);
+    if (rc) return rc;
+    const long total = 9L * Cout * Cin;
+    hipLaunchKernelGGL(cb_wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, workspace, Gz, Cout, Cin,
+                       grad_w);
+    MV_LAUNCH_CHECK("cb_wgrad_reduce_kernel");
+    return 0;
+}
+
+}  // extern "C"

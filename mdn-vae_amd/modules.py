@@ -117,7 +117,8 @@ def _dev_int(a, device):
 # ---------------------------------------------------------------------------------------
 # conv-encoder VAE family
 # ---------------------------------------------------------------------------------------
-CONV_PRECISIONS = {"fp32_mfma": 0, "bf16": 1, "bf16x2": 2, "fp32": 3}
+CONV_PRECISIONS = {"fp32_mfma": 0, "bf16": 1, "bf16_planar": 1, "bf16x2": 2, "fp32": 3}
+CONV_BLOCKED = {"bf16"}          # precisions whose activations live in the channel-blocked 16-bit layout
 
 
 class ConvVAE(nn.Module):
@@ -126,7 +127,9 @@ class ConvVAE(nn.Module):
 
     precision: how the encoder's 3x3 convolutions multiply (CONV_PRECISIONS): 'fp32_mfma' the fp32 matrix
               instruction; 'fp32' fp32 accuracy from three bf16 parts per operand on the bf16 matrix cores;
-              'bf16x2' two parts (2^-16 per product); 'bf16' operands rounded to bf16.  fp32 accumulation always.
+              'bf16x2' two parts (2^-16 per product); 'bf16' operands rounded to bf16, kept between the convolutions
+              in the channel-blocked layout the matrix cores read directly ('bf16_planar': the same rounding with fp32
+              planes between the layers).  fp32 accumulation always.
     decoder:  'nn'   plain second layers                          (VAE_CNN_NN scripts)
               'gcn'  GraphCNN second layers + diagonal intercept  (VAE-CNN-GCN scripts)
     intercept: 'dense' | 'diag' | 'none';  final: 'exp' | 'none';  dropout: p or 0
@@ -195,7 +198,7 @@ class ConvVAE(nn.Module):
             h12 = self.fc222(self.fc12(x, act="relu"), act="relu")
             return self.fc21(h11), self.fc22(h12)
         feat = ops.conv_encoder(x, self.n_nodes, [(m.weight, m.bias) for m in self.conv_params()],
-                                parts=CONV_PRECISIONS[self.precision])
+                                parts=CONV_PRECISIONS[self.precision], blocked=self.precision in CONV_BLOCKED)
         return self.fc_mean(feat), self.fc_log_var(feat)
 
     def reparameterize(self, mu, logvar, eps=None):

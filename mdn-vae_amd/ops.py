@@ -1333,14 +1333,228 @@ class _ConvEncoder(torch.autograd.Function):
         return (None, None, None, *grads)
 
 
-def conv_encoder(x, n_nodes, weights_and_biases, parts=0):
+# ---------------------------------------------------------------------------------------
+# the same encoder on channel-blocked 16-bit operands (csrc/cbconv.hip)
+# ---------------------------------------------------------------------------------------
+def _ru(v, m):
+    return (v + m - 1) // m * m
+
+
+class _CBGeom:
+    """Grids of the channel-blocked encoder for n_nodes x n_nodes inputs.  A convolution's output rows are
+    positions of its INPUT grid (row pitch = that grid's width), Qr of them per sample; PP is the number of
+    positions per (group-plane, sample) of a channel-blocked tensor: its own rows x pitch, and far enough
+    past the last output row for the largest tap offset."""
+
+    def __init__(self, n):
+        self.n = n
+        self.h2 = (n + 1) // 2                 # output of the first stride-2 layer
+        self.h3 = (self.h2 + 1) // 2           # output of the second one = the residual blocks' planes
+        self.p2, self.p3, self.pr = self.h2 + 1, self.h3 + 1, self.h3 + 2
+        self.q2, self.q3 = _ru(self.h2 * self.p2, 4), _ru(self.h3 * self.p3, 4)
+        self.qr = _ru(self.h3 * self.pr, 4)                  # residual forward rows
+        self.qd = _ru((self.h3 + 2) * self.pr, 4)            # residual data-gradient rows (reflection-padded grid)
+        s2d = lambda rows, pitch, q: _ru(max((rows + 1) * pitch, q + pitch + 1) + 1, 4)
+        self.pp_a1 = s2d(self.h2, self.p2, self.q2)          # parity planes of the first stride-2 layer's input
+        self.pp_a2 = s2d(self.h3, self.p3, self.q3)
+        self.pp_d2 = self.pp_a1                              # output gradients of the stride-2 layers (zero row / column behind)
+        self.pp_d3 = self.pp_a2
+        self.pp_r = _ru(max((self.h3 + 2) * self.pr, self.qr + 2 * self.pr + 2) + 1, 4)      # reflection-padded activations
+        self.pp_dr = _ru(max((self.h3 + 4) * self.pr, self.qd + 2 * self.pr + 2) + 1, 4)     # zero-bordered gradients
+        # weight-gradient position ranges (whole 32-position steps around the output pixels)
+        self.k_r = ((2 * self.pr) // 32 * 32, _ru((2 + self.h3) * self.pr, 32))
+        self.k_2 = (0, _ru(self.h2 * self.p2, 32))
+        self.k_3 = (0, _ru(self.h3 * self.p3, 32))
+        if self.qr < 256 or self.q3 < 256:
+            raise ValueError(f"n_nodes = {n}: planes of {self.h3} x {self.h3} are smaller than the 256-position tile")
+
+
+def _cb_alloc(groups, B, PP, dev, parts=1):
+    """Channel-blocked tensor [parts][groups][B][PP][8] as bytes (+ slack for clamped reads)."""
+    return torch.empty(parts * groups * B * PP * 16 + 4096, dtype=torch.uint8, device=dev), groups * B * PP * 16
+
+
+def _cb_pack(w, kind, dev):
+    cout, cin = w.shape[0], w.shape[1]
+    n = _lib.load().mdnvae_cb_packed_bytes(cout, cin, kind, 1)
+    if n == 0:
+        raise RuntimeError(f"channel-blocked convolution: unsupported layer {cin} -> {cout} (kind {kind})")
+    out = torch.empty(n, dtype=torch.uint8, device=dev)
+    call("mdnvae_cb_pack_weights", ptr(_c(w), "conv weight"), cout, cin, kind, 1, None, out.data_ptr(), stream())
+    return out
+
+
+def _cb_conv(act, part_stride, wp, bias, B, cout, cin, kind, rows, pitch, PP):
+    nout = {0: cout, 1: cout, 2: cin, 3: 4 * cin}[kind]
+    out = torch.empty(B, nout, _ru(rows * pitch, 4), dtype=torch.float32, device=act.device)
+    call("mdnvae_cb_conv", act.data_ptr(), part_stride, wp.data_ptr(), ptr(bias, "conv bias"), ptr(out), B, cout, cin, kind,
+         rows, pitch, PP, 1, 1.0, stream())
+    return out
+
+
+def _cb_stats(y, H, W, pitch):
+    B, C, Q = y.shape
+    st = torch.empty(B * C, 2, dtype=torch.float32, device=y.device)
+    call("mdnvae_cb_plane_stats", ptr(y), B * C, H, W, pitch, Q, ptr(st), stream())
+    return st
+
+
+def _cb_norm_fwd(y, stats, H, W, pitch_y, relu, mode, PP, skip=None, want_stream=False, want_act=True):
+    """Channel-blocked activation (and, if asked, the fp32 residual stream [B,C,H,W]) of a raw conv output."""
+    B, C = y.shape[0], y.shape[1]
+    Qy = y.numel() // (B * C)
+    dev = y.device
+    act, ps = (None, 0)
+    if want_act:
+        act, ps = _cb_alloc((C // 8) * (4 if mode == 1 else 1), B, PP, dev)
+    so = torch.empty(B, C, H, W, dtype=torch.float32, device=dev) if want_stream else None
+    call("mdnvae_cb_norm_fwd", ptr(y), ptr(stats), ptr(skip), ptr(so), None if act is None else act.data_ptr(), ps, B, C, H, W,
+         pitch_y, Qy, int(relu), mode, PP, 1, 1.0, stream())
+    return act, so
+
+
+def _cb_norm_bwd(g, gmode, pitch_g, y, stats, pitch_y, relu, C, H, W, omode, PP, base=None, want_sum=False):
+    """(dc, plane sums [B,C], base + gradient or None)."""
+    B = y.shape[0]
+    dev = y.device
+    Qy = y.numel() // (B * C)
+    Qg = 0 if g is None else g.numel() // (B * (4 * C if gmode == 2 else C))
+    if omode == 2:
+        dc = torch.empty(B, C, H, W, dtype=torch.float32, device=dev)
+        ps = 0
+    else:
+        dc, ps = _cb_alloc(C // 8, B, PP, dev)
+    gsum = torch.empty(B, C, dtype=torch.float32, device=dev)
+    so = torch.empty(B, C, H, W, dtype=torch.float32, device=dev) if want_sum else None
+    call("mdnvae_cb_norm_bwd", ptr(g), gmode, pitch_g, Qg, ptr(base), ptr(so), ptr(y), ptr(stats), pitch_y, Qy, int(relu), B, C,
+         H, W, omode, dc.data_ptr(), ps, PP, 1, 1.0, ptr(gsum), stream())
+    return dc, gsum, so
+
+
+def _cb_wgrad(g, act, B, cout, cin, planes, PPg, PPa, krange, pitch):
+    lib = _lib.load()
+    ws = torch.empty(lib.mdnvae_cb_wgrad_workspace_floats(B, cout, cin, planes), dtype=torch.float32, device=g.device)
+    gw = torch.empty(cout, cin, 3, 3, dtype=torch.float32, device=g.device)
+    call("mdnvae_cb_wgrad", g.data_ptr(), act.data_ptr(), ptr(ws), ptr(gw), B, cout, cin, planes, PPg, PPa, krange[0], krange[1],
+         pitch, 1, 1.0, stream())
+    return gw
+
+
+class _ConvEncoderCB(torch.autograd.Function):
+    """The encoder of _ConvEncoder with bf16 operands in the channel-blocked layout: x [B, n*n] -> pooled
+    features.  The 7x7 single-channel stem and the max pool are the fp32 kernels of _ConvEncoder."""
+
+    @staticmethod
+    def forward(ctx, x, n_nodes, *wb):
+        x = _c(x)
+        B, dev = x.shape[0], x.device
+        ptr(x, "x")
+        G = _CBGeom(n_nodes)
+        nres = (len(wb) // 2 - 3) // 2
+        need_bwd = any(ctx.needs_input_grad[2:])
+        ws, bs = list(wb[0::2]), list(wb[1::2])
+        stem = _ConvLayer(1, 48, 7, 1, 3, True, n_nodes)
+        wstem, _ = stem.pack(ws[0], dev, False)
+        kinds = [1, 1] + [0] * (2 * nres)
+        wf = [_cb_pack(w, k, dev) for w, k in zip(ws[1:], kinds)]
+        raw1 = stem.fwd(x, None, 0, wstem, bs[0], B)                                   # [B,48,n,n]
+        st1 = _plane_stats(raw1)
+        a1, _ = _cb_norm_fwd(raw1, st1, n_nodes, n_nodes, n_nodes, True, 1, G.pp_a1)
+        y2 = _cb_conv(a1, 0, wf[0], bs[1], B, 96, 48, 1, G.h2, G.p2, G.pp_a1)
+        st2 = _cb_stats(y2, G.h2, G.h2, G.p2)
+        a2, _ = _cb_norm_fwd(y2, st2, G.h2, G.h2, G.p2, True, 1, G.pp_a2)
+        y3 = _cb_conv(a2, 0, wf[1], bs[2], B, 192, 96, 1, G.h3, G.p3, G.pp_a2)
+        st3 = _cb_stats(y3, G.h3, G.h3, G.p3)
+        H = G.h3
+        xp, xs = _cb_norm_fwd(y3, st3, H, H, G.p3, True, 0, G.pp_r, want_stream=True)
+        saved = [x, raw1, st1, a1, y2, st2, a2, y3, st3]
+        for k in range(nres):
+            ia, ib = 2 + 2 * k, 3 + 2 * k           # index into wf / (ws[1:], bs[1:])
+            ya = _cb_conv(xp, 0, wf[ia], bs[ia + 1], B, 192, 192, 0, H, G.pr, G.pp_r)
+            sa = _cb_stats(ya, H, H, G.pr)
+            aa, _ = _cb_norm_fwd(ya, sa, H, H, G.pr, True, 0, G.pp_r)
+            yb = _cb_conv(aa, 0, wf[ib], bs[ib + 1], B, 192, 192, 0, H, G.pr, G.pp_r)
+            sb = _cb_stats(yb, H, H, G.pr)
+            saved += [xp, ya, sa, aa, yb, sb]
+            xp, xs = _cb_norm_fwd(yb, sb, H, H, G.pr, False, 0, G.pp_r, skip=xs, want_stream=True, want_act=k + 1 < nres)
+        K = 8
+        PH = H // K
+        feat = torch.empty(B, 192 * PH * PH, dtype=torch.float32, device=dev)
+        argmax = torch.empty(B, 192 * PH * PH, dtype=torch.int32, device=dev)
+        call("mdnvae_maxpool_fwd", ptr(xs), B * 192, H, H, K, ptr(feat), ptr(argmax, "argmax", torch.int32), stream())
+        if need_bwd:
+            ctx.save_for_backward(*saved, argmax, *ws[1:])
+            ctx.n_nodes, ctx.nres = n_nodes, nres
+        return feat
+
+    @staticmethod
+    def backward(ctx, gfeat):
+        sv = ctx.saved_tensors
+        nres, n = ctx.nres, ctx.n_nodes
+        G = _CBGeom(n)
+        x, raw1, st1, a1, y2, st2, a2, y3, st3 = sv[:9]
+        blocks = [sv[9 + 6 * k: 15 + 6 * k] for k in range(nres)]
+        argmax = sv[9 + 6 * nres]
+        ws = sv[10 + 6 * nres:]                     # weights of layers 1.. (the two stride-2 layers, then the blocks)
+        B, dev = x.shape[0], x.device
+        H = G.h3
+        kinds = [3, 3] + [2] * (2 * nres)
+        wt = [_cb_pack(w, k, dev) for w, k in zip(ws, kinds)]
+        gfeat = _c(gfeat)
+        Gs = torch.empty(B, 192, H, H, dtype=torch.float32, device=dev)
+        call("mdnvae_maxpool_bwd", ptr(gfeat), ptr(argmax, "argmax", torch.int32), B * 192, H, H, 8, ptr(Gs), stream())
+        nl = 3 + 2 * nres
+        gw, gb = [None] * nl, [None] * nl
+        dcb = None
+        for k in range(nres - 1, -1, -1):
+            xp, ya, sa, aa, yb, sb = blocks[k]
+            ia, ib = 3 + 2 * k, 4 + 2 * k           # layer numbers (0 = stem)
+            if dcb is None:
+                dcb, gs, _ = _cb_norm_bwd(Gs, 0, H, yb, sb, G.pr, False, 192, H, H, 0, G.pp_dr)
+                gb[ib] = _colsum(gs)
+            gw[ib] = _cb_wgrad(dcb, aa, B, 192, 192, 1, G.pp_dr, G.pp_r, G.k_r, G.pr)
+            dap = _cb_conv(dcb, 0, wt[ib - 1], None, B, 192, 192, 2, H + 2, G.pr, G.pp_dr)
+            dca, gs, _ = _cb_norm_bwd(dap, 1, G.pr, ya, sa, G.pr, True, 192, H, H, 0, G.pp_dr)
+            gb[ia] = _colsum(gs)
+            gw[ia] = _cb_wgrad(dca, xp, B, 192, 192, 1, G.pp_dr, G.pp_r, G.k_r, G.pr)
+            dxp = _cb_conv(dca, 0, wt[ia - 1], None, B, 192, 192, 2, H + 2, G.pr, G.pp_dr)
+            if k > 0:
+                # the stream's gradient in front of this block, and straight on into the block before it
+                ybp, sbp = blocks[k - 1][4], blocks[k - 1][5]
+                dcb, gs, Gs = _cb_norm_bwd(dxp, 1, G.pr, ybp, sbp, G.pr, False, 192, H, H, 0, G.pp_dr, base=Gs, want_sum=True)
+                gb[ib - 2] = _colsum(gs)
+            else:
+                dc3, gs, _ = _cb_norm_bwd(dxp, 1, G.pr, y3, st3, G.p3, True, 192, H, H, 1, G.pp_d3, base=Gs)
+                gb[2] = _colsum(gs)
+        gw[2] = _cb_wgrad(dc3, a2, B, 192, 96, 4, G.pp_d3, G.pp_a2, G.k_3, G.p3)
+        da2 = _cb_conv(dc3, 0, wt[1], None, B, 192, 96, 3, G.h3, G.p3, G.pp_d3)
+        dc2, gs, _ = _cb_norm_bwd(da2, 2, G.p3, y2, st2, G.p2, True, 96, G.h2, G.h2, 1, G.pp_d2)
+        gb[1] = _colsum(gs)
+        gw[1] = _cb_wgrad(dc2, a1, B, 96, 48, 4, G.pp_d2, G.pp_a1, G.k_2, G.p2)
+        da1 = _cb_conv(dc2, 0, wt[0], None, B, 96, 48, 3, G.h2, G.p2, G.pp_d2)
+        g_r1, gs, _ = _cb_norm_bwd(da1, 2, G.p2, raw1, st1, n, True, 48, n, n, 2, 0)
+        gb[0] = _colsum(gs)
+        stem = _ConvLayer(1, 48, 7, 1, 3, True, n)
+        gw[0] = stem.wgrad(x.view(B, 1, n, n), None, 0, g_r1, B)
+        grads = []
+        for w_, b_ in zip(gw, gb):
+            grads += [w_, b_]
+        return (None, None, *grads)
+
+
+def conv_encoder(x, n_nodes, weights_and_biases, parts=0, blocked=False):
     """weights_and_biases: [(weight, bias)] for the stem, the two stride-2 convs and the residual
     block convs, in network order.  parts: 0 = the fp32 matrix instruction; 1..3 = the 3x3 convolutions on
     the bf16 matrix cores with operands split into that many bf16 parts (1: operands rounded to bf16,
-    3: fp32 accuracy); the stem, the norms and the pool are fp32 in every mode."""
+    3: fp32 accuracy); the stem, the norms and the pool are fp32 in every mode.  blocked: activations between
+    the 3x3 convolutions in the channel-blocked 16-bit layout (_ConvEncoderCB) instead of fp32 planes."""
     flat = []
     for w, b in weights_and_biases:
         flat += [w, b]
+    if blocked:
+        if int(parts) != 1:
+            raise ValueError("the channel-blocked encoder is built for bf16 operands (parts = 1)")
+        return _ConvEncoderCB.apply(x, n_nodes, *flat)
     return _ConvEncoder.apply(x, n_nodes, int(parts), *flat)
 
 
