@@ -409,9 +409,11 @@ int mdnvae_maxpool_bwd(const float* grad_feat, const int* argmax, long nplanes, 
  * 3x3 convolution kept as   act[part][group-plane][B][PP positions][8 channels]   (16-bit elements):
  * written once, already padded and rounded, by the normalisation pass that produces it, so that the
  * convolutions copy their operands straight into LDS (no staging arithmetic).  parts = 1: bf16;
- * parts = 2: two fp16 parts of value * scale.  Convolutions write fp32 planes out[B][channels][Qr],
- * Qr = rows * pitch rounded up to 4, over the pitched grid of their input (columns past the plane's
- * width are scratch).
+ * parts = 2: two fp16 parts of value * scale.  Convolutions write planes out[B][channels][Qr],
+ * Qr = rows * pitch rounded up to 8, over the pitched grid of their input (columns past the plane's
+ * width are scratch): fp32, or (out16 = 1, forward kinds) fp16 clamped to the finite range - a raw
+ * convolution output is normalised and rounded to bf16 by the next pass, which 11 significant bits
+ * do not disturb, and a workgroup's write-out is bound by bytes per CU.
  *
  * kind of product: 0 forward of a stride-1 reflection-pad-1 layer (input: reflected border, pitch W + 2;
  *   rows = H);  1 forward of a stride-2 pad-1 layer (input: four parity planes with a zero block row /
@@ -427,8 +429,8 @@ size_t mdnvae_cb_packed_bytes(int Cout, int Cin, int kind, int parts);
  * amax (MDNVAE_ABSMAX_SLOTS partial maxima of |w| as bit patterns) is read for parts = 2 only. */
 int mdnvae_cb_pack_weights(const float* w, int Cout, int Cin, int kind, int parts, const unsigned* amax,
                            void* packed, void* stream);
-int mdnvae_cb_conv(const void* act, long part_stride, const void* packed_w, const float* bias, float* out, int B,
-                   int Cout, int Cin, int kind, int rows, int pitch, int PP, int parts, float out_scale,
+int mdnvae_cb_conv(const void* act, long part_stride, const void* packed_w, const float* bias, void* out, int out16,
+                   int B, int Cout, int Cin, int kind, int rows, int pitch, int PP, int parts, float out_scale,
                    void* stream);
 /* stats[plane] = {mean, 1/sqrt(var + 1e-5)} (nn.InstanceNorm2d defaults) over the H x W valid entries of
  * planes stored with a row pitch (planes of at most 2048 positions). */
@@ -437,9 +439,13 @@ int mdnvae_cb_plane_stats(const float* y, long nplanes, int H, int W, int pitch,
 /* a = [relu]((y - mean) * rstd) (+ skip), function/VAE_CNN_NN.py:113-114,97: written as the next
  * convolution's operand (mode 0: reflected border of 1, pitch W + 2, for kind 0; mode 1: four parity
  * planes, pitch (W + 1) / 2 + 1, for kind 1; every one of the PP positions is written) and, when
- * stream_out is given, as fp32 planes [B][C][H * W] (the residual stream).  skip: [B][C][H * W]. */
-int mdnvae_cb_norm_fwd(const float* y, const float* stats, const float* skip, float* stream_out, void* act,
-                       long part_stride, int B, int C, int H, int W, int pitch_y, long Qy, int relu, int mode,
+ * stream_out is given, as fp32 planes [B][C][H * W] (the residual stream).  skip: [B][C][H * W].
+ * compute_stats = 1: stats [B * C][2] is an output - the pass stages its planes in LDS and takes
+ * {mean, rstd} from them first (planes of a multiple of 4 and at most 5000 positions);
+ * compute_stats = 0: stats is read (mdnvae_plane_stats / mdnvae_cb_plane_stats).
+ * y16 = 1 (here and in mdnvae_cb_norm_bwd): y holds fp16 planes (mdnvae_cb_conv with out16). */
+int mdnvae_cb_norm_fwd(const void* y, int y16, float* stats, int compute_stats, const float* skip, float* stream_out,
+                       void* act, long part_stride, int B, int C, int H, int W, int pitch_y, long Qy, int relu, int mode,
                        int PP, int parts, float scale, void* stream);
 /* Backward of the same pass, fused with what comes before it: the gradient w.r.t. the activation is
  * gathered from the consumer's data gradient (gmode 0: planes on this grid with pitch_g; 1: the
@@ -452,8 +458,8 @@ int mdnvae_cb_norm_fwd(const float* y, const float* stats, const float* skip, fl
  * for kind 3) or as fp32 planes [B][C][H * W] (omode 2).  gsum [B * C]: plane sums of dc (the
  * convolution-bias gradient before the sum over the batch). */
 int mdnvae_cb_norm_bwd(const float* g, int gmode, int pitch_g, long Qg, const float* base, float* sum_out,
-                       const float* y, const float* stats, int pitch_y, long Qy, int relu, int B, int C, int H, int W,
-                       int omode, void* dc, long part_stride, int PP, int parts, float scale, float* gsum,
+                       const void* y, int y16, const float* stats, int pitch_y, long Qy, int relu, int B, int C, int H,
+                       int W, int omode, void* dc, long part_stride, int PP, int parts, float scale, float* gsum,
                        void* stream);
 /* dW [Cout][Cin][3][3] from the channel-blocked output gradient g (as mdnvae_cb_norm_bwd leaves it) and the
  * layer's channel-blocked input.  planes = 1: stride-1 reflection layer (g: omode 0, act: mode 0, same

@@ -61,101 +61,119 @@ __device__ __forceinline__ void cb_wait_vm() {
 // NGP: group-planes per 16-channel chunk (2: k halves; 8: four parity planes x k halves).  NJ: 64-position blocks per
 // group-plane in the slab.  WGM x WGN waves of WM x WN 32x32 tiles.  TPS taps per stage, SPC stages per chunk.
 //
-// Pipeline: weights of stage s + 3 and (at the first stage of a chunk) the slab of the next chunk are issued right
-// after the barrier of stage s; the wait before each barrier is the wave's own counted vmcnt, so three weight stages
-// and one slab stay in flight across barriers.  Past the end the last stage / chunk is fetched again into buffers
-// nobody reads any more, which keeps the counts the same in every iteration.
-template <int PARTS, int NGP, int NJ, int WGM, int WGN, int WM, int WN, int TPS, int SPC>
-__global__ __launch_bounds__(512) void cb_conv_kernel(CbConv p) {
+// Pipeline.  Stage s = (chunk c, r) is TPS taps of one 16-channel chunk.  Weights of stage s + 4 and (at the end of
+// a chunk) the slab of chunk c + 2 are issued at the gate of stage s + 1, which stands in front of stage s's last
+// tap: at that point this wave's own pieces of stage s + 1 have landed (a counted vmcnt that leaves the two younger
+// weight stages, and a younger slab, in flight) and every LDS read of stage s is complete; the barrier makes both
+// true for all waves.  Fragments are read one tap ahead of the MFMAs that use them, across stage boundaries too.
+// Past the end the last stage / chunk is fetched again into buffers nobody reads any more, which keeps the counts
+// the same in every iteration.
+//
+// PERSIST: one workgroup per CU walks tiles blockIdx.x, + gridDim.x, ...: the first operands of the next tile are
+// requested before this tile's epilogue, and the epilogue's stores drain to memory under the next tile's MFMAs
+// (with one workgroup per CU and a grid of tiles, the matrix cores sat idle for the whole write-out: 28 % of the
+// kernel).  The epilogue then has an LDS region of its own behind the stage buffers.
+template <int PARTS, int NGP, int NJ, int WGM, int WGN, int WM, int WN, int TPS, int SPC, bool PERSIST, int NSW = 8, int NSB = 2, bool OUT16 = false>
+__global__ __launch_bounds__(512) void cb_conv_kernel(CbConv p, int nblk, int ntiles) {
     static_assert(WGM * WGN == 8 && WGM * WM * 32 == CB_ROWS, "eight waves cover 256 rows");
     constexpr int NT = WGN * WN;                              // 32-channel tiles per workgroup
     constexpr int WSTAGE = TPS * NT * PARTS * 1024;           // bytes of one weight stage
     constexpr int WPIECES = TPS * NT * PARTS;                 // 1 KiB pieces per weight stage
-    constexpr int WQ = WPIECES / 8, WREM = WPIECES % 8;
+    // NSW waves (0 .. NSW - 1) issue the LDS-DMA; with NSW = 4 the other four write the results out, so that no wave
+    // ever waits for its own stores when it waits for operands (one counter covers a wave's loads and stores, in order)
+    static_assert(NSW == 8 || NSW == 4, "all waves stage, or four stage and four store");
+    constexpr int WQ = WPIECES / NSW, WREM = WPIECES % NSW;
     constexpr int SLABPOS = NJ * 64;
     constexpr int SLABPART = NGP * SLABPOS * 16;              // bytes of one part of a slab
     constexpr int SLAB = PARTS * SLABPART;
     constexpr int SPIECES = PARTS * NGP * NJ;
-    static_assert(SPIECES % 8 == 0, "every wave stages the same number of slab pieces");
-    constexpr int SP = SPIECES / 8;
+    static_assert(SPIECES % NSW == 0, "every staging wave stages the same number of slab pieces");
+    constexpr int SP = SPIECES / NSW;
+    constexpr int MAIN = CB_NBUF * WSTAGE + NSB * SLAB;       // NSB slab buffers: chunks c .. c + NSB - 1 resident or in flight
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     char* wring = smem;                                       // [CB_NBUF][WSTAGE]
-    char* slabs = smem + CB_NBUF * WSTAGE;                    // [2][SLAB]
+    char* slabs = smem + CB_NBUF * WSTAGE;                    // [NSB][SLAB]
+    float* ep = reinterpret_cast<float*>(smem + (PERSIST ? MAIN : 0));     // epilogue transpose buffer
 
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = wid / WGN, wn = wid - wm * WGN;
     const int h = lane >> 5, l32 = lane & 31;
+    const int nstage = p.nchunk * SPC;
+    const long chunk_stride = (long)NGP * p.B * p.PP * 16;
+    const long Rend = (long)p.B * p.Qr;
 
-    // rows of this workgroup: flat over (sample, output row), a tile may end one sample and begin the next
-    const long R0 = (long)blockIdx.x * CB_ROWS;
-    const int s0 = (int)(R0 / p.Qr);
-    const int qa = (int)(R0 - (long)s0 * p.Qr);
-    const int n0 = min(CB_ROWS, p.Qr - qa);                   // rows of sample s0; the rest belong to s0 + 1
-    const int L0 = n0 + p.halo;                               // slab positions of the first segment
-    const int s1off = (s0 + 1 < p.B) ? p.PP : 0;              // where the second segment's positions come from
+    int taps[TPS * SPC];
+#pragma unroll
+    for (int t = 0; t < TPS * SPC; ++t) taps[t] = p.tap_lds[t];
 
-    // ---- staging plan of this wave ----
-    // slab piece u = wid + 8 i of a chunk: (64-position block j, part, group-plane) with the group-plane running fastest
+    // ---- per-tile state ----
+    struct Tile {
+        long R0;
+        int nb, s0, qa, n0;
+    };
+    auto tile_of = [&](int t) {
+        Tile T;
+        const int rt = t / nblk;
+        T.nb = t - rt * nblk;
+        T.R0 = (long)rt * CB_ROWS;
+        T.s0 = (int)(T.R0 / p.Qr);
+        T.qa = (int)(T.R0 - (long)T.s0 * p.Qr);
+        T.n0 = min(CB_ROWS, p.Qr - T.qa);                     // rows of sample s0; the rest belong to s0 + 1
+        return T;
+    };
+    // staging plan of this wave for a tile: slab piece u = wid + NSW i of a chunk is (64-position block j, part,
+    // group-plane), the group-plane running fastest
     long ssrc[SP];
     int sdst[SP];
+    int lane_addr[WM];
+    const char* wsrc;
+    auto plan = [&](const Tile& T) {
+        const int L0 = T.n0 + p.halo;                         // slab positions of the first segment
+        const int s1off = (T.s0 + 1 < p.B) ? p.PP : 0;        // where the second segment's positions come from
 #pragma unroll
-    for (int i = 0; i < SP; ++i) {
-        const int u = wid + 8 * i;
-        const int j = u / (PARTS * NGP), pg = u - j * (PARTS * NGP);
-        const int part = pg / NGP, gp = pg - part * NGP;
-        const int pos = j * 64 + lane;
-        int src = pos < L0 ? qa + pos : s1off + (pos - L0);
-        src = min(src, 2 * p.PP - 1);
-        ssrc[i] = part * p.part_stride + (((long)gp * p.B + s0) * p.PP + src) * 16;
-        sdst[i] = part * SLABPART + (gp * SLABPOS + j * 64) * 16;
-    }
-    const long chunk_stride = (long)NGP * p.B * p.PP * 16;
+        for (int i = 0; i < SP; ++i) {
+            const int u = (wid & (NSW - 1)) + NSW * i;
+            const int j = u / (PARTS * NGP), pg = u - j * (PARTS * NGP);
+            const int part = pg / NGP, gp = pg - part * NGP;
+            const int pos = j * 64 + lane;
+            int src = pos < L0 ? T.qa + pos : s1off + (pos - L0);
+            src = min(src, 2 * p.PP - 1);
+            ssrc[i] = part * p.part_stride + (((long)gp * p.B + T.s0) * p.PP + src) * 16;
+            sdst[i] = part * SLABPART + (gp * SLABPOS + j * 64) * 16;
+        }
+#pragma unroll
+        for (int m = 0; m < WM; ++m) {
+            const int i = (wm * WM + m) * 32 + l32;
+            lane_addr[m] = (h * SLABPOS + (i < T.n0 ? i : L0 + (i - T.n0))) * 16;
+        }
+        wsrc = p.w + (long)T.nb * nstage * WSTAGE + lane * 16;
+    };
     auto stage_slab = [&](int c, int buf) {
+        if (NSW < 8 && wid >= NSW) return;
 #pragma unroll
         for (int i = 0; i < SP; ++i)
             __builtin_amdgcn_global_load_lds(CB_GLOBAL_PTR(p.act + ssrc[i] + c * chunk_stride),
                                              CB_LDS_PTR(slabs + buf * SLAB + sdst[i]), 16, 0, 0);
     };
-    const int nstage = p.nchunk * SPC;
-    const char* wsrc = p.w + (long)blockIdx.y * nstage * WSTAGE + lane * 16;
     auto stage_w = [&](int s, int buf) {
+        if (NSW < 8 && wid >= NSW) return;
 #pragma unroll
         for (int i = 0; i < WQ + (WREM ? 1 : 0); ++i) {
             if (i < WQ || wid < WREM) {
-                const int q = wid + 8 * i;
+                const int q = wid + NSW * i;
                 __builtin_amdgcn_global_load_lds(CB_GLOBAL_PTR(wsrc + (long)s * WSTAGE + q * 1024),
                                                  CB_LDS_PTR(wring + buf * WSTAGE + q * 1024), 16, 0, 0);
             }
         }
     };
-
-    // per-lane slab address of each row tile (k half folded in)
-    int lane_addr[WM];
+    // first requests of a tile: slab of chunk 0, weights of stages 0..2
+    auto prologue = [&]() {
+        stage_slab(0, 0);
+        if (NSB == 3) stage_slab(min(1, p.nchunk - 1), 1);
 #pragma unroll
-    for (int m = 0; m < WM; ++m) {
-        const int i = (wm * WM + m) * 32 + l32;
-        lane_addr[m] = (h * SLABPOS + (i < n0 ? i : L0 + (i - n0))) * 16;
-    }
-    int taps[TPS * SPC];
-#pragma unroll
-    for (int t = 0; t < TPS * SPC; ++t) taps[t] = p.tap_lds[t];
-
-    // biases of this lane's output channels (loaded now, long landed by the epilogue)
-    float bv[WN];
-#pragma unroll
-    for (int n = 0; n < WN; ++n) {
-        const int ch = (blockIdx.y * NT + wn * WN + n) * 32 + l32;
-        bv[n] = (p.bias && ch < p.ntot) ? p.bias[ch] : 0.0f;
-    }
-
-    cb_acc16 acc[WM][WN];
-#pragma unroll
-    for (int m = 0; m < WM; ++m)
-#pragma unroll
-        for (int n = 0; n < WN; ++n)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[m][n][e] = 0.0f;
+        for (int s = 0; s < CB_NBUF - 1; ++s) stage_w(min(s, nstage - 1), s);
+    };
 
     auto mfma = [](const cb_bf8& a, const cb_bf8& b, const cb_acc16& c) {
         if constexpr (PARTS == 2)
@@ -163,86 +181,185 @@ __global__ __launch_bounds__(512) void cb_conv_kernel(CbConv p) {
         else
             return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
     };
-
-    // one stage: TPS taps of one chunk
-    auto compute = [&](int r, const char* wb, const char* sl) {
-        cb_bf8 A[2][PARTS][WM], Bv[2][PARTS][WN];
-        auto load_tap = [&](int tt, int slot) {
+    cb_acc16 acc[WM][WN];
+    // Fragments of one tap: A from the slab at the tap's offset, B from the stage's weight buffer.
+    struct Frags {
+        cb_bf8 a[PARTS][WM], b[PARTS][WN];
+    };
+    auto load_tap = [&](Frags& f, const char* wb, const char* sl, int tap_in_chunk, int tt) {
 #pragma unroll
-            for (int pt = 0; pt < PARTS; ++pt) {
+        for (int pt = 0; pt < PARTS; ++pt) {
 #pragma unroll
-                for (int n = 0; n < WN; ++n)
-                    Bv[slot][pt][n] = *reinterpret_cast<const cb_bf8*>(wb + ((tt * NT + wn * WN + n) * PARTS + pt) * 1024 + lane * 16);
-#pragma unroll
-                for (int m = 0; m < WM; ++m)
-                    A[slot][pt][m] = *reinterpret_cast<const cb_bf8*>(sl + pt * SLABPART + lane_addr[m] + taps[r * TPS + tt]);
-            }
-        };
-        load_tap(0, 0);
-#pragma unroll
-        for (int tt = 0; tt < TPS; ++tt) {
-            if (tt + 1 < TPS) load_tap(tt + 1, (tt + 1) & 1);
-            __builtin_amdgcn_sched_barrier(0);
+            for (int n = 0; n < WN; ++n)
+                f.b[pt][n] = *reinterpret_cast<const cb_bf8*>(wb + ((tt * NT + wn * WN + n) * PARTS + pt) * 1024 + lane * 16);
 #pragma unroll
             for (int m = 0; m < WM; ++m)
-#pragma unroll
-                for (int n = 0; n < WN; ++n) {
-                    if constexpr (PARTS == 2) {
-                        acc[m][n] = mfma(A[tt & 1][0][m], Bv[tt & 1][1][n], acc[m][n]);
-                        acc[m][n] = mfma(A[tt & 1][1][m], Bv[tt & 1][0][n], acc[m][n]);
-                    }
-                    acc[m][n] = mfma(A[tt & 1][0][m], Bv[tt & 1][0][n], acc[m][n]);
-                }
-            __builtin_amdgcn_sched_barrier(0);
+                f.a[pt][m] = *reinterpret_cast<const cb_bf8*>(sl + pt * SLABPART + lane_addr[m] + taps[tap_in_chunk]);
         }
     };
-
-    // prologue: slab of chunk 0, weights of stages 0..2
-    stage_slab(0, 0);
+    auto mma_tap = [&](const Frags& f) {
 #pragma unroll
-    for (int s = 0; s < CB_NBUF - 1; ++s) stage_w(min(s, nstage - 1), s);
-
-    int s = 0;
-    for (int c = 0; c < p.nchunk; ++c) {
+        for (int m = 0; m < WM; ++m)
 #pragma unroll
-        for (int r = 0; r < SPC; ++r, ++s) {
-            // all but the two youngest weight stages (and, at r = 1, 2, the slab issued at r = 0) have landed
-            const bool slab_young = (r == 1 || r == 2);
-            if (WREM && wid < WREM) {
-                if (slab_young) cb_wait_vm<2 * (WQ + 1) + SP>(); else cb_wait_vm<2 * (WQ + 1)>();
-            } else {
-                if (slab_young) cb_wait_vm<2 * WQ + SP>(); else cb_wait_vm<2 * WQ>();
+            for (int n = 0; n < WN; ++n) {
+                if constexpr (PARTS == 2) {
+                    acc[m][n] = mfma(f.a[0][m], f.b[1][n], acc[m][n]);
+                    acc[m][n] = mfma(f.a[1][m], f.b[0][n], acc[m][n]);
+                }
+                acc[m][n] = mfma(f.a[0][m], f.b[0][n], acc[m][n]);
             }
-            __builtin_amdgcn_s_barrier();
-            if (r == 0) stage_slab(min(c + 1, p.nchunk - 1), (c + 1) & 1);
-            stage_w(min(s + CB_NBUF - 1, nstage - 1), (s + CB_NBUF - 1) % CB_NBUF);
-            compute(r, wring + (s % CB_NBUF) * WSTAGE, slabs + (c & 1) * SLAB);
+    };
+    // gate of a stage whose position in its chunk is r (see the head comment)
+    auto gate = [&](int r) {
+        const bool slab_young = (r == 1 || r == 2);
+        if (NSW < 8 && wid >= NSW) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        } else if (WREM && wid < WREM) {
+            if (slab_young) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * (WQ + 1) + SP) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * (WQ + 1)) : "memory");
+        } else {
+            if (slab_young) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * WQ + SP) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * WQ) : "memory");
         }
-    }
-    cb_wait_vm<0>();                                          // nothing in flight when the LDS goes back
+        __builtin_amdgcn_s_barrier();
+    };
 
-    // epilogue: accumulator registers 4g..4g+3 of a tile are rows 8g + 4h .. + 3 of column l32
-    const long Rend = (long)p.B * p.Qr;
+    // biases of this lane's output channels.  Loaded once where every tile has the same channels (one block of output
+    // channels): an ordinary load inside the tile loop makes the compiler wait for ALL of the wave's memory operations
+    // where its value is first used, the stores of the previous tile included.
+    float bv[WN];
+    auto load_bias = [&](int nb) {
 #pragma unroll
-    for (int n = 0; n < WN; ++n) {
-        const int ch = (blockIdx.y * NT + wn * WN + n) * 32 + l32;
-        if (ch >= p.ntot) continue;
+        for (int n = 0; n < WN; ++n) {
+            const int ch = (nb * NT + wn * WN + n) * 32 + l32;
+            bv[n] = (p.bias && ch < p.ntot) ? p.bias[ch] : 0.0f;
+        }
 #pragma unroll
-        for (int m = 0; m < WM; ++m) {
+        for (int n = 0; n < WN; ++n) asm volatile("" : "+v"(bv[n]));
+    };
+    int tile = blockIdx.x;
+    Tile T = tile_of(tile);
+    load_bias(T.nb);
+    plan(T);
+    prologue();
+    while (true) {
+        if (nblk > 1) load_bias(T.nb);
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int i = (wm * WM + m) * 32 + 8 * g + 4 * h;
-                if (R0 + i >= Rend) continue;
-                const int sg = i >= n0;
-                const int q = sg ? i - n0 : qa + i;
-                cb_f4 o;
-                o.x = acc[m][n][4 * g] * p.out_scale + bv[n];
-                o.y = acc[m][n][4 * g + 1] * p.out_scale + bv[n];
-                o.z = acc[m][n][4 * g + 2] * p.out_scale + bv[n];
-                o.w = acc[m][n][4 * g + 3] * p.out_scale + bv[n];
-                *reinterpret_cast<cb_f4*>(p.out + ((long)(s0 + sg) * p.ntot + ch) * p.Qr + q) = o;
+        for (int m = 0; m < WM; ++m)
+#pragma unroll
+            for (int n = 0; n < WN; ++n)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[m][n][e] = 0.0f;
+
+        gate(0);
+        stage_slab(min(NSB - 1, p.nchunk - 1), NSB - 1);
+        stage_w(min(CB_NBUF - 1, nstage - 1), CB_NBUF - 1);
+        Frags cur, nxt;
+        load_tap(cur, wring, slabs, 0, 0);
+        int s = 0;
+        for (int c = 0; c < p.nchunk; ++c) {
+#pragma unroll
+            for (int r = 0; r < SPC; ++r, ++s) {
+                const char* wb = wring + (s % CB_NBUF) * WSTAGE;
+                const char* sl = slabs + (c % NSB) * SLAB;
+#pragma unroll
+                for (int tt = 0; tt + 1 < TPS; ++tt) {
+                    load_tap(nxt, wb, sl, r * TPS + tt + 1, tt + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mma_tap(cur);
+                    __builtin_amdgcn_sched_barrier(0);
+                    cur = nxt;
+                }
+                const int r1 = (r + 1) % SPC;
+                gate(r1);
+                if (r1 == 0) stage_slab(min(c + NSB, p.nchunk - 1), c % NSB);
+                stage_w(min(s + CB_NBUF, nstage - 1), s % CB_NBUF);
+                if (s + 1 < nstage)
+                    load_tap(nxt, wring + ((s + 1) % CB_NBUF) * WSTAGE, slabs + ((r1 == 0 ? c + 1 : c) % NSB) * SLAB, r1 * TPS, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                mma_tap(cur);
+                __builtin_amdgcn_sched_barrier(0);
+                cur = nxt;
             }
         }
+        if (NSW == 8 || wid < NSW) cb_wait_vm<0>();            // the refetched last stages: nothing may land later
+        __builtin_amdgcn_s_barrier();                          // every wave is done with the stage buffers and slabs
+        // the next tile's first operands are requested now and arrive under this tile's epilogue
+        const Tile Tc = T;
+        const int next = tile + gridDim.x;
+        const bool more = PERSIST && next < ntiles;
+        if (more) {
+            T = tile_of(next);
+            plan(T);
+            prologue();
+        }
+        // Epilogue.  Accumulator registers 4g..4g+3 of a 32 x 32 tile are rows 8g + 4h .. + 3 of column l32: a lane holds
+        // 16 rows of ONE channel, and the output is channel-major planes, so the tiles cross through LDS, [channel][row],
+        // and leave as runs of 128 consecutive rows of a channel (runs of 32 rows, which a pass per tile row would give,
+        // cost a quarter of the kernel: every run ends in partially written lines).  One pass per (tile column n, half
+        // of the rows): WGN * 32 channels x 128 rows, written by the waves that own those rows.
+        {
+            constexpr int ROWS_P = 128, ROWP = ROWS_P + 4;         // row pitch = 4 mod 32: a store group's 8 lanes hit different banks
+            constexpr int RPL = OUT16 ? 8 : 4;                     // rows per lane in the read-back (16 bytes of output)
+            constexpr int LPC = ROWS_P / RPL;                      // lanes per channel in the read-back
+            constexpr int CPI = 64 / LPC;                          // channels per read-back instruction
+            constexpr int NSTW = NSW == 8 ? 8 : 4;                 // waves that write out (the last NSTW)
+            constexpr int NI = WGN * 32 / (NSTW * CPI);            // read-back instructions per storing wave and pass
+            static_assert(NI >= 1 && NI * NSTW * CPI == WGN * 32, "the storing waves cover a pass exactly");
+            constexpr int WROWS = WM * 32;                         // rows of a wave
+            const int swid = wid - (8 - NSTW);                     // < 0: this wave does not store
+            const int rp = (lane % LPC) * RPL;                     // row within the pass
+#pragma unroll
+            for (int n = 0; n < WN; ++n)
+#pragma unroll
+                for (int hr = 0; hr < CB_ROWS / ROWS_P; ++hr) {
+                    if ((wm * WROWS) / ROWS_P == hr) {
+#pragma unroll
+                        for (int m = 0; m < WM; ++m)
+#pragma unroll
+                            for (int g = 0; g < 4; ++g) {
+                                cb_f4 o;
+                                o.x = acc[m][n][4 * g] * p.out_scale + bv[n];
+                                o.y = acc[m][n][4 * g + 1] * p.out_scale + bv[n];
+                                o.z = acc[m][n][4 * g + 2] * p.out_scale + bv[n];
+                                o.w = acc[m][n][4 * g + 3] * p.out_scale + bv[n];
+                                *reinterpret_cast<cb_f4*>(ep + (wn * 32 + l32) * ROWP + (wm * WROWS) % ROWS_P + m * 32 + 8 * g + 4 * h) = o;
+                            }
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    const int i = hr * ROWS_P + rp;                // row of the 256-row tile
+                    const int sg = i >= Tc.n0;
+                    const int q = sg ? i - Tc.n0 : Tc.qa + i;
+                    const bool row_ok = Tc.R0 + i < Rend;
+#pragma unroll
+                    for (int k = 0; k < NI; ++k) {
+                        if (swid < 0) break;
+                        const int chl = (swid * NI + k) * CPI + lane / LPC;
+                        const int ch = (Tc.nb * NT + (chl >> 5) * WN + n) * 32 + (chl & 31);
+                        const long at = ((long)(Tc.s0 + sg) * p.ntot + ch) * p.Qr + q;
+                        const bool live = ch < p.ntot && row_ok;
+                        const cb_f4 v = *reinterpret_cast<const cb_f4*>(ep + chl * ROWP + rp);
+                        if constexpr (OUT16) {
+                            // fp16 output: 11 significant bits, clamped to the finite range
+                            const cb_f4 v2 = *reinterpret_cast<const cb_f4*>(ep + chl * ROWP + rp + 4);
+                            cb_h8 o;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                o[e] = (_Float16)fminf(fmaxf(v[e], -65504.0f), 65504.0f);
+                                o[4 + e] = (_Float16)fminf(fmaxf(v2[e], -65504.0f), 65504.0f);
+                            }
+                            if (live) *reinterpret_cast<cb_h8*>(reinterpret_cast<_Float16*>(p.out) + at) = o;
+                        } else {
+                            if (live) *reinterpret_cast<cb_f4*>(p.out + at) = v;
+                        }
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                }
+        }
+        if (!more) break;
+        tile = next;
     }
 }
 
@@ -366,7 +483,7 @@ __device__ __forceinline__ void cb_store8(const float (&v)[8], float scale, char
 }
 
 struct CbNormFwd {
-    const float* y;          // raw conv output [B][C][Qy], pitched rows
+    const void* y;           // raw conv output [B][C][Qy], pitched rows (fp32, or fp16 for the kernels that stage it in LDS)
     const float* stats;      // [B * C][2]
     const float* skip;       // residual stream [B][C][H * W] or null
     float* stream_out;       // skip + norm(y), [B][C][H * W], or null
@@ -393,7 +510,7 @@ __global__ __launch_bounds__(256) void cb_norm_fwd_kernel(CbNormFwd p) {
         const long pl = (long)b * p.C + g8 * 8 + e;
         mean[e] = p.stats[2 * pl];
         rstd[e] = p.stats[2 * pl + 1];
-        yp[e] = p.y + pl * p.Qy;
+        yp[e] = static_cast<const float*>(p.y) + pl * p.Qy;
     }
     const unsigned mop = (unsigned)(0x100000000ull / (unsigned)p.opitch) + 1u;
     const int nplanes = p.mode == 1 ? 4 : 1;
@@ -447,7 +564,7 @@ struct CbNormBwd {
     int pitch_g; long Qg;
     const float* base;       // [B][C][H * W] added to the gradient (the residual stream's gradient), or null
     float* sum_out;          // [B][C][H * W]: base + gradient, or null
-    const float* y;          // raw conv output of this layer [B][C][Qy]
+    const void* y;           // raw conv output of this layer [B][C][Qy] (fp32, or fp16 for the kernels that stage it in LDS)
     const float* stats;
     int pitch_y; long Qy;
     int relu;
@@ -521,7 +638,7 @@ __global__ __launch_bounds__(256) void cb_norm_bwd_kernel(CbNormBwd p) {
                     gv = p.g[((long)b * 4 * p.C + ((r & 1) * 2 + (c & 1)) * p.C + cg * CH + e) * p.Qg + (r >> 1) * p.pitch_g + (c >> 1)];
                 if (p.base) gv += p.base[pl * HW + r * p.W + c];
                 if (p.sum_out) p.sum_out[pl * HW + r * p.W + c] = gv;
-                const float x = (p.y[pl * p.Qy + r * p.pitch_y + c] - mean[e]) * rstd[e];
+                const float x = (static_cast<const float*>(p.y)[pl * p.Qy + r * p.pitch_y + c] - mean[e]) * rstd[e];
                 if (p.relu && !(x > 0.0f)) gv = 0.0f;
                 dn[i][e] = gv;
                 xh[i][e] = x;
@@ -597,6 +714,284 @@ __global__ __launch_bounds__(256) void cb_norm_bwd_kernel(CbNormBwd p) {
     }
 }
 
+
+// ---- the same two passes with their input planes staged in LDS -------------------------------
+// The 8 planes a workgroup needs of a tensor [B][C][Q] are one contiguous run of 8 Q floats: they are copied into LDS
+// by 16-byte LDS-DMA and every gather (reflection, parity planes, fold) becomes an LDS read.  The forward pass also
+// takes the instance-norm statistics from the staged planes (mean first, then squared deviations), so the raw
+// convolution output is read from memory once.
+
+// nbytes (multiple of 16, 16-byte aligned source) -> LDS, all NT threads
+template <int NT>
+__device__ __forceinline__ void cb_dma_bytes(const char* __restrict__ src, char* dst, int nbytes) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int base = 0; base < nbytes; base += NT * 16) {
+        const int e = base + wave * 1024 + lane * 16;
+        if (e < nbytes)
+            __builtin_amdgcn_global_load_lds(CB_GLOBAL_PTR(src + e), CB_LDS_PTR(dst + base + wave * 1024), 16, 0, 0);
+    }
+}
+template <int NT>
+__device__ __forceinline__ void cb_dma_floats(const float* __restrict__ src, float* dst, int n) {
+    cb_dma_bytes<NT>(reinterpret_cast<const char*>(src), reinterpret_cast<char*>(dst), n * 4);
+}
+
+// sums of 8 values over the workgroup (NT / 64 waves, in wave order), result in every thread; red: [NT / 64][8] floats
+template <int NT>
+__device__ __forceinline__ void cb_block_sum8(float (&v)[8], float* red) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = wave_sum_all(v[e]);
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[wave * 8 + e] = v[e];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        float t = 0.0f;
+#pragma unroll
+        for (int w = 0; w < NT / 64; ++w) t += red[w * 8 + e];
+        v[e] = t;
+    }
+}
+
+template <int PARTS, int MODE, typename YT>
+__global__ __launch_bounds__(256) void cb_norm_fwd_lds_kernel(CbNormFwd p, float* __restrict__ stats_out) {
+    extern __shared__ __attribute__((aligned(16))) float fsm[];
+    float* red = fsm;                    // [64]
+    YT* ybuf = reinterpret_cast<YT*>(fsm + 64);      // [8][Qy]
+    const int g8 = blockIdx.x, b = blockIdx.y;
+    const int HW = p.H * p.W;
+    const long pl0 = (long)b * p.C + g8 * 8;
+    cb_dma_bytes<256>(reinterpret_cast<const char*>(static_cast<const YT*>(p.y) + pl0 * p.Qy), reinterpret_cast<char*>(ybuf),
+                      8 * p.Qy * (int)sizeof(YT));
+    const unsigned mpy = (unsigned)(0x100000000ull / (unsigned)p.pitch_y) + 1u;
+    const unsigned mop = (unsigned)(0x100000000ull / (unsigned)p.opitch) + 1u;
+    cb_wait_vm<0>();
+    __syncthreads();
+    // statistics over the valid entries of the pitched planes
+    const int Qv = p.H * p.pitch_y;
+    float mean[8], rstd[8];
+    {
+        float s[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s[e] = 0.0f;
+        for (int i = threadIdx.x; i < Qv; i += 256) {
+            const int r = (int)__umulhi((unsigned)i, mpy), c = i - r * p.pitch_y;
+            if (c < p.W) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s[e] += (float)ybuf[e * p.Qy + i];
+            }
+        }
+        cb_block_sum8<256>(s, red);
+        const float inv = 1.0f / (float)HW;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) mean[e] = s[e] * inv;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s[e] = 0.0f;
+        for (int i = threadIdx.x; i < Qv; i += 256) {
+            const int r = (int)__umulhi((unsigned)i, mpy), c = i - r * p.pitch_y;
+            if (c < p.W) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float d = (float)ybuf[e * p.Qy + i] - mean[e];
+                    s[e] += d * d;
+                }
+            }
+        }
+        cb_block_sum8<256>(s, red);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) rstd[e] = 1.0f / sqrtf(s[e] * inv + CB_IN_EPS);
+        if (threadIdx.x < 8) {
+            const int e = threadIdx.x;
+            float m = mean[0], r = rstd[0];
+#pragma unroll
+            for (int k = 1; k < 8; ++k) {
+                m = e == k ? mean[k] : m;
+                r = e == k ? rstd[k] : r;
+            }
+            stats_out[2 * (pl0 + e)] = m;
+            stats_out[2 * (pl0 + e) + 1] = r;
+        }
+    }
+    constexpr int NPL = MODE == 1 ? 4 : 1;
+#pragma unroll
+    for (int plane = 0; plane < NPL; ++plane) {
+        const long gp = MODE == 1 ? (long)(g8 >> 1) * 8 + plane * 2 + (g8 & 1) : g8;
+        char* dst = p.act ? p.act + ((gp * p.B + b) * p.PP) * 16 : nullptr;
+        for (int pos = threadIdx.x; pos < p.PP; pos += 256) {
+            const int pr = (int)__umulhi((unsigned)pos, mop), pc = pos - pr * p.opitch;
+            int r, c;
+            bool ok, interior = false;
+            if (MODE == 0) {
+                r = pr - 1; c = pc - 1;
+                ok = pr < p.H + 2 && pc < p.W + 2;
+                interior = ok && r >= 0 && r < p.H && c >= 0 && c < p.W;
+                r = r < 0 ? -r : (r >= p.H ? 2 * (p.H - 1) - r : r);
+                c = c < 0 ? -c : (c >= p.W ? 2 * (p.W - 1) - c : c);
+            } else {
+                r = 2 * (pr - 1) + (plane >> 1); c = 2 * (pc - 1) + (plane & 1);
+                ok = pr >= 1 && pc >= 1 && r < p.H && c < p.W;
+            }
+            const int src = ok ? r * p.pitch_y + c : 0;
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float t = ((float)ybuf[e * p.Qy + src] - mean[e]) * rstd[e];
+                if (p.relu) t = fmaxf(t, 0.0f);
+                v[e] = ok ? t : 0.0f;
+            }
+            if (MODE == 0 && p.skip && ok) {
+                const float* sk = p.skip + pl0 * HW + r * p.W + c;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += sk[(long)e * HW];
+            }
+            if (MODE == 0 && p.stream_out && interior) {
+                float* so = p.stream_out + pl0 * HW + r * p.W + c;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) so[(long)e * HW] = v[e];
+            }
+            if (dst) cb_store8<PARTS>(v, p.scale, dst + (long)pos * 16, p.part_stride);
+        }
+    }
+}
+
+// GMODE / OMODE as in CbNormBwd (OMODE 0 or 1: channel-blocked output, 8 channels per workgroup); BASE: p.base is given
+// (its sum with the gathered gradient can be written to p.sum_out).  NT threads own NPOS output positions each.
+template <int PARTS, int GMODE, int OMODE, bool BASE, int NT, int NPOS, typename YT>
+__global__ __launch_bounds__(NT) void cb_norm_bwd_lds_kernel(CbNormBwd p) {
+    extern __shared__ __attribute__((aligned(16))) float fsm[];
+    float* red = fsm;                                  // [64]
+    YT* ybuf = reinterpret_cast<YT*>(fsm + 64);        // [8][Qy]
+    const int Qy = (int)p.Qy, Qg = (int)p.Qg;
+    float* gbuf = fsm + 64 + 8 * Qy * (int)sizeof(YT) / 4;    // GMODE 0, 1: [8][Qg] and one zero;  2: [4][8][Qg]
+    const int g8 = blockIdx.x, b = blockIdx.y;
+    const int HW = p.H * p.W;
+    const long pl0 = (long)b * p.C + g8 * 8;
+    cb_dma_bytes<NT>(reinterpret_cast<const char*>(static_cast<const YT*>(p.y) + pl0 * Qy), reinterpret_cast<char*>(ybuf),
+                     8 * Qy * (int)sizeof(YT));
+    if (GMODE == 2) {
+#pragma unroll
+        for (int pl = 0; pl < 4; ++pl)
+            cb_dma_floats<NT>(p.g + (((long)b * 4 + pl) * p.C + g8 * 8) * Qg, gbuf + pl * 8 * Qg, 8 * Qg);
+    } else if (GMODE != 3) {
+        cb_dma_floats<NT>(p.g + pl0 * Qg, gbuf, 8 * Qg);
+    }
+    const int zero_at = 8 * Qg;                        // GMODE 1: where absent fold terms read
+    if (GMODE == 1 && threadIdx.x == 0) gbuf[zero_at] = 0.0f;
+    const unsigned mop = (unsigned)(0x100000000ull / (unsigned)p.opitch) + 1u;
+    float mean[8], rstd[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        mean[e] = p.stats[2 * (pl0 + e)];
+        rstd[e] = p.stats[2 * (pl0 + e) + 1];
+    }
+    // this thread's positions: source offsets first (no memory traffic), then everything comes from LDS
+    constexpr int NG = GMODE == 1 ? 4 : 1;
+    int ysrc[NPOS], gsrc[NPOS][NG], bsrc[NPOS];
+#pragma unroll
+    for (int i = 0; i < NPOS; ++i) {
+        const int pos = threadIdx.x + NT * i;
+        const int pr = (int)__umulhi((unsigned)pos, mop), pc = pos - pr * p.opitch;
+        const int r = OMODE == 0 ? pr - 2 : pr, c = OMODE == 0 ? pc - 2 : pc;
+        const bool ok = pos < p.PP && r >= 0 && r < p.H && c >= 0 && c < p.W;
+        ysrc[i] = ok ? r * p.pitch_y + c : -1;
+        bsrc[i] = ok ? r * p.W + c : 0;
+#pragma unroll
+        for (int k = 0; k < NG; ++k) gsrc[i][k] = -1;
+        if (GMODE == 0) {
+            gsrc[i][0] = ok ? r * p.pitch_g + c : 0;
+        } else if (GMODE == 1) {
+            // padded position (r + 1, c + 1) plus the mirrored border rows / columns that reflect onto (r, c)
+            const int Wp = p.pitch_g;
+            const int r1 = (r == 1) ? 0 : ((r == p.H - 2) ? p.H + 1 : -1);
+            const int c1 = (c == 1) ? 0 : ((c == p.W - 2) ? p.W + 1 : -1);
+            gsrc[i][0] = ok ? (r + 1) * Wp + c + 1 : -1;
+            if (ok && r1 >= 0) gsrc[i][1] = r1 * Wp + c + 1;
+            if (ok && c1 >= 0) gsrc[i][NG > 2 ? 2 : 0] = (r + 1) * Wp + c1;
+            if (ok && r1 >= 0 && c1 >= 0) gsrc[i][NG > 3 ? 3 : 0] = r1 * Wp + c1;
+        } else if (GMODE == 2) {
+            gsrc[i][0] = ok ? ((r & 1) * 2 + (c & 1)) * 8 * Qg + (r >> 1) * p.pitch_g + (c >> 1) : 0;
+        }
+    }
+    float bv[BASE ? NPOS : 1][8];
+    if (BASE) {
+#pragma unroll
+        for (int i = 0; i < NPOS; ++i)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bv[BASE ? i : 0][e] = p.base[(pl0 + e) * HW + bsrc[i]];
+    }
+    cb_wait_vm<0>();
+    __syncthreads();
+    float dn[NPOS][8], xh[NPOS][8];
+    float s1[8], s2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NPOS; ++i) {
+        const bool ok = ysrc[i] >= 0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float gv = 0.0f;
+            if (GMODE == 1) {
+                float t[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) t[k] = gbuf[gsrc[i][k % NG] >= 0 ? e * Qg + gsrc[i][k % NG] : zero_at];
+                gv = (t[0] + t[1]) + (t[2] + t[3]);
+            } else if (GMODE != 3) {
+                gv = gbuf[e * Qg + gsrc[i][0]];
+            }
+            if (BASE) gv += bv[BASE ? i : 0][e];
+            gv = ok ? gv : 0.0f;
+            const float x = ok ? ((float)ybuf[e * Qy + (ok ? ysrc[i] : 0)] - mean[e]) * rstd[e] : 0.0f;
+            if (BASE) bv[BASE ? i : 0][e] = gv;          // base + gradient, before the mask
+            if (p.relu && !(x > 0.0f)) gv = 0.0f;
+            dn[i][e] = gv;
+            xh[i][e] = x;
+            s1[e] += gv;
+            s2[e] += gv * x;
+        }
+    }
+    if (BASE && p.sum_out) {
+#pragma unroll
+        for (int i = 0; i < NPOS; ++i)
+            if (ysrc[i] >= 0) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) p.sum_out[(pl0 + e) * HW + bsrc[i]] = bv[BASE ? i : 0][e];
+            }
+    }
+    cb_block_sum8<NT>(s1, red);
+    cb_block_sum8<NT>(s2, red);
+    const float inv = 1.0f / (float)HW;
+    float gs[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) gs[e] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NPOS; ++i) {
+        const int pos = threadIdx.x + NT * i;
+        if (pos >= p.PP) continue;
+        const bool ok = ysrc[i] >= 0;
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            o[e] = ok ? rstd[e] * (dn[i][e] - s1[e] * inv - xh[i][e] * (s2[e] * inv)) : 0.0f;
+            gs[e] += o[e];
+        }
+        cb_store8<PARTS>(o, p.scale, p.dc + (((long)g8 * p.B + b) * p.PP + pos) * 16, p.part_stride);
+    }
+    if (p.gsum) {
+        cb_block_sum8<NT>(gs, red);
+        if (threadIdx.x < 8) {
+            const int e = threadIdx.x;
+            float v = gs[0];
+#pragma unroll
+            for (int k = 1; k < 8; ++k) v = e == k ? gs[k] : v;
+            p.gsum[pl0 + e] = v;
+        }
+    }
+}
 
 // ---------------------------------------------------------------------------------------
 // weight gradient
@@ -805,16 +1200,25 @@ static bool cb_shape(int kind, int Cout, int Cin, CbShape& sh) {
     return false;
 }
 
-template <int PARTS, int NGP, int NJ, int WGM, int WGN, int WM, int WN, int TPS, int SPC>
+template <int PARTS, int NGP, int NJ, int WGM, int WGN, int WM, int WN, int TPS, int SPC, bool PERSIST, int NSW = 8, int NSB = 2, bool OUT16 = false>
 static int cb_launch_conv(const CbConv& a, int nblk, hipStream_t st) {
     constexpr int NT = WGN * WN;
-    constexpr size_t lds = (size_t)CB_NBUF * TPS * NT * PARTS * 1024 + (size_t)2 * PARTS * NGP * NJ * 64 * 16;
-    static_assert(lds <= 160 * 1024, "stage ring + two slabs must fit the LDS");
-    auto kern = cb_conv_kernel<PARTS, NGP, NJ, WGM, WGN, WM, WN, TPS, SPC>;
+    constexpr size_t lds_main = (size_t)CB_NBUF * TPS * NT * PARTS * 1024 + (size_t)NSB * PARTS * NGP * NJ * 64 * 16;
+    constexpr size_t lds_epi = (size_t)WGN * 32 * (128 + 4) * 4;                // the epilogue's transpose buffer
+    constexpr size_t lds = PERSIST ? lds_main + lds_epi : (lds_main > lds_epi ? lds_main : lds_epi);
+    static_assert(lds <= 160 * 1024, "stage ring + two slabs (+ the epilogue buffer) must fit the LDS");
+    auto kern = cb_conv_kernel<PARTS, NGP, NJ, WGM, WGN, WM, WN, TPS, SPC, PERSIST, NSW, NSB, OUT16>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const long rows = (long)a.B * a.Qr;
-    dim3 grid((unsigned)((rows + CB_ROWS - 1) / CB_ROWS), nblk, 1);
-    hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, a);
+    const int ntiles = (int)((rows + CB_ROWS - 1) / CB_ROWS) * nblk;
+    int grid = ntiles;
+    if (PERSIST) {
+        int dev = 0, cus = 256;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (grid > cus) grid = cus;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, a, nblk, ntiles);
     MV_LAUNCH_CHECK("cb_conv_kernel");
     return 0;
 }
@@ -872,8 +1276,8 @@ int mdnvae_cb_pack_weights(const float* w, int Cout, int Cin, int kind, int part
     return 0;
 }
 
-int mdnvae_cb_conv(const void* act, long part_stride, const void* packed_w, const float* bias, float* out, int B, int Cout,
-                   int Cin, int kind, int rows, int pitch, int PP, int parts, float out_scale, void* stream) {
+int mdnvae_cb_conv(const void* act, long part_stride, const void* packed_w, const float* bias, void* out, int out16, int B,
+                   int Cout, int Cin, int kind, int rows, int pitch, int PP, int parts, float out_scale, void* stream) {
     MV_REQUIRE(B >= 0, E_ARG, "mdnvae_cb_conv: negative batch");
     if (B == 0) return 0;
     MV_REQUIRE(act && packed_w && out, E_ARG, "mdnvae_cb_conv: null pointer");
@@ -887,11 +1291,12 @@ int mdnvae_cb_conv(const void* act, long part_stride, const void* packed_w, cons
     a.part_stride = part_stride;
     a.w = static_cast<const char*>(packed_w);
     a.bias = bias;
-    a.out = out;
+    a.out = static_cast<float*>(out);
     a.B = B; a.PP = PP;
     a.nchunk = sh.kch / 16;
-    a.Qr = cb_round_up(rows * pitch, 4);
+    a.Qr = cb_round_up(rows * pitch, 8);
     a.ntot = sh.nout;
+    MV_REQUIRE(!out16 || kind <= 1, E_ARG, "mdnvae_cb_conv: fp16 output is for the forward products");
     a.out_scale = out_scale;
     const int slabpos = sh.NJ * 64;
     int ntaps = 0;
@@ -916,10 +1321,15 @@ int mdnvae_cb_conv(const void* act, long part_stride, const void* packed_w, cons
     MV_REQUIRE(parts == 1, E_SHAPE, "mdnvae_cb_conv: two-part operands are not built yet");
     const int nblk = (sh.nout + sh.NT * 32 - 1) / (sh.NT * 32);
     hipStream_t st = (hipStream_t)stream;
-    if (kind == 0 || kind == 2) return cb_launch_conv<1, 2, 8, 4, 2, 2, 3, 3, 3>(a, nblk, st);
-    if (kind == 3) return cb_launch_conv<1, 2, 8, 4, 2, 2, 3, 2, 2>(a, nblk, st);
-    if (sh.NT == 6) return cb_launch_conv<1, 8, 5, 4, 2, 2, 3, 3, 3>(a, nblk, st);
-    return cb_launch_conv<1, 8, 6, 8, 1, 1, 3, 3, 3>(a, nblk, st);
+    if (kind == 0 && out16) return cb_launch_conv<1, 2, 8, 4, 2, 2, 3, 3, 3, true, 8, 2, true>(a, nblk, st);
+    if (kind == 0 || kind == 2) return cb_launch_conv<1, 2, 8, 4, 2, 2, 3, 3, 3, true, 8, 2, false>(a, nblk, st);
+    if (kind == 3) return cb_launch_conv<1, 2, 8, 4, 2, 2, 3, 2, 2, true, 8, 2, false>(a, nblk, st);
+    if (sh.NT == 6) {
+        if (out16) return cb_launch_conv<1, 8, 5, 4, 2, 2, 3, 3, 3, false, 8, 2, true>(a, nblk, st);
+        return cb_launch_conv<1, 8, 5, 4, 2, 2, 3, 3, 3, false, 8, 2, false>(a, nblk, st);
+    }
+    if (out16) return cb_launch_conv<1, 8, 6, 8, 1, 1, 3, 3, 3, false, 8, 2, true>(a, nblk, st);
+    return cb_launch_conv<1, 8, 6, 8, 1, 1, 3, 3, 3, false, 8, 2, false>(a, nblk, st);
 }
 
 int mdnvae_cb_plane_stats(const float* y, long nplanes, int H, int W, int pitch, long plane_stride, float* stats,
@@ -937,15 +1347,17 @@ int mdnvae_cb_plane_stats(const float* y, long nplanes, int H, int W, int pitch,
     return 0;
 }
 
-int mdnvae_cb_norm_fwd(const float* y, const float* stats, const float* skip, float* stream_out, void* act,
-                       long part_stride, int B, int C, int H, int W, int pitch_y, long Qy, int relu, int mode, int PP,
-                       int parts, float scale, void* stream) {
+int mdnvae_cb_norm_fwd(const void* y, int y16, float* stats, int compute_stats, const float* skip, float* stream_out,
+                       void* act, long part_stride, int B, int C, int H, int W, int pitch_y, long Qy, int relu, int mode,
+                       int PP, int parts, float scale, void* stream) {
     MV_REQUIRE(B >= 0 && C >= 8 && C % 8 == 0 && H >= 2 && W >= 2, E_SHAPE, "mdnvae_cb_norm_fwd: bad shape");
     if (B == 0) return 0;
     MV_REQUIRE(y && stats && (act || stream_out), E_ARG, "mdnvae_cb_norm_fwd: null pointer");
     MV_REQUIRE(mode == 0 || mode == 1, E_ARG, "mdnvae_cb_norm_fwd: mode %d", mode);
     MV_REQUIRE(parts == 1 || parts == 2, E_ARG, "mdnvae_cb_norm_fwd: parts = %d", parts);
     MV_REQUIRE(B <= 65535, E_SHAPE, "mdnvae_cb_norm_fwd: batch %d exceeds the grid limit", B);
+    MV_REQUIRE(mode == 0 || (!skip && !stream_out), E_ARG, "mdnvae_cb_norm_fwd: skip / stream_out go with mode 0");
+    MV_REQUIRE(!y16 || compute_stats, E_ARG, "mdnvae_cb_norm_fwd: fp16 planes go with compute_stats = 1");
     CbNormFwd a{};
     a.y = y; a.stats = stats; a.skip = skip; a.stream_out = stream_out;
     a.act = static_cast<char*>(act);
@@ -953,18 +1365,44 @@ int mdnvae_cb_norm_fwd(const float* y, const float* stats, const float* skip, fl
     a.B = B; a.C = C; a.H = H; a.W = W; a.pitch_y = pitch_y; a.Qy = (int)Qy; a.relu = relu; a.mode = mode; a.PP = PP;
     a.opitch = mode == 0 ? W + 2 : (W + 1) / 2 + 1;
     const int orows = mode == 0 ? H + 2 : (H + 1) / 2 + 1;
-    MV_REQUIRE(PP >= orows * a.opitch, E_SHAPE, "mdnvae_cb_norm_fwd: %d positions per plane are fewer than %d x %d", PP, orows, a.opitch);
+    MV_REQUIRE(!act || PP >= orows * a.opitch, E_SHAPE, "mdnvae_cb_norm_fwd: %d positions per plane are fewer than %d x %d", PP, orows, a.opitch);
     a.scale = scale;
     dim3 grid(C / 8, B);
-    if (parts == 1) hipLaunchKernelGGL(cb_norm_fwd_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(cb_norm_fwd_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    hipStream_t st = (hipStream_t)stream;
+    const size_t lds = (size_t)64 * 4 + 8 * (size_t)Qy * (y16 ? 2 : 4);
+    if (compute_stats) {
+        MV_REQUIRE(Qy % (y16 ? 8 : 4) == 0 && lds <= 160 * 1024, E_SHAPE,
+                   "mdnvae_cb_norm_fwd: statistics in the pass need planes of a multiple of %d positions that fit the LDS (got %ld)",
+                   y16 ? 8 : 4, Qy);
+#define MV_FWD(P_, M_, T_)                                                                                                    \
+    do {                                                                                                                      \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cb_norm_fwd_lds_kernel<P_, M_, T_>),                          \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                                    \
+        hipLaunchKernelGGL((cb_norm_fwd_lds_kernel<P_, M_, T_>), grid, dim3(256), lds, st, a, stats);                         \
+    } while (0)
+#define MV_FWD_T(P_, M_)                       \
+    do {                                       \
+        if (y16) MV_FWD(P_, M_, _Float16);     \
+        else MV_FWD(P_, M_, float);            \
+    } while (0)
+        if (parts == 1 && mode == 0) MV_FWD_T(1, 0);
+        else if (parts == 1) MV_FWD_T(1, 1);
+        else if (mode == 0) MV_FWD_T(2, 0);
+        else MV_FWD_T(2, 1);
+#undef MV_FWD_T
+#undef MV_FWD
+        MV_LAUNCH_CHECK("cb_norm_fwd_lds_kernel");
+        return 0;
+    }
+    if (parts == 1) hipLaunchKernelGGL(cb_norm_fwd_kernel<1>, grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(cb_norm_fwd_kernel<2>, grid, dim3(256), 0, st, a);
     MV_LAUNCH_CHECK("cb_norm_fwd_kernel");
     return 0;
 }
 
-int mdnvae_cb_norm_bwd(const float* g, int gmode, int pitch_g, long Qg, const float* base, float* sum_out, const float* y,
-                       const float* stats, int pitch_y, long Qy, int relu, int B, int C, int H, int W, int omode, void* dc,
-                       long part_stride, int PP, int parts, float scale, float* gsum, void* stream) {
+int mdnvae_cb_norm_bwd(const float* g, int gmode, int pitch_g, long Qg, const float* base, float* sum_out, const void* y,
+                       int y16, const float* stats, int pitch_y, long Qy, int relu, int B, int C, int H, int W, int omode,
+                       void* dc, long part_stride, int PP, int parts, float scale, float* gsum, void* stream) {
     MV_REQUIRE(B >= 0 && C >= 1 && H >= 3 && W >= 3, E_SHAPE, "mdnvae_cb_norm_bwd: bad shape");
     if (B == 0) return 0;
     MV_REQUIRE(y && stats && dc && (g || gmode == 3), E_ARG, "mdnvae_cb_norm_bwd: null pointer");
@@ -981,21 +1419,63 @@ int mdnvae_cb_norm_bwd(const float* g, int gmode, int pitch_g, long Qg, const fl
     a.opitch = omode == 0 ? W + 2 : (omode == 1 ? W + 1 : W);
     hipStream_t st = (hipStream_t)stream;
     if (omode == 2) {
+        MV_REQUIRE(!y16, E_ARG, "mdnvae_cb_norm_bwd: fp32 planes out take fp32 planes in");
         MV_REQUIRE(H * W <= 32 * 256, E_SHAPE, "mdnvae_cb_norm_bwd: plane of %d entries exceeds %d", H * W, 32 * 256);
         hipLaunchKernelGGL((cb_norm_bwd_kernel<1, 1, 32>), dim3(C, B), dim3(256), 0, st, a);
+        MV_LAUNCH_CHECK("cb_norm_bwd_kernel");
+        return 0;
+    }
+    MV_REQUIRE(C % 8 == 0, E_SHAPE, "mdnvae_cb_norm_bwd: %d channels are not a multiple of 8", C);
+    const int orows = omode == 0 ? H + 4 : H + 1;
+    MV_REQUIRE(PP >= orows * a.opitch, E_SHAPE, "mdnvae_cb_norm_bwd: %d positions per plane are fewer than %d x %d", PP, orows, a.opitch);
+    MV_REQUIRE(PP <= 9 * 256, E_SHAPE, "mdnvae_cb_norm_bwd: %d positions per plane exceed %d", PP, 9 * 256);
+    dim3 grid(C / 8, B);
+    // planes staged in LDS when they fit and their runs of 8 planes are 16-byte aligned
+    const size_t gfl = gmode == 3 ? 0 : (gmode == 2 ? (size_t)32 * Qg : (size_t)8 * Qg + 4);
+    const size_t lds = (size_t)64 * 4 + 8 * (size_t)Qy * (y16 ? 2 : 4) + gfl * 4;
+    const bool aligned = Qy % (y16 ? 8 : 4) == 0 && (gmode == 3 || gmode == 0 || Qg % 4 == 0);
+    if (parts == 1 && aligned && lds <= 160 * 1024 && PP <= 2048 && (!sum_out || base) && gmode != 3) {
+#define MV_BWD(G_, O_, B_, NT_, NP_, T_)                                                                                      \
+    do {                                                                                                                      \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cb_norm_bwd_lds_kernel<1, G_, O_, B_, NT_, NP_, T_>),         \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                                    \
+        hipLaunchKernelGGL((cb_norm_bwd_lds_kernel<1, G_, O_, B_, NT_, NP_, T_>), grid, dim3(NT_), lds, st, a);               \
+    } while (0)
+#define MV_BWD_T(G_, O_, B_, NT_, NP_)                          \
+    do {                                                        \
+        if (y16) MV_BWD(G_, O_, B_, NT_, NP_, _Float16);        \
+        else MV_BWD(G_, O_, B_, NT_, NP_, float);               \
+    } while (0)
+#define MV_BWD_SZ(G_, O_, B_)                                   \
+    do {                                                        \
+        if (PP <= 768) MV_BWD_T(G_, O_, B_, 256, 3);            \
+        else MV_BWD_T(G_, O_, B_, 512, 4);                      \
+    } while (0)
+#define MV_BWD_B(G_, O_)                                        \
+    do {                                                        \
+        if (base) MV_BWD_SZ(G_, O_, true);                      \
+        else MV_BWD_SZ(G_, O_, false);                          \
+    } while (0)
+        if (gmode == 0 && omode == 0) MV_BWD_B(0, 0);
+        else if (gmode == 0) MV_BWD_B(0, 1);
+        else if (gmode == 1 && omode == 0) MV_BWD_B(1, 0);
+        else if (gmode == 1) MV_BWD_B(1, 1);
+        else if (omode == 0) MV_BWD_B(2, 0);
+        else MV_BWD_B(2, 1);
+#undef MV_BWD_B
+#undef MV_BWD_SZ
+#undef MV_BWD_T
+#undef MV_BWD
+        MV_LAUNCH_CHECK("cb_norm_bwd_lds_kernel");
+        return 0;
+    }
+    MV_REQUIRE(!y16, E_SHAPE, "mdnvae_cb_norm_bwd: fp16 planes need the LDS-staged kernel (planes too large or misaligned)");
+    if (parts == 1) {
+        if (PP <= 3 * 256) hipLaunchKernelGGL((cb_norm_bwd_kernel<1, 8, 3>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((cb_norm_bwd_kernel<1, 8, 9>), grid, dim3(256), 0, st, a);
     } else {
-        MV_REQUIRE(C % 8 == 0, E_SHAPE, "mdnvae_cb_norm_bwd: %d channels are not a multiple of 8", C);
-        const int orows = omode == 0 ? H + 4 : H + 1;
-        MV_REQUIRE(PP >= orows * a.opitch, E_SHAPE, "mdnvae_cb_norm_bwd: %d positions per plane are fewer than %d x %d", PP, orows, a.opitch);
-        MV_REQUIRE(PP <= 9 * 256, E_SHAPE, "mdnvae_cb_norm_bwd: %d positions per plane exceed %d", PP, 9 * 256);
-        dim3 grid(C / 8, B);
-        if (parts == 1) {
-            if (PP <= 3 * 256) hipLaunchKernelGGL((cb_norm_bwd_kernel<1, 8, 3>), grid, dim3(256), 0, st, a);
-            else hipLaunchKernelGGL((cb_norm_bwd_kernel<1, 8, 9>), grid, dim3(256), 0, st, a);
-        } else {
-            if (PP <= 3 * 256) hipLaunchKernelGGL((cb_norm_bwd_kernel<2, 8, 3>), grid, dim3(256), 0, st, a);
-            else hipLaunchKernelGGL((cb_norm_bwd_kernel<2, 8, 9>), grid, dim3(256), 0, st, a);
-        }
+        if (PP <= 3 * 256) hipLaunchKernelGGL((cb_norm_bwd_kernel<2, 8, 3>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((cb_norm_bwd_kernel<2, 8, 9>), grid, dim3(256), 0, st, a);
     }
     MV_LAUNCH_CHECK("cb_norm_bwd_kernel");
     return 0;

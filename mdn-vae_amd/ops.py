@@ -1351,9 +1351,9 @@ class _CBGeom:
         self.h2 = (n + 1) // 2                 # output of the first stride-2 layer
         self.h3 = (self.h2 + 1) // 2           # output of the second one = the residual blocks' planes
         self.p2, self.p3, self.pr = self.h2 + 1, self.h3 + 1, self.h3 + 2
-        self.q2, self.q3 = _ru(self.h2 * self.p2, 4), _ru(self.h3 * self.p3, 4)
-        self.qr = _ru(self.h3 * self.pr, 4)                  # residual forward rows
-        self.qd = _ru((self.h3 + 2) * self.pr, 4)            # residual data-gradient rows (reflection-padded grid)
+        self.q2, self.q3 = _ru(self.h2 * self.p2, 8), _ru(self.h3 * self.p3, 8)
+        self.qr = _ru(self.h3 * self.pr, 8)                  # residual forward rows
+        self.qd = _ru((self.h3 + 2) * self.pr, 8)            # residual data-gradient rows (reflection-padded grid)
         s2d = lambda rows, pitch, q: _ru(max((rows + 1) * pitch, q + pitch + 1) + 1, 4)
         self.pp_a1 = s2d(self.h2, self.p2, self.q2)          # parity planes of the first stride-2 layer's input
         self.pp_a2 = s2d(self.h3, self.p3, self.q3)
@@ -1384,11 +1384,12 @@ def _cb_pack(w, kind, dev):
     return out
 
 
-def _cb_conv(act, part_stride, wp, bias, B, cout, cin, kind, rows, pitch, PP):
+def _cb_conv(act, part_stride, wp, bias, B, cout, cin, kind, rows, pitch, PP, out16=False):
+    """out16: the planes leave as fp16 (forward kinds; what reads them normalises and rounds to bf16 anyway)."""
     nout = {0: cout, 1: cout, 2: cin, 3: 4 * cin}[kind]
-    out = torch.empty(B, nout, _ru(rows * pitch, 4), dtype=torch.float32, device=act.device)
-    call("mdnvae_cb_conv", act.data_ptr(), part_stride, wp.data_ptr(), ptr(bias, "conv bias"), ptr(out), B, cout, cin, kind,
-         rows, pitch, PP, 1, 1.0, stream())
+    out = torch.empty(B, nout, _ru(rows * pitch, 8), dtype=torch.float16 if out16 else torch.float32, device=act.device)
+    call("mdnvae_cb_conv", act.data_ptr(), part_stride, wp.data_ptr(), ptr(bias, "conv bias"), out.data_ptr(), int(out16), B, cout,
+         cin, kind, rows, pitch, PP, 1, 1.0, stream())
     return out
 
 
@@ -1400,7 +1401,8 @@ def _cb_stats(y, H, W, pitch):
 
 
 def _cb_norm_fwd(y, stats, H, W, pitch_y, relu, mode, PP, skip=None, want_stream=False, want_act=True):
-    """Channel-blocked activation (and, if asked, the fp32 residual stream [B,C,H,W]) of a raw conv output."""
+    """(channel-blocked activation, fp32 residual stream [B,C,H,W] if asked, statistics) of a raw conv output;
+    stats = None: the pass computes them itself."""
     B, C = y.shape[0], y.shape[1]
     Qy = y.numel() // (B * C)
     dev = y.device
@@ -1408,9 +1410,13 @@ def _cb_norm_fwd(y, stats, H, W, pitch_y, relu, mode, PP, skip=None, want_stream
     if want_act:
         act, ps = _cb_alloc((C // 8) * (4 if mode == 1 else 1), B, PP, dev)
     so = torch.empty(B, C, H, W, dtype=torch.float32, device=dev) if want_stream else None
-    call("mdnvae_cb_norm_fwd", ptr(y), ptr(stats), ptr(skip), ptr(so), None if act is None else act.data_ptr(), ps, B, C, H, W,
-         pitch_y, Qy, int(relu), mode, PP, 1, 1.0, stream())
-    return act, so
+    compute = stats is None
+    if compute:
+        stats = torch.empty(B * C, 2, dtype=torch.float32, device=dev)
+    y16 = y.dtype == torch.float16
+    call("mdnvae_cb_norm_fwd", ptr(y, "raw conv output", y.dtype), int(y16), ptr(stats), int(compute), ptr(skip), ptr(so),
+         None if act is None else act.data_ptr(), ps, B, C, H, W, pitch_y, Qy, int(relu), mode, PP, 1, 1.0, stream())
+    return act, so, stats
 
 
 def _cb_norm_bwd(g, gmode, pitch_g, y, stats, pitch_y, relu, C, H, W, omode, PP, base=None, want_sum=False):
@@ -1426,8 +1432,9 @@ def _cb_norm_bwd(g, gmode, pitch_g, y, stats, pitch_y, relu, C, H, W, omode, PP,
         dc, ps = _cb_alloc(C // 8, B, PP, dev)
     gsum = torch.empty(B, C, dtype=torch.float32, device=dev)
     so = torch.empty(B, C, H, W, dtype=torch.float32, device=dev) if want_sum else None
-    call("mdnvae_cb_norm_bwd", ptr(g), gmode, pitch_g, Qg, ptr(base), ptr(so), ptr(y), ptr(stats), pitch_y, Qy, int(relu), B, C,
-         H, W, omode, dc.data_ptr(), ps, PP, 1, 1.0, ptr(gsum), stream())
+    y16 = y.dtype == torch.float16
+    call("mdnvae_cb_norm_bwd", ptr(g), gmode, pitch_g, Qg, ptr(base), ptr(so), ptr(y, "raw conv output", y.dtype), int(y16),
+         ptr(stats), pitch_y, Qy, int(relu), B, C, H, W, omode, dc.data_ptr(), ps, PP, 1, 1.0, ptr(gsum), stream())
     return dc, gsum, so
 
 
@@ -1459,24 +1466,21 @@ class _ConvEncoderCB(torch.autograd.Function):
         wf = [_cb_pack(w, k, dev) for w, k in zip(ws[1:], kinds)]
         raw1 = stem.fwd(x, None, 0, wstem, bs[0], B)                                   # [B,48,n,n]
         st1 = _plane_stats(raw1)
-        a1, _ = _cb_norm_fwd(raw1, st1, n_nodes, n_nodes, n_nodes, True, 1, G.pp_a1)
-        y2 = _cb_conv(a1, 0, wf[0], bs[1], B, 96, 48, 1, G.h2, G.p2, G.pp_a1)
-        st2 = _cb_stats(y2, G.h2, G.h2, G.p2)
-        a2, _ = _cb_norm_fwd(y2, st2, G.h2, G.h2, G.p2, True, 1, G.pp_a2)
-        y3 = _cb_conv(a2, 0, wf[1], bs[2], B, 192, 96, 1, G.h3, G.p3, G.pp_a2)
-        st3 = _cb_stats(y3, G.h3, G.h3, G.p3)
+        a1, _, _ = _cb_norm_fwd(raw1, st1, n_nodes, n_nodes, n_nodes, True, 1, G.pp_a1)
+        y2 = _cb_conv(a1, 0, wf[0], bs[1], B, 96, 48, 1, G.h2, G.p2, G.pp_a1, out16=True)
+        a2, _, st2 = _cb_norm_fwd(y2, None, G.h2, G.h2, G.p2, True, 1, G.pp_a2)
+        y3 = _cb_conv(a2, 0, wf[1], bs[2], B, 192, 96, 1, G.h3, G.p3, G.pp_a2, out16=True)
         H = G.h3
-        xp, xs = _cb_norm_fwd(y3, st3, H, H, G.p3, True, 0, G.pp_r, want_stream=True)
+        xp, xs, st3 = _cb_norm_fwd(y3, None, H, H, G.p3, True, 0, G.pp_r, want_stream=True)
         saved = [x, raw1, st1, a1, y2, st2, a2, y3, st3]
         for k in range(nres):
             ia, ib = 2 + 2 * k, 3 + 2 * k           # index into wf / (ws[1:], bs[1:])
-            ya = _cb_conv(xp, 0, wf[ia], bs[ia + 1], B, 192, 192, 0, H, G.pr, G.pp_r)
-            sa = _cb_stats(ya, H, H, G.pr)
-            aa, _ = _cb_norm_fwd(ya, sa, H, H, G.pr, True, 0, G.pp_r)
-            yb = _cb_conv(aa, 0, wf[ib], bs[ib + 1], B, 192, 192, 0, H, G.pr, G.pp_r)
-            sb = _cb_stats(yb, H, H, G.pr)
+            ya = _cb_conv(xp, 0, wf[ia], bs[ia + 1], B, 192, 192, 0, H, G.pr, G.pp_r, out16=True)
+            aa, _, sa = _cb_norm_fwd(ya, None, H, H, G.pr, True, 0, G.pp_r)
+            yb = _cb_conv(aa, 0, wf[ib], bs[ib + 1], B, 192, 192, 0, H, G.pr, G.pp_r, out16=True)
+            xp_next, xs, sb = _cb_norm_fwd(yb, None, H, H, G.pr, False, 0, G.pp_r, skip=xs, want_stream=True, want_act=k + 1 < nres)
             saved += [xp, ya, sa, aa, yb, sb]
-            xp, xs = _cb_norm_fwd(yb, sb, H, H, G.pr, False, 0, G.pp_r, skip=xs, want_stream=True, want_act=k + 1 < nres)
+            xp = xp_next
         K = 8
         PH = H // K
         feat = torch.empty(B, 192 * PH * PH, dtype=torch.float32, device=dev)

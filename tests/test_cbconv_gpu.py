@@ -109,6 +109,8 @@ def test_stride1_forward_dgrad_wgrad(h, B):
     tag = f"h{h} B{B}"
     recipe.record("conv blocked bf16", "forward vs float64 on the rounded operands", tag, _rel(got, want), 1e-5)
     assert _rel(got, want) <= 1e-5
+    y16 = ops._cb_conv(act, 0, wf, b.to(DEV), B, C, C, 0, h, G.pr, G.pp_r, out16=True)       # the same planes as fp16
+    assert y16.dtype == torch.float16 and torch.equal(y16[:, :, :h * G.pr], y[:, :, :h * G.pr].to(torch.float16))
 
     dc, _ = _to_dev(cb_zero2(cot, G.pp_dr))
     wt = ops._cb_pack(w.to(DEV), 2, DEV)
@@ -174,15 +176,22 @@ def _pitched(t, pitch, Q):
     return out
 
 
-@pytest.mark.parametrize("C,H,relu,mode", [(16, 22, True, 0), (8, 17, False, 0), (16, 44, True, 1), (16, 87, True, 1), (16, 34, True, 1)])
-def test_norm_forward_pass(C, H, relu, mode):
+@pytest.mark.parametrize("C,H,relu,mode,y16", [(16, 22, True, 0, False), (8, 17, False, 0, False), (16, 44, True, 1, False),
+                                               (16, 87, True, 1, False), (16, 34, True, 1, False), (16, 22, True, 0, True),
+                                               (16, 44, True, 1, True), (8, 17, False, 0, True)])
+def test_norm_forward_pass(C, H, relu, mode, y16):
     g = torch.Generator().manual_seed(C * H + mode)
     B = 3
     raw = torch.randn(B, C, H, H, generator=g) * 2 + 0.5
+    if y16:
+        raw = raw.half().float()              # the planes arrive as fp16: the pass sees exactly these values
     skip = torch.randn(B, C, H, H, generator=g)
     pitch = H + 2
-    Q = ops._ru(H * pitch, 4)
-    if Q <= 2048:
+    Q = ops._ru(H * pitch, 8)
+    if y16:
+        y = _pitched(raw, pitch, Q).half().to(DEV)
+        st = None                             # fp16 planes: statistics come from the pass itself
+    elif Q <= 2048:
         y = _pitched(raw, pitch, Q).to(DEV)
         st = ops._cb_stats(y, H, H, pitch)
     else:                                   # the stem's output: planes without a pitch, statistics by the planar kernel
@@ -190,13 +199,15 @@ def test_norm_forward_pass(C, H, relu, mode):
         st = ops._plane_stats(y)
     mean = raw.double().mean(dim=(2, 3)).reshape(-1)
     rstd = 1.0 / torch.sqrt(raw.double().var(dim=(2, 3), unbiased=False) + 1e-5).reshape(-1)
-    assert _rel(st[:, 0], mean) <= 1e-6 and _rel(st[:, 1], rstd) <= 1e-6
+    if st is not None:
+        assert _rel(st[:, 0], mean) <= 1e-6 and _rel(st[:, 1], rstd) <= 1e-6
     want = F.instance_norm(raw.double(), eps=1e-5)
     if relu:
         want = want.relu()
     if mode == 0:
         PP = ops._ru((H + 2) * (H + 2) + 5, 4)
-        act, so = ops._cb_norm_fwd(y, st, H, H, pitch, relu, 0, PP, skip=skip.to(DEV), want_stream=True)
+        act, so, st2 = ops._cb_norm_fwd(y, st, H, H, pitch, relu, 0, PP, skip=skip.to(DEV), want_stream=True)
+        assert _rel(st2[:, 0], mean) <= 1e-6 and _rel(st2[:, 1], rstd) <= 1e-6
         want = want + skip.double()
         assert _rel(so, want) <= 2e-6
         got = unblock(act, C // 8, B, PP)
@@ -205,7 +216,7 @@ def test_norm_forward_pass(C, H, relu, mode):
     else:
         oh = (H + 1) // 2
         PP = ops._ru((oh + 1) * (oh + 1) + 3, 4)
-        act, _ = ops._cb_norm_fwd(y, st, H, H, pitch, relu, 1, PP)
+        act, _, _ = ops._cb_norm_fwd(y, st, H, H, pitch, relu, 1, PP)
         got = unblock(act, (C // 8) * 4, B, PP)
         ref = cb_parity(want.float(), PP).to(torch.bfloat16).double()
     # bf16 rounding of values that differ in the last fp32 bit may land one bf16 step apart
@@ -213,24 +224,31 @@ def test_norm_forward_pass(C, H, relu, mode):
     assert float((got != ref).double().mean()) < 1e-3
 
 
+@pytest.mark.parametrize("y16", [False, True])
 @pytest.mark.parametrize("C,H,relu,gmode,omode", [(16, 22, False, 0, 0), (16, 22, True, 1, 0), (8, 17, True, 1, 1),
                                                   (16, 44, True, 2, 1), (16, 34, True, 2, 1), (4, 87, True, 2, 2), (3, 68, True, 2, 2)])
-def test_norm_backward_pass(C, H, relu, gmode, omode):
+def test_norm_backward_pass(C, H, relu, gmode, omode, y16):
     """dc against autograd through [pad / parity gather] + relu + instance norm; the gradient arrives the way the
     consumer's data gradient leaves it, plus (gmode 1) the residual stream's own gradient."""
     g = torch.Generator().manual_seed(C * H + gmode * 7 + omode)
     B = 2
     raw = torch.randn(B, C, H, H, generator=g) * 2 + 0.5
+    if y16:
+        if omode == 2:
+            pytest.skip("the stem's planes stay fp32")
+        raw = raw.half().float()
     rd = raw.double().requires_grad_(True)
     a = F.instance_norm(rd, eps=1e-5)
     if relu:
         a = a.relu()
     pitch_y = H + 3
-    Qy = ops._ru(H * pitch_y, 4)
+    Qy = ops._ru(H * pitch_y, 8)
     y = _pitched(raw, pitch_y, Qy).to(DEV)
     st = ops._cb_stats(y, H, H, pitch_y) if Qy <= 2048 else ops._plane_stats(raw.to(DEV))
     if Qy > 2048:
         y, pitch_y = raw.to(DEV), H
+    if y16:
+        y = y.half()
     base = None
     if gmode == 0:
         cot = torch.randn(B, C, H, H, generator=g)
@@ -242,11 +260,11 @@ def test_norm_backward_pass(C, H, relu, gmode, omode):
         (F.pad(a, (1, 1, 1, 1), mode="reflect") * cotp.double()).sum().backward(retain_graph=True)
         (a * base.double()).sum().backward()
         pitch_g = H + 2
-        gt = _pitched(cotp, pitch_g, ops._ru((H + 2) * pitch_g, 4)).to(DEV)
+        gt = _pitched(cotp, pitch_g, ops._ru((H + 2) * pitch_g, 8)).to(DEV)
     else:
         oh = (H + 1) // 2
         pitch_g = oh + 1
-        Qg = ops._ru(oh * pitch_g, 4)
+        Qg = ops._ru(oh * pitch_g, 8)
         cot = torch.randn(B, C, H, H, generator=g)
         (a * cot.double()).sum().backward()
         full = torch.zeros(B, C, 2 * oh, 2 * oh)
