@@ -247,15 +247,19 @@ SPLIT_PRODUCTS = {"conv_bf16x2_kernel": 3, "conv_bf16x3_kernel": 6, "conv_wgrad_
 ABI_TAGS["mdnvae_split_gemm"] = (lambda a: "split_gemm_kernel" if a[16] == 6 else "split_gemm_kernel<3 terms>",
                                  lambda a: 2.0 * a[16] * a[5] * min(a[3], a[6] * (a[3] // a[13])) * a[4])
 # (a, b, absmax_a, absmax_b, M, N, K, m_valid, n_valid, ..., n_split at 15): three fp16 products per fp32 multiply-add
-ABI_TAGS["mdnvae_split_gemm_f16"] = ("split_gemm_kernel<3 fp16 terms>",
+ABI_TAGS["mdnvae_split_gemm_f16"] = (lambda a: "split_gemm_kernel<3 fp16 terms>" if a[18] < 0
+                                     else "split_gemm_kernel<3 fp16 terms, weight gradient>",
                                      lambda a: 6.0 * a[7] * min(a[5], a[8] * (a[5] // a[15])) * a[6])
-BF16_TAGS.add("split_gemm_kernel<3 fp16 terms>")          # the fp16 matrix rate equals the bf16 one
+BF16_TAGS |= {"split_gemm_kernel<3 fp16 terms>", "split_gemm_kernel<3 fp16 terms, weight gradient>"}   # fp16 rate = bf16 rate
 ABI_TAGS.update({
     # (src, R, K, ld, ...): the fp32 source in, two fp16 parts out; (src, gate, Kd, R, ld, ...) likewise
     "mdnvae_split_rows_f16": ("split_rows_kernel<fp16>", lambda a: 8.0 * a[1] * a[2]),
     "mdnvae_split_cols_f16": ("split_cols_kernel<fp16>", lambda a: (8.0 + (4.0 if a[1] is not None else 0.0)) * a[2] * a[3]),
     # (src, Kd, R, ld, ones_row, parts, ...): the batch in once, two fp16 parts and `parts` bf16 parts out
-    "mdnvae_split_rows_f16_cols": ("split_both_kernel", lambda a: (8.0 + 2.0 * a[5]) * a[1] * a[3]),
+    "mdnvae_split_rows_f16_cols": ("split_both_kernel", lambda a: (8.0 + 2.0 * (a[5] or 2)) * a[1] * a[3]),
+    # (gpre, w, dense, gate, Kd, R, J, ...): grad_pre and the gate in (+ the addend), two fp16 parts out
+    "mdnvae_split_cols_dgrad_f16": ("split_cols_dgrad_kernel",
+                                    lambda a: a[4] * (4.0 * a[6] + (8.0 + (4.0 if a[2] is not None else 0.0)) * a[5])),
     "mdnvae_absmax": ("absmax_kernel", lambda a: 4.0 * a[1] * a[2]),
     "mdnvae_tri_pack_absmax": ("tri_pack_kernel", lambda a: 4.0 * a[1] * (a[2] * a[2] + a[2] * (a[2] + 1) // 2)),
     "mdnvae_tri_fold_absmax": ("tri_pack_kernel<fold>", lambda a: 4.0 * a[1] * (a[2] * a[2] + a[2] * (a[2] + 1) // 2)),
@@ -270,6 +274,36 @@ ABI_TAGS.update({
     "mdnvae_linear_wgrad": ("tsgemm_partial_kernel+tsgemm_reduce_kernel", lambda a: 2.0 * a[2] * a[3] * a[4]),
     "mdnvae_linear_wgrad_bias": ("tsgemm_partial_kernel+tsgemm_reduce_kernel", lambda a: 2.0 * a[2] * a[3] * a[4]),
 })
+
+
+# ---- channel-blocked conv encoder (bf16 operands): flops of the convolution the launch stands for ----
+# mdnvae_cb_conv(act, part_stride, w, bias, out, out16, B, Cout, Cin, kind, rows, pitch, ...): square planes, `rows` output
+# rows per side (the padded grid, two more, for the stride-1 data gradient)
+_CB_KIND = {0: "cb_conv_kernel<forward>", 1: "cb_conv_kernel<forward, stride 2>", 2: "cb_conv_kernel<data gradient>",
+            3: "cb_conv_kernel<data gradient, stride 2>"}
+ABI_TAGS.update({
+    "mdnvae_cb_conv": (lambda a: _CB_KIND[a[9]],
+                       lambda a: 18.0 * a[6] * a[7] * a[8] * (a[10] - (2 if a[9] == 2 else 0)) ** 2),
+    # (g, act, workspace, grad_w, B, Cout, Cin, planes, PPg, PPa, kbeg, kend, pitch, ...)
+    "mdnvae_cb_wgrad": (lambda a: "cb_wgrad_kernel" if a[7] == 1 else "cb_wgrad_kernel<stride 2>",
+                        lambda a: 18.0 * a[4] * a[5] * a[6] * (a[12] - (2 if a[7] == 1 else 1)) ** 2),
+    # (y, y16, stats, compute, skip, stream_out, act, part_stride, B, C, H, W, pitch_y, Qy, relu, mode, PP, ...): every
+    # buffer once, as laid out (padding included)
+    "mdnvae_cb_norm_fwd": ("cb_norm_fwd_kernel",
+                           lambda a: 1.0 * a[8] * a[9] * (a[13] * (2 if a[1] else 4) + (4 * a[10] * a[11] if a[4] is not None else 0)
+                                                          + (4 * a[10] * a[11] if a[5] is not None else 0)
+                                                          + (2 * a[16] * (4 if a[15] == 1 else 1) if a[6] is not None else 0))),
+    # (g, gmode, pitch_g, Qg, base, sum_out, y, y16, stats, pitch_y, Qy, relu, B, C, H, W, omode, dc, part_stride, PP, ...)
+    "mdnvae_cb_norm_bwd": ("cb_norm_bwd_kernel",
+                           lambda a: 1.0 * a[12] * a[13] * ((4 * a[3] * (4 if a[1] == 2 else 1) if a[0] is not None else 0)
+                                                            + (4 * a[14] * a[15] if a[4] is not None else 0)
+                                                            + (4 * a[14] * a[15] if a[5] is not None else 0)
+                                                            + a[10] * (2 if a[7] else 4)
+                                                            + (4 * a[14] * a[15] if a[16] == 2 else 2 * a[19]))),
+})
+BF16_TAGS |= set(_CB_KIND.values()) | {"cb_wgrad_kernel", "cb_wgrad_kernel<stride 2>"}
+HBM_TAGS |= {"cb_norm_fwd_kernel", "cb_norm_bwd_kernel"}
+ELEMENTWISE_TAGS = {"cb_norm_fwd_kernel", "cb_norm_bwd_kernel"}
 
 
 def install_clock(clock):
@@ -392,8 +426,74 @@ def mixture_stream_rates(batch, nodes, device, reps=5):
             for k, v in table.items()}
 
 
+def fused_loss_rates(nodes, device, batches=(16384, 1024), reps=20):
+    """mdnvae_vae_loss_fwd / _bwd / _fwdbwd (the reference's own loss_function, function/VAE_CNN_NN.py:197-200 and
+    function/MM_Gate.py:179-182, and its gradient) for the three reconstruction modes, each timed as `reps`
+    back-to-back calls between one pair of HIP events on the launch stream.  Algorithmic bytes per call: forward
+    reads recon and x [B,N*N] and the latent rows; backward and the fused pass also write grad_recon and the two
+    latent gradients.  The calls rotate over enough buffer sets (about 1 GB in all) that no call finds its
+    operands in the 256 MB memory-side cache."""
+    from mdnvae_amd._lib import call, ptr, stream
+    out = {}
+    D, L = nodes * nodes, 68
+    for B in batches:
+        per_set = 4.0 * B * (3 * D + 4 * L)
+        nsets = max(1, min(16, int(1.0e9 // per_set)))
+        g = torch.Generator(device=device).manual_seed(B)
+        sets = []
+        for _ in range(nsets):
+            sets.append(dict(recon=torch.rand(B, D, device=device, generator=g) + 0.1, x=torch.rand(B, D, device=device, generator=g),
+                             mu=torch.randn(B, L, device=device, generator=g) * 0.1,
+                             lv=torch.randn(B, L, device=device, generator=g) * 0.1,
+                             gr=torch.empty(B, D, device=device), gm=torch.empty(B, L, device=device),
+                             gl=torch.empty(B, L, device=device)))
+        ws = torch.empty(int(M._lib.load().mdnvae_loss_workspace_bytes()), dtype=torch.uint8, device=device)
+        loss = torch.empty(3, device=device)
+        entry = {}
+        for mode_name, mode in ops.RECON_MODES.items():
+            def fwd(t):
+                call("mdnvae_vae_loss_fwd", mode, ptr(t["recon"]), ptr(t["x"]), B, D, ptr(t["mu"]), ptr(t["lv"]), L, None, None,
+                     ws.data_ptr(), ptr(loss), stream())
+
+            def bwd(t):
+                call("mdnvae_vae_loss_bwd", mode, ptr(t["recon"]), ptr(t["x"]), B, D, ptr(t["mu"]), ptr(t["lv"]), L, None, None,
+                     None, ptr(t["gr"]), ptr(t["gm"]), ptr(t["gl"]), stream())
+
+            def fwdbwd(t):
+                call("mdnvae_vae_loss_fwdbwd", mode, ptr(t["recon"]), ptr(t["x"]), B, D, ptr(t["mu"]), ptr(t["lv"]), L,
+                     ptr(t["gr"]), ptr(t["gm"]), ptr(t["gl"]), ws.data_ptr(), ptr(loss), stream())
+
+            for name, fn, nbytes in (("fwd", fwd, 4.0 * B * (2 * D + 2 * L)), ("bwd", bwd, 4.0 * B * (3 * D + 4 * L)),
+                                     ("fwdbwd", fwdbwd, 4.0 * B * (3 * D + 4 * L))):
+                for i in range(2):
+                    fn(sets[i % nsets])
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                for i in range(reps):
+                    fn(sets[i % nsets])
+                b.record()
+                torch.cuda.synchronize()
+                sec = a.elapsed_time(b) * 1e-3 / reps
+                entry[f"{mode_name}_{name}"] = dict(bound="hbm", achieved=nbytes / sec / 1e9, peak=PEAK_HBM_GBPS, unit="GB/s",
+                                                    frac=nbytes / sec / 1e9 / PEAK_HBM_GBPS, avg_ms=sec * 1e3,
+                                                    algorithmic_bytes=nbytes)
+        out[f"B={B}"] = entry
+        del sets
+    out["note"] = (f"N = {nodes}, L = {L}; {reps} back-to-back calls per figure between one HIP-event pair (each call = the "
+                   "streaming kernel + the one-workgroup finalize where a loss is returned); buffer sets rotated past the "
+                   "memory-side cache")
+    return out
+
+
 def run_workload(model_name, batch, nodes, steps, warmup, pool_batches, device, rank, world, use_clock,
-                 overlap=True, symmetric=True, graph=False, precision="fp32"):
+                 overlap=True, symmetric=True, graph=False, precision="fp32", fast_wgrad=False, arith=None):
+    with ops.arithmetic(**(arith or {})):
+        return _run_workload(model_name, batch, nodes, steps, warmup, pool_batches, device, rank, world, use_clock,
+                             overlap, symmetric, graph, precision, fast_wgrad)
+
+
+def _run_workload(model_name, batch, nodes, steps, warmup, pool_batches, device, rank, world, use_clock,
+                  overlap, symmetric, graph, precision, fast_wgrad):
     """Warm up, then time exactly `steps` steps between barrier + synchronize pairs; returns
     (elapsed seconds: max over ranks, final loss, kernel clock, wall time of the instrumented pass
     or None, workload description)."""
@@ -409,7 +509,7 @@ def run_workload(model_name, batch, nodes, steps, warmup, pool_batches, device, 
         extra_inputs = (knn_adjacency_from(gen(256, nodes, seed=1234, device=device), nodes),)
     if model_name == "mdn_gate":
         extra_inputs += (torch.randn(batch, 4, device=device, generator=torch.Generator(device=device).manual_seed(7)),)
-    trainer = M.Trainer(model, mode) if overlap else M.Trainer(model, mode, overlap_floats=0)
+    trainer = M.Trainer(model, mode, fast_wgrad=fast_wgrad, **({} if overlap else {"overlap_floats": 0}))
     eps_gen = torch.Generator(device=device).manual_seed(99 + rank)
 
     if graph:                                    # the whole step recorded once, replayed as one launch
@@ -461,7 +561,40 @@ def run_workload(model_name, batch, nodes, steps, warmup, pool_batches, device, 
     return elapsed, float(loss.item()), clock, clocked, what
 
 
+def headline_dtype(args):
+    """The arithmetic of the step's products, as short as it can be said; config["arithmetic"] spells it out."""
+    if args.model in ("mm_gate", "mdn_gate"):
+        wg = "bf16x3" if args.fast_wgrad else ops.ARITH_WGRAD
+        return f"f32 (first-layer products: {ops.ARITH_FWD} forward / {wg} weight gradients on the 16-bit MFMA, f32 accumulate)"
+    return {"fp32": "f32 (3x3 convolutions: bf16x3 / bf16x2 split MFMA, f32 accumulate)", "fp32_mfma": "f32",
+            "bf16x2": "f32 (3x3 convolutions: bf16x2 split MFMA, f32 accumulate)"}.get(
+                args.precision, "bf16 operands, f32 accumulate (3x3 convolutions); f32 elsewhere")
+
+
+ARITHMETIC_NOTE = (
+    "every tensor is f32.  The two big first-layer products run on the 16-bit matrix cores from split operands: "
+    "f16x2 = two fp16 parts per operand (22 significand bits, per-tensor power-of-two scale), three products, f32 "
+    "accumulate - entry-wise error <= 3 * 2^-22 of sum |a||b|, the level of an f32 dot product; bf16x6 = three bf16 "
+    "parts, six products, 2^-24; bf16x3 = two bf16 parts, three products, up to 3 * 2^-16 per product (weight gradients "
+    "only, opt-in).  All other products: f32 MFMA or f32 VALU.")
+
+
 def main():
+    global REHEARSE_EXCHANGE
+    # the one JSON line is all that may reach stdout: libraries that print there (RCCL's version banner) go to stderr
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        line = _main()
+    finally:
+        os.dup2(json_fd, 1)
+        os.close(json_fd)
+    if line is not None:
+        print(json.dumps(line), flush=True)
+
+
+def _main():
+    global REHEARSE_EXCHANGE
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
@@ -483,6 +616,12 @@ def main():
     ap.add_argument("--no-full-variant", action="store_true",
                     help="skip the short run without the symmetric-input promise reported under 'full_first_layer'")
     ap.add_argument("--no-kernel-clock", action="store_true")
+    ap.add_argument("--fast-wgrad", action="store_true",
+                    help="Trainer(fast_wgrad=True): first-layer weight gradients from two bf16 parts (3 products, about 1e-5 of "
+                         "the gradient's norm) instead of two fp16 parts")
+    ap.add_argument("--no-variants", action="store_true",
+                    help="skip the 'strict' (six bf16 products everywhere) and 'fast_wgrad' runs of the headline workload, the "
+                         "'fused_loss_kernels' block and the 'exchange_rehearsal' runs reported on one GPU")
     ap.add_argument("--no-overlap", action="store_true", help="all-reduce every gradient after backward")
     ap.add_argument("--full-first-layer", action="store_true",
                     help="FNN-encoder models: run the first layers on all N*N entries instead of the packed triangle")
@@ -506,7 +645,6 @@ def main():
     if args.rehearse_exchange and world == 1:
         # one GPU: a one-rank RCCL group whose collectives are identities, so that the calls of the
         # multi-GPU path (barriers, early and bucketed gradient all-reduce, MAX of the timings) run
-        global REHEARSE_EXCHANGE
         REHEARSE_EXCHANGE = True
         M.trainer.MIN_RANKS_FOR_EXCHANGE = 1
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -524,26 +662,27 @@ def main():
                                                              args.pool, device, rank, world,
                                                              not args.no_kernel_clock and not args.graph,
                                                              not args.no_overlap, not args.full_first_layer,
-                                                             graph=args.graph and world == 1, precision=args.precision)
+                                                             graph=args.graph and world == 1, precision=args.precision,
+                                                             fast_wgrad=args.fast_wgrad)
     if rank == 0:
         line = {
             "metric": "train samples/sec (fwd+bwd, 87x87 connectome)" if args.nodes == 87 else
                       f"train samples/sec (fwd+bwd, {args.nodes}x{args.nodes} connectome)",
             "value": world * batch * args.steps / elapsed, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": headline_dtype(args), "data": "synthetic",
             "config": {"workload": what, "per_gpu_batch": batch, "global_batch": batch * world,
                        "n_nodes": args.nodes, "parallelism": f"dp{world}", "final_loss_per_sample": final_loss / batch,
+                       "arithmetic": ARITHMETIC_NOTE,
                        # FNN-encoder models: first layers on the packed upper triangle of the (device-verified)
                        # symmetric input, half the reference's multiply-adds; the like-for-like number without
                        # that shortcut is full_first_layer_value
                        "symmetric_first_layer": bool(args.model in ("mm_gate", "mdn_gate") and not args.full_first_layer),
-                       "first_layer_gemm": ("two-part fp16 MFMA, 3 products (22-bit operands, fp32 accumulation), hand-written"
-                                            if ops.SPLIT_FWD == "f16" else "split-bf16 MFMA (fp32-accurate), hand-written")
-                       if args.model in ("mm_gate", "mdn_gate") else "library fp32",
-                       # bf16 products per multiply-add in the weight gradient
-                       # (3 = error about 1e-5 of the gradient's norm, bar 1e-4; MDNVAE_SPLIT_WGRAD_TERMS=6 for all)
-                       "first_layer_wgrad_terms": ops.SPLIT_WGRAD_TERMS},
+                       # arithmetic of the two hand-written first-layer products (see ops.ARITH_FWD / ARITH_WGRAD)
+                       "first_layer_forward": ops.ARITH_FWD if args.model in ("mm_gate", "mdn_gate") else "library fp32",
+                       "first_layer_weight_gradient": ("bf16x3" if args.fast_wgrad else ops.ARITH_WGRAD)
+                       if args.model in ("mm_gate", "mdn_gate") else "library fp32"},
         }
         kernels = kernel_table(clock, clocked) if clocked else {}
         if kernels:
@@ -565,6 +704,23 @@ def main():
                      "training step uses the rank-one form (mdn_outer_kernel)")
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(args.model, args.nodes)
+    fnn = args.model in ("mm_gate", "mdn_gate")
+    if world == 1 and fnn and not args.no_variants and not args.full_first_layer and not args.fast_wgrad and not args.graph:
+        # the same workload with every hand-written product at six bf16 terms (2^-24 of sum |a||b|, the finest this
+        # library has), and with the faster three-term bf16 weight gradients
+        vsteps = max(2, args.steps)
+        for key, kw, note in (
+                ("strict", dict(arith=dict(fwd="bf16x6", wgrad="bf16x6")),
+                 "first-layer products (forward and weight gradients) from three bf16 parts, six products, f32 accumulate"),
+                ("fast_wgrad", dict(fast_wgrad=True),
+                 "Trainer(fast_wgrad=True): first-layer weight gradients from two bf16 parts, three products")):
+            elv, lossv, _, _, whatv = run_workload(args.model, batch, args.nodes, vsteps, 3, args.pool, device, rank, world,
+                                                   False, not args.no_overlap, True, **kw)
+            line[key] = {"workload": whatv, "arithmetic": note, "value": batch * vsteps / elv, "unit": "samples/s",
+                         "per_gpu_batch": batch, "steps": vsteps, "warmup": 3, "ms_per_step": elv / vsteps * 1e3,
+                         "final_loss_per_sample": lossv / batch}
+    if world == 1 and not args.no_variants:
+        line["fused_loss_kernels"] = fused_loss_rates(args.nodes, device)
     if world == 1 and args.nodes != 68 and not args.no_n68:
         # the reference-parity shape (68 x 68 crop) next to the 87 x 87 headline shape
         steps68 = max(2, args.steps)             # the same step count as the headline: a 4-step window read 15 % low
@@ -593,6 +749,39 @@ def main():
                                            not args.no_overlap, not args.full_first_layer, graph=use_graph)
             entry[key] = {"value": sb * ssteps / el, "ms_per_step": el / ssteps * 1e3, "final_loss_per_sample": ls / sb}
         line["script_batch"] = entry
+    if world == 1 and fnn and not args.no_variants and not args.rehearse_exchange and not args.graph:
+        # What the gradient exchange costs on the host side, as far as one GPU can show it: the same steps with the
+        # collective calls of the data-parallel path issued on a one-rank RCCL group (every sum is an identity), next to
+        # the same steps without; and the scripts' batch size replayed as two graphs split at the exchange.
+        try:
+            rsteps = max(2, args.steps)
+            el0, _, _, _, _ = run_workload(args.model, batch, args.nodes, rsteps, 3, args.pool, device, rank, world, False,
+                                           not args.no_overlap, not args.full_first_layer)
+            REHEARSE_EXCHANGE = True
+            M.trainer.MIN_RANKS_FOR_EXCHANGE = 1
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            dist.init_process_group(backend="nccl", world_size=1, rank=0, device_id=device)
+            try:
+                el1, _, _, _, _ = run_workload(args.model, batch, args.nodes, rsteps, 3, args.pool, device, rank, world, False,
+                                               not args.no_overlap, not args.full_first_layer)
+                elg, _, _, _, _ = run_workload(args.model, 256, args.nodes, 100, 10, args.pool, device, rank, world, False,
+                                               not args.no_overlap, not args.full_first_layer, graph=True)
+            finally:
+                dist.destroy_process_group()
+                REHEARSE_EXCHANGE = False
+                M.trainer.MIN_RANKS_FOR_EXCHANGE = 2
+            line["exchange_rehearsal"] = {
+                "what": "one-rank RCCL group on this GPU: early all-reduce of the folded first-layer gradients from inside "
+                        "backward, bucketed all-reduce of the rest, barriers; sums are identities, so this is the cost of "
+                        "issuing and waiting for the collectives, not of moving bytes over xGMI",
+                "per_gpu_batch": batch, "steps": rsteps, "ms_per_step_without": el0 / rsteps * 1e3,
+                "ms_per_step_with": el1 / rsteps * 1e3, "overhead_ms_per_step": (el1 - el0) / rsteps * 1e3,
+                "script_batch_split_graph": {"per_gpu_batch": 256, "steps": 100, "ms_per_step": elg / 100 * 1e3,
+                                             "value": 256 * 100 / elg, "unit": "samples/s",
+                                             "what": "captured step replayed as backward graph -> all-reduce -> Adam graph"}}
+        except Exception as e:      # no RCCL on this box: the headline does not depend on it
+            line["exchange_rehearsal"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     if world == 1 and args.also and args.also != args.model:
         ab = default_batch(args.also)
         steps = args.steps
@@ -605,6 +794,7 @@ def main():
         if k2:
             dom2 = max(k2, key=lambda k: k2[k]["share_of_step"])
             also["roofline"] = dict(k2[dom2], kernel=dom2)
+            also["elementwise_share_of_step"] = sum(v["share_of_step"] for k, v in k2.items() if k in ELEMENTWISE_TAGS)
         if not args.no_cpu_baseline:
             also["cpu_baseline"] = cpu_baseline(args.also, args.nodes, seconds_budget=12.0)
         line["also"] = also
@@ -618,11 +808,11 @@ def main():
         if k3:
             dom3 = max(k3, key=lambda k: k3[k]["share_of_step"])
             bf["roofline"] = dict(k3[dom3], kernel=dom3)
+            bf["elementwise_share_of_step"] = sum(v["share_of_step"] for k, v in k3.items() if k in ELEMENTWISE_TAGS)
         line["also_bf16"] = bf
-    if rank == 0:
-        print(json.dumps(line))
     if world > 1 or REHEARSE_EXCHANGE:
         dist.destroy_process_group()
+    return line if rank == 0 else None
 
 
 if __name__ == "__main__":

@@ -298,7 +298,7 @@ int mdnvae_split_gemm(const void* a, const void* b, long M, long N, long K, long
  * the kernels that use it take the largest). */
 #define MDNVAE_ABSMAX_SLOTS 64
 /* absmax = max(absmax, |floor_value|, largest |src[r][c]|), src [rows][ld], c < cols; reset != 0 clears the
- * slots first (hipMemsetAsync on the stream).  Several tensors that share a scale are folded into one array by
+ * slots first (a one-workgroup kernel on the stream).  Several tensors that share a scale are folded into one array by
  * consecutive calls with reset = 0. */
 int mdnvae_absmax(const float* src, long rows, long cols, long ld, float floor_value, int reset, unsigned* absmax,
                   void* stream);
@@ -308,23 +308,39 @@ int mdnvae_tri_pack_absmax(const float* x, long B, int N, int ld, float* out, in
                            void* stream);
 int mdnvae_tri_fold_absmax(const float* w, long H, int N, int ld, float* out, int reset, unsigned* absmax, void* stream);
 /* mdnvae_split_rows / mdnvae_split_cols_gated writing the two fp16 parts of src * 2^e(*absmax); *absmax must
- * be at least the largest magnitude of everything written into the operand (a row of ones included: give
- * mdnvae_absmax floor_value = 1). */
+ * be at least the largest magnitude of the source entries written into the operand.  ones_row != 0: operand row R
+ * holds 2^14 in its high part whatever the scale (ones times the scale could leave fp16's range); pass R as
+ * unit_row to mdnvae_split_gemm_f16 and row R of the product is the column sum of the other operand. */
 int mdnvae_split_rows_f16(const float* src, long R, long K, long ld, long row_tile0, const unsigned* absmax, void* out,
                           void* stream);
 int mdnvae_split_cols_f16(const float* src, const float* gate, long Kd, long R, long ld, int ones_row, long row_tile0,
                           const unsigned* absmax, void* out, void* stream);
 /* Both operands a batch src [Kd][ld] takes part in, from one read of it: out_rows = what mdnvae_split_rows_f16(src,
- * Kd, ld, ld, 0, absmax, ...) writes (the forward product's operand: every column up to ld), out_cols = what
- * mdnvae_split_cols_gated(src, NULL, Kd, R, ld, ones_row, parts, 0, ...) writes (the weight-gradient product's
- * operand: columns < R and the row of ones, bf16 parts).  ld a multiple of 16, 16-byte aligned rows. */
+ * Kd, ld, ld, 0, absmax, ...) writes (the forward product's operand: every column up to ld), out_cols = the
+ * weight-gradient product's operand (columns < R and the row of ones): parts = 1..3: that many bf16 parts, as
+ * mdnvae_split_cols_gated(src, NULL, Kd, R, ld, ones_row, parts, 0, ...) writes them; parts = 0: two fp16 parts at
+ * the same scale, as mdnvae_split_cols_f16(src, NULL, Kd, R, ld, ones_row, 0, absmax, ...) writes them.  ld a
+ * multiple of 16, 16-byte aligned rows. */
 int mdnvae_split_rows_f16_cols(const float* src, long Kd, long R, long ld, int ones_row, int parts, const unsigned* absmax,
                                void* out_rows, void* out_cols, void* stream);
+/* mdnvae_split_cols_dgrad writing two fp16 parts: the gradient of relu(fc11) / relu(fc12) formed from the next
+ * layer's (grad_pre, weight) under the gate (function/MM_Gate.py:157-160), scaled by 2^e(*absmax).  *absmax must
+ * bound |gpre . w + dense|: mdnvae_dgrad_bound gives such a bound without forming the product. */
+int mdnvae_split_cols_dgrad_f16(const float* gpre, const float* w, const float* dense, const float* gate, long Kd, long R,
+                                long J, long row_tile0, const unsigned* absmax, void* out, void* stream);
+/* absmax = max(absmax, |gpre|max * max_c sum_j |w[j][c]| + |dense|max) for w [J][R]: an upper bound of every entry
+ * of gpre . w + dense from the two tensors' largest magnitudes (absmax_gpre, absmax_dense or NULL: arrays
+ * mdnvae_absmax filled).  A bound some binades above the true maximum only moves the fp16 split's absolute error
+ * floor (2^-29 of the bound); reset != 0 clears the slots first. */
+int mdnvae_dgrad_bound(const unsigned* absmax_gpre, const float* w, long J, long R, const unsigned* absmax_dense, int reset,
+                       unsigned* absmax, void* stream);
 /* mdnvae_split_gemm on two such operands (three products); the epilogue divides by both scales before bias and
- * ReLU.  Arguments as mdnvae_split_gemm. */
+ * ReLU.  Arguments as mdnvae_split_gemm; unit_row: the row of `a` written with ones_row != 0 (its products are
+ * divided by 2^14 instead of a's scale), or -1. */
 int mdnvae_split_gemm_f16(const void* a, const void* b, const unsigned* absmax_a, const unsigned* absmax_b, long M, long N,
                           long K, long m_valid, long n_valid, const float* bias0, const float* bias1, int relu,
-                          int accumulate, float* out0, float* out1, long n_split, long ld_out, int tile_m, void* stream);
+                          int accumulate, float* out0, float* out1, long n_split, long ld_out, int tile_m, long unit_row,
+                          void* stream);
 
 /* ---- conv / ResNet encoder ---------------------------------------------------------------
  * The ATen conv2d / instance_norm / relu / max_pool2d calls (and their autograd) of the encoder

@@ -123,4 +123,16 @@ __device__ __forceinline__ PairSum block_pair_sum(const double* __restrict__ pai
 
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
 
+// Clearing a few words that kernels launched next update with atomics (largest-magnitude records, small
+// accumulators).  A kernel, not hipMemsetAsync: inside a replayed HIP graph a memset node was seen to overlap the
+// kernel node recorded after it (the record then missed the atomics that had already landed), while a kernel
+// node always ran before the next one.
+static __global__ void clear_words_kernel(unsigned* __restrict__ p, int n) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) p[i] = 0u;
+}
+static inline hipError_t clear_words(void* p, int n_words, hipStream_t stream) {
+    hipLaunchKernelGGL(clear_words_kernel, dim3(1), dim3(64), 0, stream, static_cast<unsigned*>(p), n_words);
+    return hipGetLastError();
+}
+
 }  // namespace mdnvae

@@ -1558,7 +1558,7 @@ static int rows_touched(int pt, int SW, int SH) {
     return r < SH ? r : SH;
 }
 
-static void set_attr_once(const void* fn) {
+static void set_lds_limit(const void* fn) {
     (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
@@ -1572,8 +1572,7 @@ template <int CK, int SI, int TAPS, bool PLAIN>
 static void launch_conv_t(const ConvGeom& g, size_t lds, const float* x, const float* stats, const float* wp,
                           const float* bias, float* out, hipStream_t st) {
     constexpr int PT = 256, NTILE = 96;
-    static bool once = false;
-    if (!once) { set_attr_once(reinterpret_cast<const void*>(conv_mfma_kernel<CK, SI, TAPS, PLAIN>)); once = true; }
+    set_lds_limit(reinterpret_cast<const void*>(conv_mfma_kernel<CK, SI, TAPS, PLAIN>));
     const long Q = (long)g.B * g.SH * g.SW;
     dim3 grid((unsigned)((Q + PT - 1) / PT), g.CoutP / NTILE, 1);
     hipLaunchKernelGGL((conv_mfma_kernel<CK, SI, TAPS, PLAIN>), grid, dim3(256), lds, st, g, x, stats, wp, bias, out);
@@ -1621,8 +1620,7 @@ template <int PARTS, int WM, int WN, int IT, int TAPS, bool PLAIN>
 static void launch_conv_bf16_t(const ConvGeom& g, size_t lds, const float* x, const float* stats, const char* wp,
                                const float* bias, float* out, hipStream_t st) {
     constexpr int PT = 4 * WM * 32, NTILE = WN * 32;
-    static bool once = false;
-    if (!once) { set_attr_once(reinterpret_cast<const void*>(conv_bf16_kernel<PARTS, WM, WN, IT, TAPS, PLAIN>)); once = true; }
+    set_lds_limit(reinterpret_cast<const void*>(conv_bf16_kernel<PARTS, WM, WN, IT, TAPS, PLAIN>));
     const long Q = (long)g.B * g.SH * g.SW;
     dim3 grid((unsigned)((Q + PT - 1) / PT), (g.Cout + NTILE - 1) / NTILE, 1);
     hipLaunchKernelGGL((conv_bf16_kernel<PARTS, WM, WN, IT, TAPS, PLAIN>), grid, dim3(256), lds, st, g, x, stats, wp, bias,
@@ -1755,8 +1753,7 @@ static int conv2d_run(const float* x, const float* in_stats, int relu_in, const 
             g.slab_stride = rows * g.IWp + 1;
             const size_t lds = ((size_t)g.slab_stride + (size_t)((KS * KS + 1) & ~1) * WN * 32) * 4;
             MV_REQUIRE(lds <= 160 * 1024, E_SHAPE, "mdnvae_conv2d: tile needs %zu bytes of LDS", lds);
-            static bool once = false;
-            if (!once) { set_attr_once(reinterpret_cast<const void*>(conv_stem_kernel<WAVES, WM, WN>)); once = true; }
+            set_lds_limit(reinterpret_cast<const void*>(conv_stem_kernel<WAVES, WM, WN>));
             dim3 grid((OH * OW + PT - 1) / PT, g.CoutP / (WN * 32), B);
             hipLaunchKernelGGL((conv_stem_kernel<WAVES, WM, WN>), grid, dim3(WAVES * 64), lds, st, g, KS, x, packed_w,
                                bias, out);
@@ -1886,8 +1883,7 @@ int mdnvae_conv2d_wgrad(const float* x, const float* in_stats, int relu_in, cons
         const size_t red = (size_t)4 * 64 * 65 * 4;
         if (lds < red) lds = red;
         MV_REQUIRE(lds <= 160 * 1024, E_SHAPE, "mdnvae_conv2d_wgrad: needs %zu bytes of LDS", lds);
-        static bool once = false;
-        if (!once) { set_attr_once(reinterpret_cast<const void*>(conv_stem_wgrad_kernel)); once = true; }
+        set_lds_limit(reinterpret_cast<const void*>(conv_stem_wgrad_kernel));
         hipLaunchKernelGGL(conv_stem_wgrad_kernel, dim3(1, 1, Gz), dim3(256), lds, st, g, KS, x, grad_out, ptw, spg,
                            workspace);
         MV_LAUNCH_CHECK("conv_stem_wgrad_kernel");
@@ -1911,12 +1907,8 @@ int mdnvae_conv2d_wgrad(const float* x, const float* in_stats, int relu_in, cons
             if (need <= WGRAD_FLAT_LDS) { nr = k; GS = gs; SS = ss; lds = need; }
         }
         if (nr > 0) {
-            static bool once_flat = false;
-            if (!once_flat) {
-                set_attr_once(reinterpret_cast<const void*>(conv_wgrad_flat_kernel<false>));
-                set_attr_once(reinterpret_cast<const void*>(conv_wgrad_flat_kernel<true>));
-                once_flat = true;
-            }
+            set_lds_limit(reinterpret_cast<const void*>(conv_wgrad_flat_kernel<false>));
+            set_lds_limit(reinterpret_cast<const void*>(conv_wgrad_flat_kernel<true>));
             dim3 grid((Cout + 63) / 64, (Cin + 63) / 64, Gz);
             if (in_stats)
                 hipLaunchKernelGGL(conv_wgrad_flat_kernel<true>, grid, dim3(WG_NT), lds, st, B, Cin, Cout, H, W, x, in_stats,
@@ -1955,12 +1947,8 @@ int mdnvae_conv2d_wgrad(const float* x, const float* in_stats, int relu_in, cons
     g.slab_stride = (((rows_touched(ptw, OW, OH) - 1) * stride + KS) * g.IWp) | 1;   // odd: conflict-free B reads
     MV_REQUIRE(g.slab_stride <= 8 * 64, E_SHAPE, "mdnvae_conv2d_wgrad: slab of %d floats per channel is too large",
                g.slab_stride);
-    static bool once = false;
-    if (!once) {
-        set_attr_once(reinterpret_cast<const void*>(conv_wgrad_kernel<false>));
-        set_attr_once(reinterpret_cast<const void*>(conv_wgrad_kernel<true>));
-        once = true;
-    }
+    set_lds_limit(reinterpret_cast<const void*>(conv_wgrad_kernel<false>));
+    set_lds_limit(reinterpret_cast<const void*>(conv_wgrad_kernel<true>));
     dim3 grid((Cout + 63) / 64, (Cin + 63) / 64, Gz);
     if (in_stats)
         hipLaunchKernelGGL(conv_wgrad_kernel<true>, grid, dim3(WG_NT), best_lds, st, g, x, in_stats, grad_out, ptw,
@@ -1980,8 +1968,7 @@ int mdnvae_conv2d_wgrad(const float* x, const float* in_stats, int relu_in, cons
 template <int S, int PARTS, int RW>
 static void launch_wgrad_bf16(const WgradBf16& p, dim3 grid, size_t lds, const float* x, const float* stats,
                               const float* grad_out, float* workspace, hipStream_t st) {
-    static bool once = false;
-    if (!once) { set_attr_once(reinterpret_cast<const void*>(conv_wgrad_bf16_kernel<S, PARTS, RW>)); once = true; }
+    set_lds_limit(reinterpret_cast<const void*>(conv_wgrad_bf16_kernel<S, PARTS, RW>));
     hipLaunchKernelGGL((conv_wgrad_bf16_kernel<S, PARTS, RW>), grid, dim3(256), lds, st, p, x, stats, grad_out, workspace);
 }
 
@@ -2014,10 +2001,6 @@ extern "C" int mdnvae_conv2d_wgrad_bf16(const float* x, const float* in_stats, i
         for (int nr = 1; nr <= OH && nr <= 16; ++nr)
             if (lds_of(nr) <= cap) best = nr;
         if (best) break;
-    }
-    if (const char* e = getenv("MDNVAE_WGRAD_NR")) {                  // tuning knob: rows per chunk
-        const int nr = atoi(e);
-        if (nr >= 1 && nr <= OH && lds_of(nr) <= 156 * 1024) best = nr;
     }
     MV_REQUIRE(best > 0, E_SHAPE, "mdnvae_conv2d_wgrad_bf16: no chunk of output rows fits in LDS (OW = %d)", OW);
     p.nr = best;

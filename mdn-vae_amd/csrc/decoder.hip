@@ -1278,22 +1278,17 @@ int mdnvae_decoder_fwd(const float* z, const float* wt, int B, int N, int L, int
     DecArgs a{B, N, L, R, NL, acts, epi_act, icpt_w != nullptr, do_exp, xlat_channels, components};
     const int ntiles = (B + CH_TS - 1) / CH_TS;
     const size_t fwd_lds = sizeof(float) * ((size_t)2 * KP * CH_LD);
-    static bool fwd_attr_set = false;
-    if (!fwd_attr_set) {
+    {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(chain_fwd_mfma_kernel),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         MV_REQUIRE(e == hipSuccess, (int)e, "mdnvae_decoder_fwd: cannot raise the LDS limit: %s", hipGetErrorString(e));
-        fwd_attr_set = true;
     }
-    static const bool rows_off = getenv("MDNVAE_CHAIN_ROWS_OFF") != nullptr;       // tuning knob
-    if (B >= CR_TS * 128 && !rows_off) {
+    if (B >= CR_TS * 128) {
         // enough 64-sample tiles for half the chip and more: the wave-per-16-samples form
-        static bool rows_attr_set = false;
-        if (!rows_attr_set) {
+        {
             const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(chain_fwd_rows_kernel),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             MV_REQUIRE(e == hipSuccess, (int)e, "mdnvae_decoder_fwd: cannot raise the LDS limit: %s", hipGetErrorString(e));
-            rows_attr_set = true;
         }
         const int rtiles = (B + CR_TS - 1) / CR_TS;
         const size_t lds = sizeof(float) * ((size_t)2 * KP * NP + (size_t)CR_WAVES * CR_ROWS * CR_LD);
@@ -1335,12 +1330,10 @@ int mdnvae_decoder_bwd(const float* z, const float* wt, const float* wn, int B, 
     DecArgs a{B, N, L, R, NL, acts, epi_act, icpt_w != nullptr, do_exp, xlat_channels, components};
     const size_t lds = chain_bwd_lds_bytes(NL);
     MV_REQUIRE(lds <= 160 * 1024, E_SHAPE, "mdnvae_decoder_bwd: needs %zu bytes of LDS", lds);
-    static bool attr_set = false;
-    if (!attr_set) {
+    {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(chain_bwd_mfma_kernel),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         MV_REQUIRE(e == hipSuccess, (int)e, "mdnvae_decoder_bwd: cannot raise the LDS limit: %s", hipGetErrorString(e));
-        attr_set = true;
     }
     hipStream_t st = (hipStream_t)stream;
     if (!grad_out) {
@@ -1354,14 +1347,11 @@ int mdnvae_decoder_bwd(const float* z, const float* wt, const float* wn, int B, 
     }
     MV_LAUNCH_CHECK("outer_grad_kernel");
     const int ntiles = (B + CH_TS - 1) / CH_TS;
-    static const bool rows_off = getenv("MDNVAE_CHAIN_ROWS_OFF") != nullptr;       // tuning knob
-    if (layer_in_saved && !drop && B >= CR_TS * 128 && !rows_off) {
-        static bool rows_attr_set = false;
-        if (!rows_attr_set) {
+    if (layer_in_saved && !drop && B >= CR_TS * 128) {
+        {
             const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(chain_bwd_rows_kernel),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             MV_REQUIRE(e == hipSuccess, (int)e, "mdnvae_decoder_bwd: cannot raise the LDS limit: %s", hipGetErrorString(e));
-            rows_attr_set = true;
         }
         const int rtiles = (B + CR_TS - 1) / CR_TS;
         const size_t rows_lds = sizeof(float) * ((size_t)2 * KP * NP + (size_t)CR_WAVES * CR_ROWS * CR_LD);

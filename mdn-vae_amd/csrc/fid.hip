@@ -478,7 +478,7 @@ int mdnvae_symmetrize(const double* a, int d, double scale, double* out, void* s
 int mdnvae_trace_norm(const double* a, int d, double* out2, void* stream) {
     MV_REQUIRE(d >= 1 && a && out2, E_ARG, "mdnvae_trace_norm: bad argument");
     hipStream_t st = (hipStream_t)stream;
-    const hipError_t e = hipMemsetAsync(out2, 0, 2 * sizeof(double), st);
+    const hipError_t e = clear_words(out2, 4, st);
     MV_REQUIRE(e == hipSuccess, (int)e, "mdnvae_trace_norm: clearing the result failed: %s", hipGetErrorString(e));
     // one workgroup up to 256 rows: small matrices keep a fixed summation order
     hipLaunchKernelGGL(trace_norm_kernel, dim3(d <= 256 ? 1u : 512u), dim3(256), 0, st, a, d, out2);
@@ -489,7 +489,7 @@ int mdnvae_trace_norm(const double* a, int d, double* out2, void* stream) {
 int mdnvae_inf_norm(const double* a, int d, double* out, void* stream) {
     MV_REQUIRE(d >= 1 && a && out, E_ARG, "mdnvae_inf_norm: bad argument");
     hipStream_t st = (hipStream_t)stream;
-    const hipError_t e = hipMemsetAsync(out, 0, sizeof(double), st);
+    const hipError_t e = clear_words(out, 2, st);
     MV_REQUIRE(e == hipSuccess, (int)e, "mdnvae_inf_norm: clearing the result failed: %s", hipGetErrorString(e));
     hipLaunchKernelGGL(inf_norm_kernel, dim3(d < 512 ? (unsigned)d : 512u), dim3(256), 0, st, a, d, out);
     MV_LAUNCH_CHECK("inf_norm_kernel");
@@ -499,7 +499,7 @@ int mdnvae_inf_norm(const double* a, int d, double* out, void* stream) {
 int mdnvae_ns_residual_gap(const double* w, int d, double* t, double* gap, void* stream) {
     MV_REQUIRE(d >= 1 && w && t && gap && w != t, E_ARG, "mdnvae_ns_residual_gap: bad argument (in-place is not supported)");
     hipStream_t st = (hipStream_t)stream;
-    const hipError_t e = hipMemsetAsync(gap, 0, sizeof(double), st);
+    const hipError_t e = clear_words(gap, 2, st);
     MV_REQUIRE(e == hipSuccess, (int)e, "mdnvae_ns_residual_gap: clearing gap failed: %s", hipGetErrorString(e));
     const unsigned tiles = (unsigned)((d + 31) / 32);
     hipLaunchKernelGGL(ns_residual_gap_kernel, dim3(tiles, tiles), dim3(256), 0, st, w, d, t, gap);

@@ -335,13 +335,11 @@ int mdnvae_ssim(const float* a, const float* b, long count, int n, float data_ra
     MV_REQUIRE(count <= 0x7fffffffL, E_SHAPE, "mdnvae_ssim: too many pairs for one launch");
     if (count == 0) return 0;
     MV_REQUIRE(a && b && out, E_ARG, "mdnvae_ssim: null pointer");
-    static bool attr_set = false;
-    if (!attr_set) {
+    {
         // two 128 x 128 images; the kernel's static LDS comes on top of this
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ssim_kernel),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
         MV_REQUIRE(e == hipSuccess, (int)e, "mdnvae_ssim: cannot raise the LDS limit: %s", hipGetErrorString(e));
-        attr_set = true;
     }
     hipLaunchKernelGGL(ssim_kernel, dim3((unsigned)count), dim3(256), sizeof(float) * 2 * n * n, (hipStream_t)stream, a, b,
                        n, data_range, out);
@@ -355,13 +353,11 @@ int mdnvae_graph_features(const float* mats, long count, int n, int weighted_pat
     MV_REQUIRE(count <= 0x7fffffffL, E_SHAPE, "mdnvae_graph_features: too many matrices for one launch");
     if (count == 0) return 0;
     MV_REQUIRE(mats && out, E_ARG, "mdnvae_graph_features: null pointer");
-    static bool attr_set = false;
-    if (!attr_set) {
+    {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(graph_features_kernel),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024);
         MV_REQUIRE(e == hipSuccess, (int)e, "mdnvae_graph_features: cannot raise the LDS limit: %s",
                    hipGetErrorString(e));
-        attr_set = true;
     }
     const size_t lds = sizeof(float) * (size_t)2 * n * (n + 1);
     hipLaunchKernelGGL(graph_features_kernel, dim3((unsigned)count), dim3(256), lds, (hipStream_t)stream, mats, n,

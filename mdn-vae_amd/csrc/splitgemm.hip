@@ -63,6 +63,7 @@ __device__ __forceinline__ void sg_emit(const float (&v)[8], char* dst, int part
 // its 22 bits as long as it is within 2^-17 of the tensor's largest one, below that its low part thins out
 // and the absolute error stays under 2^-29 of the largest entry.
 typedef _Float16 sg_hfrag __attribute__((ext_vector_type(8)));
+constexpr float SG_UNIT_F16 = 16384.0f;       // what a row of ones holds in a scaled fp16 operand (exact at every scale)
 
 // the power of two that brings a magnitude with bit pattern `bits` (the tensor's largest) into [2^14, 2^15)
 __device__ __forceinline__ float sg_pow2_scale(unsigned bits) {
@@ -175,6 +176,8 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict
 // ReLU backward of a layer whose outputs are the gate, done while its output gradient is split.  ones_col:
 // operand row R (one past the source's columns) is all ones over k < Kd, so that the product's row R is
 // the column sum of the other operand (a bias gradient).  parts: how many of the three parts are written.
+// With amax (two fp16 parts) that row holds 2^14 whatever the tensor's scale - ones times the scale could leave
+// fp16's range - and the product is told which row it is (unit_row of split_gemm_kernel).
 template <bool VEC>
 __global__ __launch_bounds__(256) void split_cols_kernel(const float* __restrict__ src, const float* __restrict__ gate,
                                                          int Kd, int R, long ld, int ones_col, int parts, int row_tile0,
@@ -206,7 +209,7 @@ __global__ __launch_bounds__(256) void split_cols_kernel(const float* __restrict
                             const float v = src[(long)kk * ld + col + e];
                             av[e] = (gate && !(gate[(long)kk * ld + col + e] > 0.0f)) ? 0.0f : v;
                         } else if (ones_col && col + e == R) {
-                            av[e] = 1.0f;
+                            av[e] = amax ? SG_UNIT_F16 / sg_pow2_scale(scale_bits) : 1.0f;
                         }
                     }
                 }
@@ -233,7 +236,8 @@ __global__ __launch_bounds__(256) void split_cols_kernel(const float* __restrict
 //   the forward product's operand (operand row = sample, k = column, all ld columns; two fp16 parts of
 //   src * 2^e(amax), as split_rows_kernel writes them) and
 //   the weight-gradient product's operand (operand row = column c < R, plus the row of ones, k = sample; `parts`
-//   bf16 parts, as split_cols_kernel writes them).
+//   bf16 parts, as split_cols_kernel writes them - or, parts == 0, two fp16 parts at the scale of the forward
+//   operand with 2^14 in the unit row).
 // One workgroup: 64 samples x 32 columns through LDS.  ld a multiple of 32 columns' worth of tiles (grid.x * 32 >= ld
 // and >= R + ones_col), 16-byte aligned rows.
 __global__ __launch_bounds__(256) void split_both_kernel(const float* __restrict__ src, int Kd, int R, long ld, int ones_col,
@@ -267,7 +271,17 @@ __global__ __launch_bounds__(256) void split_both_kernel(const float* __restrict
                 const bool in_k = kb + q * 8 + e < Kd;
                 v[e] = c < R ? tile[q * 8 + e][r] : ((ones_col && c == R && in_k) ? 1.0f : 0.0f);
             }
-            sg_emit(v, out_cols + ((long)ct * KS_cols + ks) * SG_STEP + h * 512 + r * 16, parts);
+            char* dst = out_cols + ((long)ct * KS_cols + ks) * SG_STEP + h * 512 + r * 16;
+            if (parts == 0) {
+                const float s = sg_pow2_scale(scale_bits);
+                if (c == R) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] *= SG_UNIT_F16 / s;
+                }
+                sg_emit_f16(v, s, dst);
+            } else {
+                sg_emit(v, dst, parts);
+            }
         }
     }
     {   // forward operand: thread = (sample sr of the block, eight consecutive columns pc)
@@ -298,8 +312,11 @@ template <int J>
 __global__ __launch_bounds__(256) void split_cols_dgrad_kernel(const float* __restrict__ gpre, const float* __restrict__ w,
                                                                const float* __restrict__ dense,
                                                                const float* __restrict__ gate, int Kd, int R, int parts,
-                                                               int row_tile0, int KS, char* __restrict__ out) {
+                                                               int row_tile0, int KS, const unsigned* __restrict__ amax,
+                                                               char* __restrict__ out) {
     static_assert(J % 16 == 0 && J <= 128, "the inner dimension runs in groups of 16; the w slice must fit static LDS");
+    // amax != NULL: two fp16 parts of g * 2^e(*amax); *amax bounds |g| from above (dgrad_bound_kernel)
+    const float f16_scale = amax ? sg_pow2_scale(sg_absmax(amax)) : 0.0f;
     __shared__ __attribute__((aligned(16))) float wsl[J * DG_LDW];
     __shared__ float tile[64][65];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -385,9 +402,43 @@ __global__ __launch_bounds__(256) void split_cols_dgrad_kernel(const float* __re
                         const float gsum = tile[q * 8 + e][half * 32 + r] + d[half][e];
                         v[e] = (c < R && r0 + q * 8 + e < Kd && y[half][e] > 0.0f) ? gsum : 0.0f;
                     }
-                    sg_emit(v, out + ((long)(row_tile0 + blockIdx.y * 2 + half) * KS + ks) * SG_STEP + h * 512 + r * 16, parts);
+                    char* dst = out + ((long)(row_tile0 + blockIdx.y * 2 + half) * KS + ks) * SG_STEP + h * 512 + r * 16;
+                    if (amax) sg_emit_f16(v, f16_scale, dst);
+                    else sg_emit(v, dst, parts);
                 }
             }
+        }
+    }
+}
+
+// An upper bound of |gpre . w + dense| over all entries, from the largest magnitudes of gpre and dense and the
+// largest column sum of |w| [J][R]: amax_out = max(itself, |gpre|max * max_c sum_j |w[j][c]| + |dense|max).  A bound
+// a few binades above the true maximum costs the fp16 split nothing that shows (its absolute error is 2^-29 of
+// the scale's magnitude), and it needs no pass over the product.  One workgroup per 32 columns: thread (c, q)
+// sums rows q, q + 8, ... of its column.
+__global__ __launch_bounds__(256) void dgrad_bound_kernel(const unsigned* __restrict__ amax_gpre, const float* __restrict__ w,
+                                                          int J, int R, const unsigned* __restrict__ amax_dense,
+                                                          unsigned* __restrict__ amax_out) {
+    __shared__ float part[8][32];
+    const int cl = threadIdx.x & 31, q = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    float s = 0.0f;
+    if (c < R)
+        for (int j = q; j < J; j += 8) s += fabsf(w[(long)j * R + c]);
+    part[q][cl] = s;
+    const float gmax = __uint_as_float(sg_absmax(amax_gpre));
+    const float dmax = amax_dense ? __uint_as_float(sg_absmax(amax_dense)) : 0.0f;
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        float col = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) col += part[i][cl];
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) col = fmaxf(col, __shfl_xor(col, o));
+        if (threadIdx.x == 0) {
+            // rounded up a little: the sums above are themselves rounded
+            const float bound = (gmax * col) * 1.0001f + dmax;
+            atomicMax(amax_out + (blockIdx.x & (MDNVAE_ABSMAX_SLOTS - 1)), __float_as_uint(bound));
         }
     }
 }
@@ -417,7 +468,9 @@ __global__ __launch_bounds__(512) void split_gemm_kernel(const char* __restrict_
                                                          int KS, int ntm, int ntn, int m_valid,
                                                          const float* __restrict__ bias0, const float* __restrict__ bias1,
                                                          float* __restrict__ out0, float* __restrict__ out1, int n_split,
-                                                         long ld_out, int n_valid, int accumulate) {
+                                                         long ld_out, int n_valid, int accumulate, int unit_row) {
+    // unit_row (F16 only, -1 = none): the row of A that holds SG_UNIT_F16 in place of scaled ones; its products
+    // are brought back with that factor instead of A's scale, so the output row is the column sum of B
     static_assert(!F16 || TERMS == 3, "two fp16 parts make a three-term product");
     static_assert(!DEEP || TERMS == 3, "the four-stage ring is sized for two-part operands");
     constexpr int TA = 2 * WM, TB = 8;                   // fragment rows-tiles of A / B per workgroup
@@ -588,7 +641,9 @@ __global__ __launch_bounds__(512) void split_gemm_kernel(const char* __restrict_
                 for (int e = 0; e < 16; ++e) {
                     const int m = m0 + (e & 3) + 8 * (e >> 2);
                     if (m < m_valid && n < n_valid)
-                        unsafeAtomicAdd(out + n + (long)m * ld_out, F16 ? acc[i][j][e] * unscale_a * unscale_b : acc[i][j][e]);
+                        unsafeAtomicAdd(out + n + (long)m * ld_out,
+                                        F16 ? acc[i][j][e] * (m == unit_row ? 1.0f / SG_UNIT_F16 : unscale_a) * unscale_b
+                                            : acc[i][j][e]);
                 }
             }
         }
@@ -605,7 +660,7 @@ __global__ __launch_bounds__(512) void split_gemm_kernel(const char* __restrict_
             for (int e = 0; e < 16; ++e) {
                 const int m = m0 + (e & 3) + 8 * (e >> 2);
                 float v = acc[i][j][e];
-                if (F16) v = v * unscale_a * unscale_b;
+                if (F16) v = v * (m == unit_row ? 1.0f / SG_UNIT_F16 : unscale_a) * unscale_b;
                 if (EPI == SG_EPI_BIAS_RELU) v = fmaxf(v + bv[j], 0.0f);
                 if (EPI == SG_EPI_BIAS) v += bv[j];
                 if (whole) col[(long)m * ld_out] = v;
@@ -659,7 +714,7 @@ int mdnvae_absmax(const float* src, long rows, long cols, long ld, float floor_v
     MV_REQUIRE(rows >= 0 && cols >= 0 && ld >= cols, E_ARG, "mdnvae_absmax: bad shape");
     MV_REQUIRE(absmax && (src || rows * cols == 0), E_ARG, "mdnvae_absmax: null pointer");
     if (reset) {
-        const hipError_t e = hipMemsetAsync(absmax, 0, MDNVAE_ABSMAX_SLOTS * sizeof(unsigned), (hipStream_t)stream);
+        const hipError_t e = clear_words(absmax, MDNVAE_ABSMAX_SLOTS, (hipStream_t)stream);
         MV_REQUIRE(e == hipSuccess, (int)e, "mdnvae_absmax: cannot clear the slot: %s", hipGetErrorString(e));
     }
     const long n = rows * cols;
@@ -705,7 +760,7 @@ int mdnvae_split_cols_f16(const float* src, const float* gate, long Kd, long R, 
 int mdnvae_split_rows_f16_cols(const float* src, long Kd, long R, long ld, int ones_row, int parts, const unsigned* absmax,
                                void* out_rows, void* out_cols, void* stream) {
     MV_REQUIRE(Kd >= 0 && R >= 0 && ld >= R, E_ARG, "mdnvae_split_rows_f16_cols: bad shape");
-    MV_REQUIRE(parts >= 1 && parts <= 3, E_ARG, "mdnvae_split_rows_f16_cols: parts must be 1, 2 or 3");
+    MV_REQUIRE(parts >= 0 && parts <= 3, E_ARG, "mdnvae_split_rows_f16_cols: parts must be 0 (fp16), 1, 2 or 3");
     if (Kd == 0 || ld == 0) return 0;
     MV_REQUIRE(src && absmax && out_rows && out_cols, E_ARG, "mdnvae_split_rows_f16_cols: null pointer");
     MV_REQUIRE(ld % 16 == 0 && aligned16(src) && aligned16(out_rows) && aligned16(out_cols), E_ALIGN,
@@ -723,8 +778,8 @@ int mdnvae_split_cols(const float* src, long Kd, long R, long ld, long row_tile0
     return mdnvae_split_cols_gated(src, nullptr, Kd, R, ld, 0, 3, row_tile0, out, stream);
 }
 
-int mdnvae_split_cols_dgrad(const float* gpre, const float* w, const float* dense, const float* gate, long Kd, long R,
-                            long J, int parts, long row_tile0, void* out, void* stream) {
+static int split_cols_dgrad_impl(const float* gpre, const float* w, const float* dense, const float* gate, long Kd, long R,
+                                 long J, int parts, long row_tile0, const unsigned* amax, void* out, void* stream) {
     MV_REQUIRE(R >= 0 && Kd >= 0 && row_tile0 >= 0, E_ARG, "mdnvae_split_cols_dgrad: bad shape");
     MV_REQUIRE(J == 64 || J == 128, E_SHAPE, "mdnvae_split_cols_dgrad: the inner dimension must be 64 or 128 (got %ld)", J);
     MV_REQUIRE(parts >= 1 && parts <= 3, E_ARG, "mdnvae_split_cols_dgrad: parts must be 1, 2 or 3");
@@ -738,7 +793,7 @@ int mdnvae_split_cols_dgrad(const float* gpre, const float* w, const float* dens
     const long rb = nrb < (768 + cb - 1) / cb ? nrb : (768 + cb - 1) / cb;
 #define DG_LAUNCH(JJ)                                                                                                 \
     hipLaunchKernelGGL(split_cols_dgrad_kernel<JJ>, dim3((unsigned)rb, (unsigned)cb), dim3(256), 0, (hipStream_t)stream, \
-                       gpre, w, dense, gate, (int)Kd, (int)R, parts, (int)row_tile0, (int)KS, (char*)out)
+                       gpre, w, dense, gate, (int)Kd, (int)R, parts, (int)row_tile0, (int)KS, amax, (char*)out)
     if (J == 64) DG_LAUNCH(64);
     else DG_LAUNCH(128);
 #undef DG_LAUNCH
@@ -746,12 +801,38 @@ int mdnvae_split_cols_dgrad(const float* gpre, const float* w, const float* dens
     return 0;
 }
 
+int mdnvae_split_cols_dgrad(const float* gpre, const float* w, const float* dense, const float* gate, long Kd, long R,
+                            long J, int parts, long row_tile0, void* out, void* stream) {
+    return split_cols_dgrad_impl(gpre, w, dense, gate, Kd, R, J, parts, row_tile0, nullptr, out, stream);
+}
+
+int mdnvae_split_cols_dgrad_f16(const float* gpre, const float* w, const float* dense, const float* gate, long Kd, long R,
+                                long J, long row_tile0, const unsigned* absmax, void* out, void* stream) {
+    MV_REQUIRE(absmax, E_ARG, "mdnvae_split_cols_dgrad_f16: the largest-magnitude slot is NULL");
+    return split_cols_dgrad_impl(gpre, w, dense, gate, Kd, R, J, 2, row_tile0, absmax, out, stream);
+}
+
+int mdnvae_dgrad_bound(const unsigned* absmax_gpre, const float* w, long J, long R, const unsigned* absmax_dense, int reset,
+                       unsigned* absmax, void* stream) {
+    MV_REQUIRE(J >= 1 && R >= 1 && R <= 0x7fffffffL && J <= 0x7fffffffL, E_ARG, "mdnvae_dgrad_bound: bad shape");
+    MV_REQUIRE(absmax_gpre && w && absmax, E_ARG, "mdnvae_dgrad_bound: null pointer");
+    if (reset) {
+        const hipError_t e = clear_words(absmax, MDNVAE_ABSMAX_SLOTS, (hipStream_t)stream);
+        MV_REQUIRE(e == hipSuccess, (int)e, "mdnvae_dgrad_bound: cannot clear the slot: %s", hipGetErrorString(e));
+    }
+    hipLaunchKernelGGL(dgrad_bound_kernel, dim3((unsigned)((R + 31) / 32)), dim3(256), 0, (hipStream_t)stream, absmax_gpre, w,
+                       (int)J, (int)R, absmax_dense, absmax);
+    MV_LAUNCH_CHECK("dgrad_bound_kernel");
+    return 0;
+}
+
 static int split_gemm_impl(const void* a, const void* b, const unsigned* amax_a, const unsigned* amax_b, long M, long N,
                            long K, long m_valid, long n_valid, const float* bias0, const float* bias1, int relu,
                            int accumulate, float* out0, float* out1, long n_split, long ld_out, int tile_m, int terms,
-                           void* stream) {
+                           long unit_row, void* stream) {
     const bool f16 = amax_a != nullptr;
-    static const bool deep = getenv("MDNVAE_SG_SHALLOW") == nullptr;      // tuning knob: the two-buffer loop
+    MV_REQUIRE(unit_row >= -1 && unit_row < M, E_ARG, "mdnvae_split_gemm_f16: unit_row is -1 or a row of a");
+    constexpr bool deep = true;       // the four-stage ring; the two-buffer loop stays instantiable for comparison
     MV_REQUIRE(terms == 6 || terms == 3, E_ARG, "mdnvae_split_gemm: terms must be 6 (every product down to 2^-24) or 3");
     MV_REQUIRE(M >= 1 && N >= 1 && K >= 16 && m_valid >= 0 && m_valid <= M, E_ARG, "mdnvae_split_gemm: bad shape");
     MV_REQUIRE(n_valid >= 0 && n_valid <= n_split, E_ARG, "mdnvae_split_gemm: n_valid counts columns of one output (at most n_split)");
@@ -783,17 +864,14 @@ static int split_gemm_impl(const void* a, const void* b, const unsigned* amax_a,
 #define SG_LAUNCH_T(WM, EPI, TERMS, F16, DEEP)                                                                               \
     do {                                                                                                            \
         const size_t lds = (size_t)(2 * WM + 8) * (TERMS == 6 ? 6 : (DEEP ? 2 * SG_NBUF : 8)) * SG_FRAG;                                   \
-        static bool raised = false;                                                                                 \
-        if (!raised) {                                                                                              \
-            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(split_gemm_kernel<WM, EPI, TERMS, F16, DEEP>), \
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);       \
-            MV_REQUIRE(e == hipSuccess, (int)e, "mdnvae_split_gemm: cannot raise the LDS limit: %s",                \
-                       hipGetErrorString(e));                                                                       \
-            raised = true;                                                                                          \
-        }                                                                                                           \
+        /* per launch: the attribute belongs to the current device's copy of the kernel */                         \
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(split_gemm_kernel<WM, EPI, TERMS, F16, DEEP>), \
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);           \
+        MV_REQUIRE(e == hipSuccess, (int)e, "mdnvae_split_gemm: cannot raise the LDS limit: %s",                    \
+                   hipGetErrorString(e));                                                                           \
         hipLaunchKernelGGL((split_gemm_kernel<WM, EPI, TERMS, F16, DEEP>), dim3((unsigned)(ntm * ntn * (accumulate == 2 ? 2 : 1))), dim3(512), lds, st, \
                            (const char*)a, (const char*)b, amax_a, amax_b, KS, (int)ntm, (int)ntn, (int)m_valid, bias0, bias1,      \
-                           out0, out1 ? out1 : out0, (int)n_split, ld_out, (int)n_valid, accumulate);               \
+                           out0, out1 ? out1 : out0, (int)n_split, ld_out, (int)n_valid, accumulate, (int)unit_row); \
     } while (0)
     if (tile_m == 256) {
         if (relu) SG_LAUNCH(4, SG_EPI_BIAS_RELU);
@@ -814,15 +892,16 @@ int mdnvae_split_gemm(const void* a, const void* b, long M, long N, long K, long
                       const float* bias0, const float* bias1, int relu, int accumulate, float* out0, float* out1,
                       long n_split, long ld_out, int tile_m, int terms, void* stream) {
     return split_gemm_impl(a, b, nullptr, nullptr, M, N, K, m_valid, n_valid, bias0, bias1, relu, accumulate, out0, out1,
-                           n_split, ld_out, tile_m, terms, stream);
+                           n_split, ld_out, tile_m, terms, -1, stream);
 }
 
 int mdnvae_split_gemm_f16(const void* a, const void* b, const unsigned* absmax_a, const unsigned* absmax_b, long M, long N,
                           long K, long m_valid, long n_valid, const float* bias0, const float* bias1, int relu,
-                          int accumulate, float* out0, float* out1, long n_split, long ld_out, int tile_m, void* stream) {
+                          int accumulate, float* out0, float* out1, long n_split, long ld_out, int tile_m, long unit_row,
+                          void* stream) {
     MV_REQUIRE(absmax_a && absmax_b, E_ARG, "mdnvae_split_gemm_f16: a largest-magnitude slot is NULL");
     return split_gemm_impl(a, b, absmax_a, absmax_b, M, N, K, m_valid, n_valid, bias0, bias1, relu, accumulate, out0, out1,
-                           n_split, ld_out, tile_m, 3, stream);
+                           n_split, ld_out, tile_m, 3, unit_row, stream);
 }
 
 }  // extern "C"

@@ -181,7 +181,7 @@ int mdnvae_tri_fold(const float* w, long H, int N, int ld, float* out, void* str
 
 static int tri_clear_slot(unsigned* absmax, void* stream, const char* who) {
     MV_REQUIRE(absmax, E_ARG, "%s: the largest-magnitude slot is NULL", who);
-    const hipError_t e = hipMemsetAsync(absmax, 0, MDNVAE_ABSMAX_SLOTS * sizeof(unsigned), (hipStream_t)stream);
+    const hipError_t e = clear_words(absmax, MDNVAE_ABSMAX_SLOTS, (hipStream_t)stream);
     MV_REQUIRE(e == hipSuccess, (int)e, "%s: cannot clear the slot: %s", who, hipGetErrorString(e));
     return 0;
 }

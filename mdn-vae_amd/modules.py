@@ -385,26 +385,31 @@ class GCNVAE(nn.Module):
         self.fc22 = Linear(128, latent_dim)
         self.decoder = MultiChannelGCNDecoder(R=R, n_nodes=n_nodes, k=k, n_layers=n_layers, latent_dim=latent_dim)
 
-    def encode(self, x):
-        """`symmetric_input`: the batch is promised to hold symmetric matrices (what the data
-        preparation produces), so both first layers run on the packed upper triangle with folded
+    def first_layers(self, x):
+        """relu(fc11(x)), relu(fc12(x)) (function/MM_Gate.py:157-158) the way this model computes them.
+        `symmetric_input`: the batch is promised to hold symmetric matrices (what the data
+        preparation produces), so both layers run on the packed upper triangle with folded
         weights, half the GEMM work for the same sums.  The promise is checked on the device with
-        every batch; `check_inputs()` reports a violation."""
+        every batch; `check_inputs()` reports a violation.
+        Batches of at least ops.SPLIT_GEMM_MIN_BATCH take the hand-written split product, smaller ones the
+        library's fp32 GEMM: both are fp32-level arithmetic (results agree to a few 1e-7 of sum |x||w|),
+        but not bit for bit - a batch of 1023 and one of 1024 round differently."""
         if self.symmetric_input:
             split = self.first_layer_gemm == "split" and x.shape[0] >= ops.SPLIT_GEMM_MIN_BATCH
-            xmax = self._xmax if split and ops.SPLIT_FWD == "f16" else None
+            xmax = self._xmax if split and ops.ARITH_FWD == "f16x2" else None
             xt = ops.tri_pack(x, self.n_nodes, self._asym, xmax)
             if split:
-                a11, a12 = ops.sym_linear_pair(xt, self.fc11.weight, self.fc11.bias, self.fc12.weight, self.fc12.bias,
-                                               self.n_nodes, xmax)
-            else:
-                a11 = ops.sym_linear_act(xt, self.fc11.weight, self.fc11.bias, "relu", self.n_nodes)
-                a12 = ops.sym_linear_act(xt, self.fc12.weight, self.fc12.bias, "relu", self.n_nodes)
-        elif (self.first_layer_gemm == "split" and x.dim() == 2 and x.shape[0] >= ops.SPLIT_GEMM_MIN_BATCH
-              and not x.requires_grad):
-            a11, a12 = ops.linear_pair(x, self.fc11.weight, self.fc11.bias, self.fc12.weight, self.fc12.bias)
-        else:
-            a11, a12 = self.fc11(x, act="relu"), self.fc12(x, act="relu")
+                return ops.sym_linear_pair(xt, self.fc11.weight, self.fc11.bias, self.fc12.weight, self.fc12.bias,
+                                           self.n_nodes, xmax)
+            return (ops.sym_linear_act(xt, self.fc11.weight, self.fc11.bias, "relu", self.n_nodes),
+                    ops.sym_linear_act(xt, self.fc12.weight, self.fc12.bias, "relu", self.n_nodes))
+        if (self.first_layer_gemm == "split" and x.dim() == 2 and x.shape[0] >= ops.SPLIT_GEMM_MIN_BATCH
+                and not x.requires_grad):
+            return ops.linear_pair(x, self.fc11.weight, self.fc11.bias, self.fc12.weight, self.fc12.bias)
+        return self.fc11(x, act="relu"), self.fc12(x, act="relu")
+
+    def encode(self, x):
+        a11, a12 = self.first_layers(x)
         h11 = self.fc111(a11, act="relu")
         h12 = self.fc222(a12, act="relu")
         return self.fc21(h11), self.fc22(h12)

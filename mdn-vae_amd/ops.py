@@ -1,7 +1,6 @@
 """Autograd wrappers over the C ABI: each op's forward and backward are hand-written HIP
 kernels; nothing here computes on the host or falls back to eager PyTorch arithmetic."""
-import os
-import weakref
+import contextlib
 
 import torch
 
@@ -283,31 +282,54 @@ def _split_linear_ok(x, weight, bias):
 
 
 SPLIT_LINEAR = True
-# bf16 products per multiply-add in the weight-gradient products: 6 keeps every term down to 2^-24 (one
-# fp32 rounding); 3 keeps x1 w1 + x1 w2 + x2 w1 and drops terms of relative size <= 2^-16 each - about
-# 1e-5 of the gradient's norm, inside the 1e-4 the gradients are held to, at half the matrix-core work.  A
-# weight gradient feeds the optimiser only: nothing downstream amplifies its error, unlike an activation's.
-SPLIT_WGRAD_KSPLIT = not os.environ.get("MDNVAE_SPLIT_WGRAD_NO_KSPLIT")     # tuning knob
-SPLIT_WGRAD_TERMS = int(os.environ.get("MDNVAE_SPLIT_WGRAD_TERMS", "3"))
-if SPLIT_WGRAD_TERMS not in (3, 6):
-    raise RuntimeError("MDNVAE_SPLIT_WGRAD_TERMS must be 3 or 6")
+# Arithmetic of the hand-written split products (results are fp32 tensors in every case):
+#   "f16x2"  two fp16 parts per operand, three matrix-core products, each tensor scaled by a power of two taken from
+#            its largest magnitude: 22-bit operands, error 3 * 2^-22 of sum |a||b| - the level of an fp32 dot product;
+#   "bf16x6" three bf16 parts, six products, error 2^-24 of sum |a||b|, at twice the matrix-core work;
+#   "bf16x3" (weight gradients only) two bf16 parts, three products: up to 3 * 2^-16 per product - about 1e-5 of a
+#            gradient's norm, 1e-3 of single entries; a little faster than "f16x2" (no magnitude bounds to take).
+# ARITH_FWD covers the products whose result feeds further layers (forward, data gradient), ARITH_WGRAD the weight
+# and bias gradients.  They are process-wide settings of this module, changed with arithmetic(...) - nothing reads
+# the environment - and an autograd node uses in its backward what was set when its forward ran.
+ARITH_FWD = "f16x2"
+ARITH_WGRAD = "f16x2"
+SPLIT_WGRAD_KSPLIT = True            # long-k products with few output tiles: two workgroups per tile
 
 
-# Products whose result feeds further layers (forward, data gradient): "f16" = two fp16 parts per operand, three
-# products, each tensor scaled by a power of two taken from its largest magnitude (22-bit operands: an fp32 dot
-# product's accuracy at half the matrix-core work); "bf16" = three bf16 parts, six products.
-SPLIT_FWD = os.environ.get("MDNVAE_SPLIT_FWD", "f16")
-if SPLIT_FWD not in ("f16", "bf16"):
-    raise RuntimeError("MDNVAE_SPLIT_FWD must be f16 or bf16")
+@contextlib.contextmanager
+def arithmetic(fwd=None, wgrad=None, factored_dgrad=None):
+    """Run the enclosed forward passes (and the backward passes of the graphs they build) with another arithmetic
+    for the split products; see ARITH_FWD / ARITH_WGRAD.  factored_dgrad=False: every data gradient is formed and
+    handed to autograd (see _FactoredGrad)."""
+    global ARITH_FWD, ARITH_WGRAD, FACTORED_DGRAD
+    if fwd not in (None, "f16x2", "bf16x6"):
+        raise ValueError(f"arithmetic: fwd must be 'f16x2' or 'bf16x6' (got {fwd!r})")
+    if wgrad not in (None, "f16x2", "bf16x3", "bf16x6"):
+        raise ValueError(f"arithmetic: wgrad must be 'f16x2', 'bf16x3' or 'bf16x6' (got {wgrad!r})")
+    saved = ARITH_FWD, ARITH_WGRAD, FACTORED_DGRAD
+    ARITH_FWD = fwd or ARITH_FWD
+    ARITH_WGRAD = wgrad or ARITH_WGRAD
+    FACTORED_DGRAD = FACTORED_DGRAD if factored_dgrad is None else bool(factored_dgrad)
+    try:
+        yield
+    finally:
+        ARITH_FWD, ARITH_WGRAD, FACTORED_DGRAD = saved
 
 
 ABSMAX_SLOTS = 64      # MDNVAE_ABSMAX_SLOTS: partial maxima per tensor
 
 
-def _absmax_slots(n, device):
+def _absmax_slots(n, device, zero=False):
     """n largest-magnitude records (ABSMAX_SLOTS bit patterns of floats each) on the device, as a list; the
-    kernels that fill them clear them."""
-    return list(torch.empty(n, ABSMAX_SLOTS, dtype=torch.int32, device=device).unbind(0))
+    kernels that fill them clear them first (reset) - or, zero=True, they start cleared by one fill."""
+    return list((torch.zeros if zero else torch.empty)(n, ABSMAX_SLOTS, dtype=torch.int32, device=device).unbind(0))
+
+
+def _check_absmax_slot(slot, device):
+    if (not torch.is_tensor(slot) or slot.dtype != torch.int32 or slot.numel() < ABSMAX_SLOTS or not slot.is_contiguous()
+            or slot.device != device):
+        raise RuntimeError(f"a largest-magnitude record is a contiguous int32[{ABSMAX_SLOTS}] tensor on {device} "
+                           f"(got {getattr(slot, 'dtype', type(slot))}, {tuple(getattr(slot, 'shape', ()))})")
 
 
 def absmax_value(slot):
@@ -329,14 +351,14 @@ def _split_linear_fwd(x, weight, bias, act):
     wb[(n_out + 31) // 32 * (Kp // 16) * 3072:].zero_()
     xa = _split_operand(Mp, Kp, dev)
     y = torch.empty(B, n_out, dtype=torch.float32, device=dev)
-    if SPLIT_FWD == "f16":
+    if ARITH_FWD == "f16x2":
         mx = _absmax_slots(2, dev)
         _absmax(weight, mx[0])
         _absmax(x, mx[1])
         call("mdnvae_split_rows_f16", ptr(weight, "weight"), n_out, K, K, 0, mx[0].data_ptr(), wb.data_ptr(), stream())
         call("mdnvae_split_rows_f16", ptr(x, "x"), B, K, K, 0, mx[1].data_ptr(), xa.data_ptr(), stream())
         call("mdnvae_split_gemm_f16", xa.data_ptr(), wb.data_ptr(), mx[1].data_ptr(), mx[0].data_ptr(), Mp, Np, Kp, B, n_out,
-             ptr(bias, "bias"), None, int(act == ACTS["relu"]), 0, ptr(y), None, Np, n_out, 128, stream())
+             ptr(bias, "bias"), None, int(act == ACTS["relu"]), 0, ptr(y), None, Np, n_out, 128, -1, stream())
     else:
         call("mdnvae_split_rows", ptr(weight, "weight"), n_out, K, K, 0, wb.data_ptr(), stream())
         call("mdnvae_split_rows", ptr(x, "x"), B, K, K, 0, xa.data_ptr(), stream())
@@ -357,7 +379,7 @@ def _split_linear_dgrad(gpre, weight):
     wb = _split_operand(Np, Kp, dev)
     wb[(n_in + 31) // 32 * (Kp // 16) * 3072:].zero_()
     gx = torch.empty(B, n_in, dtype=torch.float32, device=dev)
-    if SPLIT_FWD == "f16":
+    if ARITH_FWD == "f16x2":
         mx = _absmax_slots(2, dev)
         _absmax(gpre, mx[0])
         _absmax(weight, mx[1])
@@ -365,7 +387,7 @@ def _split_linear_dgrad(gpre, weight):
         call("mdnvae_split_cols_f16", ptr(weight, "weight"), None, n_out, n_in, n_in, 0, 0, mx[1].data_ptr(), wb.data_ptr(),
              stream())
         call("mdnvae_split_gemm_f16", ga.data_ptr(), wb.data_ptr(), mx[0].data_ptr(), mx[1].data_ptr(), Mp, Np, Kp, B, n_in,
-             None, None, 0, 0, ptr(gx), None, Np, n_in, 128, stream())
+             None, None, 0, 0, ptr(gx), None, Np, n_in, 128, -1, stream())
         return gx
     call("mdnvae_split_rows", ptr(gpre, "grad_pre"), B, n_out, n_out, 0, ga.data_ptr(), stream())
     call("mdnvae_split_cols", ptr(weight, "weight"), n_out, n_in, n_in, 0, wb.data_ptr(), stream())
@@ -373,7 +395,7 @@ def _split_linear_dgrad(gpre, weight):
     return gx
 
 
-def _split_linear_wgrad(gpre, x, param):
+def _split_linear_wgrad(gpre, x, param, arith):
     """grad_w [n_out, n_in] = gpre^T . x; None when it was added straight into param.grad"""
     B, n_out = gpre.shape
     n_in = x.shape[1]
@@ -381,14 +403,24 @@ def _split_linear_wgrad(gpre, x, param):
     Kp, Mp, Np = _round_up(B, 16), _round_up(n_out, 128), _round_up(n_in, 256)
     pa = _split_operand(Mp, Kp, dev)
     pa[(n_out + 31) // 32 * (Kp // 16) * 3072:].zero_()
-    call("mdnvae_split_cols", ptr(gpre, "grad_pre"), B, n_out, n_out, 0, pa.data_ptr(), stream())
     xb = _split_operand(Np, Kp, dev)
     xb[(n_in + 31) // 32 * (Kp // 16) * 3072:].zero_()
-    call("mdnvae_split_cols", ptr(x, "x"), B, n_in, n_in, 0, xb.data_ptr(), stream())
     target = _grad_target(param)
     out = target if target is not None else torch.empty(n_out, n_in, dtype=torch.float32, device=dev)
-    call("mdnvae_split_gemm", pa.data_ptr(), xb.data_ptr(), Mp, Np, Kp, n_out, n_in, None, None, 0, int(target is not None),
-         ptr(out), None, Np, n_in, 128, SPLIT_WGRAD_TERMS, stream())
+    if arith == "f16x2":
+        mx = _absmax_slots(2, dev)
+        _absmax(gpre, mx[0])
+        _absmax(x, mx[1])
+        call("mdnvae_split_cols_f16", ptr(gpre, "grad_pre"), None, B, n_out, n_out, 0, 0, mx[0].data_ptr(), pa.data_ptr(), stream())
+        call("mdnvae_split_cols_f16", ptr(x, "x"), None, B, n_in, n_in, 0, 0, mx[1].data_ptr(), xb.data_ptr(), stream())
+        call("mdnvae_split_gemm_f16", pa.data_ptr(), xb.data_ptr(), mx[0].data_ptr(), mx[1].data_ptr(), Mp, Np, Kp, n_out, n_in,
+             None, None, 0, int(target is not None), ptr(out), None, Np, n_in, 128, -1, stream())
+    else:
+        parts, terms = (3, 6) if arith == "bf16x6" else (2, 3)
+        call("mdnvae_split_cols_gated", ptr(gpre, "grad_pre"), None, B, n_out, n_out, 0, parts, 0, pa.data_ptr(), stream())
+        call("mdnvae_split_cols_gated", ptr(x, "x"), None, B, n_in, n_in, 0, parts, 0, xb.data_ptr(), stream())
+        call("mdnvae_split_gemm", pa.data_ptr(), xb.data_ptr(), Mp, Np, Kp, n_out, n_in, None, None, 0, int(target is not None),
+             ptr(out), None, Np, n_in, 128, terms, stream())
     if target is not None:
         _grad_added(param)
         return None
@@ -397,19 +429,38 @@ def _split_linear_wgrad(gpre, x, param):
 
 class _FactoredGrad:
     """Where the gradient of a tensor may be left as a product instead of being formed: the producer of y
-    (the first-layer pair) registers one per output, the dense layer that consumes y finds it at forward
-    time and, in its backward, hands over (grad_pre, weight) - its data gradient is grad_pre . weight - and
-    returns zeros that occupy no memory.  The producer's backward forms the product inside the pass that
-    needs it anyway (ReLU gate + operand split).  Anything else that flows back into y arrives the usual
-    way and is added."""
-    __slots__ = ("taken", "gpre", "weight", "__weakref__")
+    (the first-layer pair) hangs one on each output tensor OBJECT, the dense layer that consumes that very
+    object (not a view, slice, reshape or detached alias of it: those are other objects and never carry the
+    record) finds it at forward time and, in its backward, hands over (grad_pre, weight) - its data gradient
+    is grad_pre . weight - and returns zeros that occupy no memory.  The producer's backward forms the
+    product inside the pass that needs it anyway (ReLU gate + operand split).  Anything else that flows
+    back into y arrives the usual way and is added.
 
-    def __init__(self):
-        self.taken, self.gpre, self.weight = False, None, None
+    Consequence for callers: the gradient of y itself is then not observable - torch.autograd.grad(loss, y),
+    y.register_hook and y.retain_grad() would see the zeros.  A y that already has hooks or retains its
+    gradient when the consumer runs is therefore left alone (dense data gradient); to observe y's gradient
+    in every case run under factored_dgrad(False)."""
+    __slots__ = ("shape", "taken", "gpre", "weight")
+
+    def __init__(self, shape):
+        self.shape, self.taken, self.gpre, self.weight = tuple(shape), False, None, None
 
 
-_FACTORED_SLOTS = weakref.WeakValueDictionary()      # y.data_ptr() -> slot, alive as long as the producer's graph node
-FACTORED_DGRAD = not os.environ.get("MDNVAE_NO_FACTORED_DGRAD")     # tuning knob
+_FACTORED_ATTR = "_mdnvae_factored_grad"
+FACTORED_DGRAD = True
+
+
+def _factored_slot_of(x, weight):
+    """The record x carries if this consumer may take it: x is the producer's own output (same object, same
+    [B,H] shape, dense rows), part of the graph, unobserved, and the weight is one the producer's kernel handles."""
+    slot = getattr(x, _FACTORED_ATTR, None)
+    if slot is None or slot.taken or not x.requires_grad or tuple(x.shape) != slot.shape or not x.is_contiguous():
+        return None
+    if x.retains_grad or getattr(x, "_backward_hooks", None):
+        return None
+    if weight.dim() != 2 or weight.shape[1] != slot.shape[1] or weight.shape[0] not in (64, 128) or weight.shape[1] % 4:
+        return None
+    return slot
 
 
 _ZERO_SCALARS = {}
@@ -447,11 +498,10 @@ class _LinearAct(torch.autograd.Function):
         ctx.act = act
         ctx.has_bias = bias is not None
         ctx.params = (weight, bias)              # the objects whose .grad a sink may add into
-        slot = _FACTORED_SLOTS.get(x.data_ptr()) if x.dim() == 2 else None
-        ctx.factored = None
-        if slot is not None and not slot.taken and weight.shape[0] in (64, 128) and weight.shape[1] % 4 == 0:
-            slot.taken = True
-            ctx.factored = slot
+        ctx.arith_wgrad = ARITH_WGRAD
+        ctx.factored = _factored_slot_of(x, weight) if FACTORED_DGRAD else None
+        if ctx.factored is not None:
+            ctx.factored.taken = True
         return y
 
     @staticmethod
@@ -478,7 +528,7 @@ class _LinearAct(torch.autograd.Function):
         gw = None
         if ctx.needs_input_grad[1]:
             if split:
-                gw = _split_linear_wgrad(_c(gpre), x, ctx.params[0])
+                gw = _split_linear_wgrad(_c(gpre), x, ctx.params[0], ctx.arith_wgrad)
             elif (_small_wgrad_ok(x.shape[0], weight.shape[0], weight.shape[1]) and ctx.has_bias and ctx.needs_input_grad[2]
                   and x.dim() == 2):
                 gw, gb = _linear_wgrad_bias(_c(gpre), x, ctx.params[0], ctx.params[1])
@@ -504,9 +554,12 @@ def linear_act(x, weight, bias=None, act=None):
 def tri_pack(x, n_nodes, asym, absmax=None):
     """Upper triangles [B, tri_row_stride(N)] of a batch of symmetric matrices x [B, N*N]; `asym` (int32[1]
     on the device) is OR-ed with 1 if a matrix is not symmetric.  The result carries no gradient:
-    the symmetric first layer is for network inputs.  `absmax` (int32[1] on the device): set to the bit
-    pattern of the largest magnitude packed, which sym_linear_pair(x_absmax=...) takes as the operand's scale."""
+    the symmetric first layer is for network inputs.  `absmax` (int32[ABSMAX_SLOTS] on the device, the record
+    _absmax_slots makes): filled with partial maxima (bit patterns) of the magnitudes packed, which
+    sym_linear_pair(x_absmax=...) takes as the operand's scale."""
     x = _c(x.detach()).reshape(-1, n_nodes * n_nodes)
+    if absmax is not None:
+        _check_absmax_slot(absmax, x.device)
     ld = tri_row_stride(n_nodes)
     out = torch.empty(x.shape[0], ld, dtype=torch.float32, device=x.device)
     if absmax is not None:
@@ -584,16 +637,16 @@ def _round_up(v, m):
     return (v + m - 1) // m * m
 
 
-def _pair_wgrad_shape(B, T, H, n_nodes):
+def _pair_wgrad_shape(B, T, H, n_nodes, arith):
     """(parts, Kp, t_real, rows, halves, tile, Tp) of the weight-gradient product of the symmetric first-layer pair."""
-    parts = 2 if SPLIT_WGRAD_TERMS == 3 else 3
+    parts = 3 if arith == "bf16x6" else 2
     Kp = _round_up(B, 16)
     # the row of ones goes where the packed triangle's zero padding starts (one past the end if there is none)
     t_real = min(n_nodes * (n_nodes + 1) // 2, T)
     rows = max(T, t_real + 1)
     # few output tiles and a long k (the batch): 256-row tiles with the k range split in two keep twice
     # the fragments in registers per LDS byte read
-    halves = SPLIT_WGRAD_TERMS == 3 and SPLIT_WGRAD_KSPLIT and B >= 4096 and (rows + 255) // 256 * (2 * H // 256) <= 128
+    halves = arith != "bf16x6" and SPLIT_WGRAD_KSPLIT and B >= 4096 and (rows + 255) // 256 * (2 * H // 256) <= 128
     tile = 256 if halves else 128
     return parts, Kp, t_real, rows, halves, tile, _round_up(rows, tile)
 
@@ -610,6 +663,8 @@ class _SymLinearPair(torch.autograd.Function):
         w1, w2 = _c(w1), _c(w2)
         B, T = xt.shape
         H = w1.shape[0]
+        if x_absmax is not None:
+            _check_absmax_slot(x_absmax, xt.device)
         if w2.shape != w1.shape or H % 256 != 0 or T % 16 != 0 or b1 is None or b2 is None:
             raise RuntimeError(f"sym_linear_pair: two [H,N*N] weights with biases, H a multiple of 256 (got {tuple(w1.shape)}, "
                                f"{tuple(w2.shape)}), T a multiple of 16 (got {T})")
@@ -621,7 +676,7 @@ class _SymLinearPair(torch.autograd.Function):
         xa = _split_operand(Mp, T, dev)
         y1 = torch.empty(B, H, dtype=torch.float32, device=dev)
         y2 = torch.empty(B, H, dtype=torch.float32, device=dev)
-        if SPLIT_FWD == "f16":
+        if ARITH_FWD == "f16x2":
             # the folding pass (and, given x_absmax, the packing pass) leaves the largest magnitude it wrote
             mx = _absmax_slots(2, dev)
             wmax, xmax = mx[0], (x_absmax if x_absmax is not None else mx[1])
@@ -630,17 +685,19 @@ class _SymLinearPair(torch.autograd.Function):
             if x_absmax is None:
                 _absmax(xt, xmax)
             call("mdnvae_split_rows_f16", ptr(wt), 2 * H, T, T, 0, wmax.data_ptr(), wb.data_ptr(), stream())
+            ctx.xmax = xmax
             if any(ctx.needs_input_grad[1:5]) and T % 16 == 0:
                 # the backward's transposed operand of the batch from the same read of it
-                parts, Kp, t_real, rows, halves, tile, Tp = _pair_wgrad_shape(B, T, H, n_nodes)
+                parts, Kp, t_real, rows, halves, tile, Tp = _pair_wgrad_shape(B, T, H, n_nodes, ARITH_WGRAD)
                 xb = _split_operand(Tp, Kp, dev)
-                call("mdnvae_split_rows_f16_cols", ptr(xt, "x"), B, t_real, T, 1, parts, xmax.data_ptr(), xa.data_ptr(),
-                     xb.data_ptr(), stream())
+                call("mdnvae_split_rows_f16_cols", ptr(xt, "x"), B, t_real, T, 1, 0 if ARITH_WGRAD == "f16x2" else parts,
+                     xmax.data_ptr(), xa.data_ptr(), xb.data_ptr(), stream())
             else:
                 call("mdnvae_split_rows_f16", ptr(xt, "x"), B, T, T, 0, xmax.data_ptr(), xa.data_ptr(), stream())
             call("mdnvae_split_gemm_f16", xa.data_ptr(), wb.data_ptr(), xmax.data_ptr(), wmax.data_ptr(), Mp, 2 * H, T, B, H,
-                 ptr(b1, "bias"), ptr(b2, "bias"), 1, 0, ptr(y1), ptr(y2), H, H, 256, stream())
+                 ptr(b1, "bias"), ptr(b2, "bias"), 1, 0, ptr(y1), ptr(y2), H, H, 256, -1, stream())
         else:
+            ctx.xmax = None
             call("mdnvae_tri_fold", ptr(w1, "weight"), H, n_nodes, T, ptr(wt[:H]), stream())
             call("mdnvae_tri_fold", ptr(w2, "weight"), H, n_nodes, T, ptr(wt[H:]), stream())
             call("mdnvae_split_rows", ptr(wt), 2 * H, T, T, 0, wb.data_ptr(), stream())
@@ -651,11 +708,12 @@ class _SymLinearPair(torch.autograd.Function):
         ctx.xb = xb
         ctx.n_nodes = n_nodes
         ctx.params = (w1, b1, w2, b2)
+        ctx.arith_wgrad = ARITH_WGRAD
         ctx.slots = None
         if FACTORED_DGRAD and any(ctx.needs_input_grad[1:5]):
-            ctx.slots = (_FactoredGrad(), _FactoredGrad())
+            ctx.slots = (_FactoredGrad(y1.shape), _FactoredGrad(y2.shape))
             for y, slot in zip((y1, y2), ctx.slots):
-                _FACTORED_SLOTS[y.data_ptr()] = slot
+                setattr(y, _FACTORED_ATTR, slot)
         return y1, y2
 
     @staticmethod
@@ -672,25 +730,70 @@ class _SymLinearPair(torch.autograd.Function):
         # row of ones appended (so that row T of the result is the column sum of grad_pre) and grad_pre^T,
         # which is split straight from the output gradients with the ReLU gate applied on the way
         # (grad_pre itself is never written)
-        parts, Kp, t_real, rows, halves, tile, Tp = _pair_wgrad_shape(B, T, H, n)
+        arith = ctx.arith_wgrad
+        f16 = arith == "f16x2"
+        parts, Kp, t_real, rows, halves, tile, Tp = _pair_wgrad_shape(B, T, H, n, arith)
         pb = _split_operand(2 * H, Kp, dev)
-        for i, (y, g, slot) in enumerate(((y1, g1, slots[0]), (y2, g2, slots[1]))):
+        towers = []
+        for y, g, slot in ((y1, g1, slots[0]), (y2, g2, slots[1])):
+            gpre_next = w_next = None
             if slot is not None and slot.gpre is not None:
+                gpre_next, w_next, slot.gpre, slot.weight = slot.gpre, slot.weight, None, None
+                if not (gpre_next.dim() == 2 and gpre_next.shape[0] == B and gpre_next.is_contiguous()
+                        and tuple(w_next.shape) == (gpre_next.shape[1], H) and w_next.is_contiguous()):
+                    # a hand-over the fused pass cannot take (_LinearAct checks at forward time and never leaves
+                    # one): the product is formed the ordinary way
+                    prod = _library_gemm(gpre_next, w_next)
+                    g = prod if _is_free_zeros(g) else g + prod
+                    gpre_next = w_next = None
+            dense = None if (gpre_next is not None and _is_free_zeros(g)) else _c(g)
+            towers.append((y, dense, gpre_next, w_next))
+        gmax = None
+        if f16:
+            # one scale for both towers' gradients (they are the columns of one operand): their largest magnitude,
+            # or - where a gradient is only known as a product - a bound of it from the factors
+            mx = _absmax_slots(5, dev, zero=True)
+            gmax = mx[4]
+            for i, (y, dense, gpre_next, w_next) in enumerate(towers):
+                if gpre_next is None:
+                    _absmax(dense, gmax, reset=False)
+                    continue
+                _absmax(gpre_next, mx[2 * i], reset=False)
+                if dense is not None:
+                    _absmax(dense, mx[2 * i + 1], reset=False)
+                call("mdnvae_dgrad_bound", mx[2 * i].data_ptr(), ptr(w_next), w_next.shape[0], H,
+                     mx[2 * i + 1].data_ptr() if dense is not None else None, 0, gmax.data_ptr(), stream())
+        for i, (y, dense, gpre_next, w_next) in enumerate(towers):
+            if gpre_next is not None and f16:
                 # the consuming layer left its data gradient as a product: formed here, under the gate
-                dense = None if _is_free_zeros(g) else _c(g)
-                call("mdnvae_split_cols_dgrad", ptr(slot.gpre), ptr(slot.weight), ptr(dense), ptr(y), B, H,
-                     slot.gpre.shape[1], parts, i * (H // 32), pb.data_ptr(), stream())
-                slot.gpre = slot.weight = None
-            else:
-                call("mdnvae_split_cols_gated", ptr(_c(g)), ptr(y), B, H, H, 0, parts, i * (H // 32), pb.data_ptr(),
+                call("mdnvae_split_cols_dgrad_f16", ptr(gpre_next), ptr(w_next), ptr(dense), ptr(y), B, H, gpre_next.shape[1],
+                     i * (H // 32), gmax.data_ptr(), pb.data_ptr(), stream())
+            elif gpre_next is not None:
+                call("mdnvae_split_cols_dgrad", ptr(gpre_next), ptr(w_next), ptr(dense), ptr(y), B, H, gpre_next.shape[1],
+                     parts, i * (H // 32), pb.data_ptr(), stream())
+            elif f16:
+                call("mdnvae_split_cols_f16", ptr(dense), ptr(y), B, H, H, 0, i * (H // 32), gmax.data_ptr(), pb.data_ptr(),
                      stream())
+            else:
+                call("mdnvae_split_cols_gated", ptr(dense), ptr(y), B, H, H, 0, parts, i * (H // 32), pb.data_ptr(), stream())
         xb, ctx.xb = ctx.xb, None
+        xmax = ctx.xmax
         if xb is None:
             xb = _split_operand(Tp, Kp, dev)
-            call("mdnvae_split_cols_gated", ptr(xt), None, B, t_real, T, 1, parts, 0, xb.data_ptr(), stream())
+            if f16:
+                if xmax is None:
+                    xmax = _absmax_slots(1, dev)[0]
+                    _absmax(xt, xmax)
+                call("mdnvae_split_cols_f16", ptr(xt), None, B, t_real, T, 1, 0, xmax.data_ptr(), xb.data_ptr(), stream())
+            else:
+                call("mdnvae_split_cols_gated", ptr(xt), None, B, t_real, T, 1, parts, 0, xb.data_ptr(), stream())
         gts = list((torch.zeros if halves else torch.empty)(2, rows, H, dtype=torch.float32, device=dev).unbind(0))    # one fill
-        call("mdnvae_split_gemm", xb.data_ptr(), pb.data_ptr(), Tp, 2 * H, Kp, t_real + 1, H, None, None, 0,
-             2 if halves else 0, ptr(gts[0]), ptr(gts[1]), H, H, tile, SPLIT_WGRAD_TERMS, stream())
+        if f16:
+            call("mdnvae_split_gemm_f16", xb.data_ptr(), pb.data_ptr(), xmax.data_ptr(), gmax.data_ptr(), Tp, 2 * H, Kp,
+                 t_real + 1, H, None, None, 0, 2 if halves else 0, ptr(gts[0]), ptr(gts[1]), H, H, tile, t_real, stream())
+        else:
+            call("mdnvae_split_gemm", xb.data_ptr(), pb.data_ptr(), Tp, 2 * H, Kp, t_real + 1, H, None, None, 0,
+                 2 if halves else 0, ptr(gts[0]), ptr(gts[1]), H, H, tile, 6 if arith == "bf16x6" else 3, stream())
         for i, (param, bias) in enumerate(((w1, b1), (w2, b2))):
             gt, gb = gts[i][:t_real], gts[i][t_real]
             if ctx.needs_input_grad[2 + 2 * i]:
@@ -741,7 +844,7 @@ class _LinearPair(torch.autograd.Function):
         xa = _split_operand(Mp, Kp, dev)
         y1 = torch.empty(B, H, dtype=torch.float32, device=dev)
         y2 = torch.empty(B, H, dtype=torch.float32, device=dev)
-        if SPLIT_FWD == "f16":
+        if ARITH_FWD == "f16x2":
             mx = _absmax_slots(2, dev)
             wmax, xmax = mx[0], mx[1]
             _absmax(w1, wmax)
@@ -751,8 +854,10 @@ class _LinearPair(torch.autograd.Function):
             call("mdnvae_split_rows_f16", ptr(w2, "weight"), H, D, D, H // 32, wmax.data_ptr(), wb.data_ptr(), stream())
             call("mdnvae_split_rows_f16", ptr(x, "x"), B, D, D, 0, xmax.data_ptr(), xa.data_ptr(), stream())
             call("mdnvae_split_gemm_f16", xa.data_ptr(), wb.data_ptr(), xmax.data_ptr(), wmax.data_ptr(), Mp, 2 * H, Kp, B, H,
-                 ptr(b1, "bias"), ptr(b2, "bias"), 1, 0, ptr(y1), ptr(y2), H, H, 256, stream())
+                 ptr(b1, "bias"), ptr(b2, "bias"), 1, 0, ptr(y1), ptr(y2), H, H, 256, -1, stream())
+            ctx.xmax = xmax
         else:
+            ctx.xmax = None
             call("mdnvae_split_rows", ptr(w1, "weight"), H, D, D, 0, wb.data_ptr(), stream())
             call("mdnvae_split_rows", ptr(w2, "weight"), H, D, D, H // 32, wb.data_ptr(), stream())
             call("mdnvae_split_rows", ptr(x, "x"), B, D, D, 0, xa.data_ptr(), stream())
@@ -760,6 +865,7 @@ class _LinearPair(torch.autograd.Function):
                  ptr(y1), ptr(y2), H, H, 256, 6, stream())
         ctx.save_for_backward(x, y1, y2)
         ctx.params = (w1, b1, w2, b2)
+        ctx.arith_wgrad = ARITH_WGRAD
         return y1, y2
 
     @staticmethod
@@ -779,17 +885,33 @@ class _LinearPair(torch.autograd.Function):
             xb = _split_operand(Np, Kp, dev)
             tail = (D + 31) // 32 * (Kp // 16) * 3072          # operand row tiles past D: zero (their columns are not stored)
             xb[tail:].zero_()
-            parts = 2 if SPLIT_WGRAD_TERMS == 3 else 3
-            call("mdnvae_split_cols_gated", ptr(x), None, B, D, D, 0, parts, 0, xb.data_ptr(), stream())
+            arith = ctx.arith_wgrad
+            f16 = arith == "f16x2"
+            parts, terms = (3, 6) if arith == "bf16x6" else (2, 3)
+            if f16:
+                xmax = ctx.xmax
+                if xmax is None:
+                    xmax = _absmax_slots(1, dev)[0]
+                    _absmax(x, xmax)
+                gmax = _absmax_slots(1, dev)[0]
+                call("mdnvae_split_cols_f16", ptr(x), None, B, D, D, 0, 0, xmax.data_ptr(), xb.data_ptr(), stream())
+            else:
+                call("mdnvae_split_cols_gated", ptr(x), None, B, D, D, 0, parts, 0, xb.data_ptr(), stream())
             pb = _split_operand(H, Kp, dev)
             for i, (param, gp) in enumerate(((w1, gpre[0]), (w2, gpre[1]))):
                 if not ctx.needs_input_grad[1 + 2 * i]:
                     continue
-                call("mdnvae_split_cols_gated", ptr(gp), None, B, H, H, 0, parts, 0, pb.data_ptr(), stream())
                 target = _grad_target(param)
                 out = target if target is not None else torch.empty(H, D, dtype=torch.float32, device=dev)
-                call("mdnvae_split_gemm", pb.data_ptr(), xb.data_ptr(), H, Np, Kp, H, D, None, None, 0, int(target is not None),
-                     ptr(out), None, Np, D, 128, SPLIT_WGRAD_TERMS, stream())
+                if f16:
+                    _absmax(gp, gmax)
+                    call("mdnvae_split_cols_f16", ptr(gp), None, B, H, H, 0, 0, gmax.data_ptr(), pb.data_ptr(), stream())
+                    call("mdnvae_split_gemm_f16", pb.data_ptr(), xb.data_ptr(), gmax.data_ptr(), xmax.data_ptr(), H, Np, Kp, H, D,
+                         None, None, 0, int(target is not None), ptr(out), None, Np, D, 128, -1, stream())
+                else:
+                    call("mdnvae_split_cols_gated", ptr(gp), None, B, H, H, 0, parts, 0, pb.data_ptr(), stream())
+                    call("mdnvae_split_gemm", pb.data_ptr(), xb.data_ptr(), H, Np, Kp, H, D, None, None, 0, int(target is not None),
+                         ptr(out), None, Np, D, 128, terms, stream())
                 if target is not None:
                     _grad_added(param)
                 else:

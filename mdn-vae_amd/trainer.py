@@ -96,6 +96,17 @@ def all_reduce_sum_(t, group=None, async_op=False):
     return work if async_op else _Done()
 
 
+def broadcast_(t, group=None):
+    """In-place broadcast of one contiguous tensor from the group's first rank."""
+    src = dist.get_global_rank(group, 0) if group is not None else 0
+    if t.is_cuda and _host_staged(group):
+        host = t.cpu()
+        dist.broadcast(host, src=src, group=group)
+        t.copy_(host)
+        return
+    dist.broadcast(t, src=src, group=group)
+
+
 def allreduce_sum(flat, group=None, bucket_floats=8 << 20):
     """In-place SUM all-reduce of a flat buffer in buckets of `bucket_floats` (32 MiB): large
     enough that each xGMI ring step moves megabytes, small enough to pipeline."""
@@ -124,12 +135,21 @@ class Trainer:
     rank runs the same graph, so the hooks fire in the same order everywhere).  A symmetric-input
     first layer (GCNVAE(symmetric_input=True)) hands over its weight gradient folded onto the upper
     triangle, so half the bytes cross the links and the copy to both triangles happens after the
-    sum.  The rest of the flat gradient buffer is reduced in buckets after backward."""
+    sum.  The rest of the flat gradient buffer is reduced in buckets after backward.
+
+    With more than one rank the parameters of the group's first rank are broadcast at construction, as
+    DistributedDataParallel does: replicas start equal whatever each process seeded its initialisation with.
+
+    `fast_wgrad`: the weight-gradient products of the large dense layers keep two bf16 parts per operand
+    (ops.arithmetic(wgrad="bf16x3"): about 1e-5 of a gradient's norm, 1e-3 of single entries) instead of the
+    default two fp16 parts (fp32 dot-product level); a few percent faster."""
 
     def __init__(self, model, loss_mode, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, group=None, fused_loss=True,
-                 overlap_floats=1 << 20, direct_grads=True, folded_adam=True):
+                 overlap_floats=1 << 20, direct_grads=True, folded_adam=True, fast_wgrad=False):
         self.model, self.loss_mode, self.group = model, loss_mode, group
         self.lr, self.betas, self.eps = lr, betas, eps
+        self.wgrad_arithmetic = "bf16x3" if fast_wgrad else None
+        self._split_graph = False   # a captured data-parallel step: gradients are exchanged between two graphs
         early = _distributed(group) and overlap_floats
         # `folded_adam`: weights of symmetric-input first layers keep their gradient folded onto the
         # upper triangle all the way into Adam (moments in the folded layout, both mirror entries
@@ -146,6 +166,8 @@ class Trainer:
                 order = [p for p in self.buf.params if id(p) in self._fold]
                 raise RuntimeError(f"Trainer: folded-gradient parameters are not a prefix of the flat buffers ({len(order)})")
         self._fold_end = self.buf.offsets[len(self._fold)] if self._fold else 0
+        if _distributed(group):
+            broadcast_(self.buf.flat_p, group)
         self.exp_avg = torch.zeros_like(self.buf.flat_p)
         self.exp_avg_sq = torch.zeros_like(self.buf.flat_p)
         self._fold_m, self._fold_v = {}, {}
@@ -191,6 +213,8 @@ class Trainer:
             if param.grad.data_ptr() != flat.data_ptr():      # autograd replaced the view: copy back
                 flat.copy_(param.grad.reshape(-1))
                 param.grad = flat.view(param.shape)
+            if self._split_graph:                              # exchanged as one range after the backward graph
+                return
             self._pending.append(all_reduce_sum_(flat, self.group, async_op=True))
         return hook
 
@@ -206,7 +230,7 @@ class Trainer:
         exchange = bool(self._hook_of)
         self._defer_fold = bool(_defer_fold and self._fold)
         try:
-            with ops.accumulate_into_grads(ready=self._grad_ready if exchange else None,
+            with ops.accumulate_into_grads(ready=self._grad_ready if (exchange and not self._split_graph) else None,
                                            folded=self._folded_grad if (exchange or self._fold) else None):
                 return self._forward_backward(inputs, target, eps)
         finally:
@@ -225,9 +249,9 @@ class Trainer:
         if not hooked and not folded_adam:   # a small layer: unfold now, its range goes with the buckets
             call("mdnvae_tri_unfold", ptr(gt), gt.shape[1], n_nodes, gt.shape[1], 1, ptr(param.grad), 1, stream())
             return
-        if not _distributed(self.group):
+        if not _distributed(self.group) or self._split_graph:
             work = None
-            if not self._defer_fold:         # a caller outside step() may read .grad
+            if not self._defer_fold and not self._split_graph:         # a caller outside step() may read .grad
                 call("mdnvae_tri_unfold", ptr(gt), gt.shape[1], n_nodes, gt.shape[1], 1, ptr(param.grad), 1, stream())
         elif hooked:
             work = all_reduce_sum_(gt, self.group, async_op=True)
@@ -236,6 +260,10 @@ class Trainer:
         self._folded.append((work, gt, param, n_nodes))
 
     def _forward_backward(self, inputs, target, eps=None):
+        with ops.arithmetic(wgrad=self.wgrad_arithmetic):
+            return self._forward_backward_pass(inputs, target, eps)
+
+    def _forward_backward_pass(self, inputs, target, eps=None):
         self._folded.clear()
         # inside step() the unfolded gradients of the folded-Adam weights are neither written nor read
         self.buf.zero_grad(self._fold_end if self._defer_fold else 0)
@@ -331,9 +359,9 @@ class Trainer:
         removes that limit.  Tensor inputs, the target and eps are copied into static buffers
         (the graph reads those addresses); other inputs (the adjacency list) are baked in.  The
         warm-up and capture passes leave parameters, Adam state and step count untouched.
-        Single-process only: with data-parallel ranks the gradient exchange is not captured."""
-        if _distributed(self.group):
-            raise RuntimeError("Trainer.capture: graph replay is single-process; use step() with data-parallel ranks")
+        With data-parallel ranks the step is recorded as TWO graphs split at the exchange: zero_grad ->
+        forward -> loss -> backward, then (outside any graph) the SUM all-reduce of the gradient buffer and
+        of the folded first-layer gradients, then Adam.  Nothing is exchanged during backward in that form."""
         if eps is None:
             raise ValueError("Trainer.capture: eps must be given (the graph cannot draw fresh noise itself)")
         dev = self.buf.flat_p.device
@@ -347,20 +375,36 @@ class Trainer:
             list(self._fold_v.values())
         keep = [t.clone() for t in state]
 
-        def one():
-            loss = self.forward_backward(self._g_inputs, self._g_target, self._g_eps, _defer_fold=True)
-            self._apply_adam((self._g_step, self._g_coef))
-            return loss
+        def backward_part():
+            return self.forward_backward(self._g_inputs, self._g_target, self._g_eps, _defer_fold=True)
 
-        side = torch.cuda.Stream(device=dev)
-        side.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(side):
-            for _ in range(2):                      # first calls: library attributes, allocator pools
-                one()
-        torch.cuda.current_stream(dev).wait_stream(side)
-        self._graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._graph):
-            self._g_loss = one()
+        def adam_part():
+            self._apply_adam((self._g_step, self._g_coef))
+
+        self._split_graph = split = _distributed(self.group)
+        try:
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                for _ in range(2):                      # first calls: library attributes, allocator pools
+                    backward_part()
+                    adam_part()
+            torch.cuda.current_stream(dev).wait_stream(side)
+            self._graph = torch.cuda.CUDAGraph()
+            self._graph_adam = None
+            with torch.cuda.graph(self._graph):
+                self._g_loss = backward_part()
+                if not split:
+                    adam_part()
+            if split:
+                # the folded gradients the first graph leaves (its own memory, alive while this list is) are
+                # what the exchange sums and what the second graph reads
+                self._g_folded = list(self._folded)
+                self._graph_adam = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self._graph_adam, pool=self._graph.pool()):
+                    adam_part()
+        finally:
+            self._split_graph = False
         for dst, src in zip(state, keep):
             dst.copy_(src)
         self._g_step.fill_(self.steps)
@@ -379,6 +423,11 @@ class Trainer:
         if self._g_step_holds != self.steps:     # eager steps since the last replay moved the host count on
             self._g_step.fill_(self.steps)
         self._graph.replay()
+        if self._graph_adam is not None:
+            allreduce_sum(self.buf.flat_g[self._fold_end:], self.group)
+            for _, gt, _, _ in self._g_folded:
+                all_reduce_sum_(gt, self.group)
+            self._graph_adam.replay()
         self.steps += 1
         self._g_step_holds = self.steps
         return self._g_loss
@@ -392,12 +441,13 @@ class Trainer:
         idx = torch.randperm(B, device=fc.device, generator=generator)[: B // 2]
         fc_without = fc.clone()
         fc_without[idx] = 0.0
-        recon, mu, logvar = self.model(fc, sc, eps=eps_with)
-        loss_with = ops.vae_loss_terms(recon, sc, mu, logvar, "mse")[0]
-        recon_no, mu_no, logvar_no = self.model(fc_without, sc, eps=eps_without)
-        loss_without = ops.vae_loss_terms(recon_no, sc, mu_no, logvar_no, "mse")[0]
-        loss = loss_with + torch.relu(loss_with - loss_without + margin)
-        loss.backward()
+        with ops.arithmetic(wgrad=self.wgrad_arithmetic):
+            recon, mu, logvar = self.model(fc, sc, eps=eps_with)
+            loss_with = ops.vae_loss_terms(recon, sc, mu, logvar, "mse")[0]
+            recon_no, mu_no, logvar_no = self.model(fc_without, sc, eps=eps_without)
+            loss_without = ops.vae_loss_terms(recon_no, sc, mu_no, logvar_no, "mse")[0]
+            loss = loss_with + torch.relu(loss_with - loss_without + margin)
+            loss.backward()
         self.optimizer_step()
         return loss.detach()
 
@@ -409,8 +459,7 @@ class Trainer:
         metric of the scripts, sum of losses / number of subjects (with data-parallel ranks: of
         this rank's shard).  `extra(idx)` may be a callable giving per-batch extra inputs (e.g.
         traits) or a tuple of fixed extra inputs (the adjacency list).  `graph`: full batches run
-        as replays of one captured HIP graph (see `capture`; needs `eps_generator`, single
-        process); the ragged last batch is stepped call by call."""
+        as replays of one captured HIP graph (see `capture`; needs `eps_generator`); the ragged last batch is stepped call by call."""
         if graph and eps_generator is None:
             raise ValueError("train_epoch(graph=True) needs eps_generator: a captured step cannot draw its own noise")
         n = data.shape[0]

@@ -110,10 +110,17 @@ def conv_encode(p, x, n_nodes=68):
     return F.linear(f, p["fc_mean.weight"], p["fc_mean.bias"]), F.linear(f, p["fc_log_var.weight"], p["fc_log_var.bias"])
 
 
-def fnn_encode(p, x):
-    """function/MM_Gate.py:157-162: two ReLU towers D->1024->128->L."""
-    a = F.relu(F.linear(F.relu(F.linear(x, p["fc11.weight"], p["fc11.bias"])), p["fc111.weight"], p["fc111.bias"]))
-    b = F.relu(F.linear(F.relu(F.linear(x, p["fc12.weight"], p["fc12.bias"])), p["fc222.weight"], p["fc222.bias"]))
+def fnn_encode(p, x, gates=None):
+    """function/MM_Gate.py:157-162: two ReLU towers D->1024->128->L.  gates = (g11, g12[, g111, g222]) boolean masks
+    [B,1024] (and [B,128]): those ReLUs pass exactly the masked entries (the ones another run passed) instead of the
+    positive ones, so that a comparison with that run measures arithmetic and not which side of zero a rounding-level
+    pre-activation fell."""
+    def gated(pre, i):
+        return F.relu(pre) if gates is None or len(gates) <= i else pre * gates[i].to(pre.dtype)
+    a1 = gated(F.linear(x, p["fc11.weight"], p["fc11.bias"]), 0)
+    a2 = gated(F.linear(x, p["fc12.weight"], p["fc12.bias"]), 1)
+    a = gated(F.linear(a1, p["fc111.weight"], p["fc111.bias"]), 2)
+    b = gated(F.linear(a2, p["fc222.weight"], p["fc222.bias"]), 3)
     return F.linear(a, p["fc21.weight"], p["fc21.bias"]), F.linear(b, p["fc22.weight"], p["fc22.bias"])
 
 

@@ -21,7 +21,10 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
                 "vs_baseline", "dtype", "data", "config", "roofline"):
         assert key in d, key
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["unit"] == "samples/s"
-    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic"
+    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic"
+    # the line says what arithmetic the step's big products run in, not just the storage type
+    assert d["dtype"].startswith("f32 (first-layer products: f16x2 forward / f16x2 weight gradients")
+    assert "f16x2" in d["config"]["arithmetic"] and d["config"]["first_layer_weight_gradient"] == "f16x2"
     assert "workload" in d["config"] and d["value"] > 0
     roof = d["roofline"]
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
@@ -33,3 +36,8 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     assert d["config"]["symmetric_first_layer"] is True and len(d["config"]["workload"]) <= 128
     assert d["config"]["full_first_layer_value"] == d["full_first_layer"]["value"]
     assert not d["roofline"]["kernel"].startswith("library_")          # a hand-written kernel
+    # the same step at the finest and at the fastest arithmetic, the reference's own loss kernels, and the
+    # cost of the collective calls on a one-rank RCCL group
+    assert d["strict"]["value"] > 0 and d["fast_wgrad"]["value"] > 0
+    assert d["fused_loss_kernels"]["B=16384"]["mse_fwdbwd"]["frac"] > 0
+    assert d["exchange_rehearsal"].get("ms_per_step_with", 0) > 0, d["exchange_rehearsal"]

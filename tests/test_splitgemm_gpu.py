@@ -115,7 +115,7 @@ def test_two_part_fp16_product_against_float64(Mrows, N, K, tile, scale_a, scale
         out0 = torch.full((Mrows, half), float("nan"), device=DEV)
         out1 = torch.full((Mrows, N - half), float("nan"), device=DEV) if half < N else None
         call("mdnvae_split_gemm_f16", oa.data_ptr(), ob.data_ptr(), ma.data_ptr(), mb.data_ptr(), Mp, N, Kp, Mrows, half,
-             None, None, 0, 0, ptr(out0), ptr(out1), half, half, tile, stream())
+             None, None, 0, 0, ptr(out0), ptr(out1), half, half, tile, -1, stream())
         got = torch.cat([out0] + ([out1] if out1 is not None else []), dim=1).double().cpu()
         assert torch.isfinite(got).all()
         assert float(((got - want).abs() / mag).max()) <= 1e-6, how
@@ -125,7 +125,7 @@ def test_two_part_fp16_product_against_float64(Mrows, N, K, tile, scale_a, scale
     out1 = torch.empty(Mrows, N - half, device=DEV) if half < N else None
     call("mdnvae_split_gemm_f16", oa.data_ptr(), ob.data_ptr(), ma.data_ptr(), mb.data_ptr(), Mp, N, Kp, Mrows, half,
          ptr(bd_[:half].contiguous()), ptr(bd_[half:].contiguous()) if half < N else None, 1, 0, ptr(out0), ptr(out1), half,
-         half, tile, stream())
+         half, tile, -1, stream())
     got = torch.cat([out0] + ([out1] if out1 is not None else []), dim=1).double().cpu()
     want_r = torch.relu(want + bias.double())
     assert float((got - want_r).abs().max() / want_r.abs().max()) <= 1e-5
@@ -151,7 +151,7 @@ def test_two_part_fp16_small_entries_and_shared_slots():
     call("mdnvae_split_rows_f16", ptr(bd), N, K, K, 0, mb.data_ptr(), ob.data_ptr(), stream())
     out = torch.empty(Mrows, N, device=DEV)
     call("mdnvae_split_gemm_f16", oa.data_ptr(), ob.data_ptr(), ma.data_ptr(), mb.data_ptr(), Mrows, N, K, Mrows, N, None,
-         None, 0, 0, ptr(out), None, N, N, 128, stream())
+         None, 0, 0, ptr(out), None, N, N, 128, -1, stream())
     want = a.double() @ b.double().t()
     bound = 3 * 2.0 ** -22 * (a.double().abs() @ b.double().abs().t()) + 2.0 ** -28 * (
         float(a.abs().max()) * b.double().abs().sum(1).unsqueeze(0) + 1e3 * a.double().abs().sum(1).unsqueeze(1))
@@ -160,7 +160,7 @@ def test_two_part_fp16_small_entries_and_shared_slots():
     call("mdnvae_absmax", ptr(zero), Mrows, K, K, 0.0, 1, ma.data_ptr(), stream())
     call("mdnvae_split_rows_f16", ptr(zero), Mrows, K, K, 0, ma.data_ptr(), oa.data_ptr(), stream())
     call("mdnvae_split_gemm_f16", oa.data_ptr(), ob.data_ptr(), ma.data_ptr(), mb.data_ptr(), Mrows, N, K, Mrows, N, None,
-         None, 0, 0, ptr(out), None, N, N, 128, stream())
+         None, 0, 0, ptr(out), None, N, N, 128, -1, stream())
     assert float(out.abs().max()) == 0.0
 
 
@@ -183,16 +183,108 @@ def test_both_operands_of_a_batch_from_one_pass(B, R, ld, parts):
     call("mdnvae_split_rows_f16_cols", ptr(src), B, R, ld, 1, parts, mx.data_ptr(), rows_b.data_ptr(), cols_b.data_ptr(), stream())
     assert torch.equal(rows_a, rows_b)
     assert torch.equal(cols_a, cols_b)
+    # parts = 0: the column operand as two fp16 parts at the rows operand's scale, 2^14 in the unit row
+    cols_a.zero_()
+    cols_b.zero_()
+    call("mdnvae_split_cols_f16", ptr(src), None, B, R, ld, 1, 0, mx.data_ptr(), cols_a.data_ptr(), stream())
+    call("mdnvae_split_rows_f16_cols", ptr(src), B, R, ld, 1, 0, mx.data_ptr(), rows_b.data_ptr(), cols_b.data_ptr(), stream())
+    assert torch.equal(rows_a, rows_b)
+    assert torch.equal(cols_a, cols_b)
 
 
-@pytest.mark.parametrize("terms", [3, 6])
-@pytest.mark.parametrize("B,n", [(1024, 68), (1500, 87)])
-def test_first_layer_pair_against_float64_and_the_library_path(B, n, terms, monkeypatch):
+@pytest.mark.parametrize("scale_x,scale_g", [(1.0, 1.0), (2e-4, 3e-7), (900.0, 5e3)])
+@pytest.mark.parametrize("B,R,H,accumulate", [(1000, 300, 256, 0), (4100, 2346, 512, 2)])
+def test_weight_gradient_product_from_two_fp16_parts(B, R, H, accumulate, scale_x, scale_g):
+    """x^T (with the unit row) times gated grad^T on the fp16 product: rows < R are the weight gradient, row R
+    the column sums (bias gradient), whatever the magnitudes of the two tensors - the unit row holds 2^14, not
+    ones times the scale - entry by entry against float64 at the fp32 dot-product level."""
+    g = torch.Generator().manual_seed(B + R)
+    ld = _up(R, 16)
+    x = torch.zeros(B, ld)
+    x[:, :R] = torch.rand(B, R, generator=g) * (torch.rand(B, R, generator=g) < 0.3) * scale_x
+    grad = torch.randn(B, H, generator=g) * scale_g
+    gate = torch.randn(B, H, generator=g)
+    xd, gd, yd = x.to(DEV), grad.to(DEV), gate.to(DEV)
+    mx, mg = _amax_slot(), _amax_slot()
+    call("mdnvae_absmax", ptr(xd), B, ld, ld, 0.0, 1, mx.data_ptr(), stream())
+    call("mdnvae_absmax", ptr(gd), B, H, H, 0.0, 1, mg.data_ptr(), stream())
+    Kp = _up(B, 16)
+    tile = 256 if accumulate == 2 else 128
+    rows = R + 1
+    Tp = _up(rows, tile)
+    xb = torch.zeros(int(_lib.load().mdnvae_split_operand_bytes(Tp, Kp)), dtype=torch.uint8, device=DEV)
+    pb = _operand(H, Kp)
+    call("mdnvae_split_cols_f16", ptr(xd), None, B, R, ld, 1, 0, mx.data_ptr(), xb.data_ptr(), stream())
+    call("mdnvae_split_cols_f16", ptr(gd), ptr(yd), B, H, H, 0, 0, mg.data_ptr(), pb.data_ptr(), stream())
+    out = torch.zeros(rows, H, device=DEV)
+    call("mdnvae_split_gemm_f16", xb.data_ptr(), pb.data_ptr(), mx.data_ptr(), mg.data_ptr(), Tp, H, Kp, rows, H, None, None,
+         0, accumulate, ptr(out), None, H, H, tile, R, stream())
+    gg = grad.double() * (gate > 0)
+    want = torch.cat([x[:, :R].double().t() @ gg, gg.sum(0, keepdim=True)])
+    mag = torch.cat([x[:, :R].double().abs().t() @ gg.abs(), gg.abs().sum(0, keepdim=True)])
+    got = out.double().cpu()
+    assert torch.isfinite(got).all()
+    assert float(((got - want).abs() / mag.clamp_min(1e-300)).max()) <= 1e-6
+    assert float((got[R] - want[R]).abs().max() / want[R].abs().max()) <= 2e-6          # the bias gradient row
+
+
+@pytest.mark.parametrize("with_dense", [False, True])
+@pytest.mark.parametrize("B,H,J", [(1000, 1024, 128), (130, 512, 64)])
+def test_factored_gradient_operand_in_fp16_parts_and_its_bound(B, H, J, with_dense):
+    """mdnvae_dgrad_bound bounds |gpre . w + dense| from the factors' magnitudes (never below the true maximum,
+    at most J times above it); mdnvae_split_cols_dgrad_f16 under that scale writes the operand
+    mdnvae_split_cols_f16 writes from the materialised, gated product - to the rounding of the fp32 product itself."""
+    g = torch.Generator().manual_seed(B + J)
+    gpre = (torch.randn(B, J, generator=g) * 3e-4).to(DEV)
+    w = (torch.randn(J, H, generator=g) / H ** 0.5).to(DEV)
+    dense = (torch.randn(B, H, generator=g) * 1e-5).to(DEV) if with_dense else None
+    gate = torch.randn(B, H, generator=g).to(DEV)
+    mg, md, mb = _amax_slot(), _amax_slot(), _amax_slot()
+    call("mdnvae_absmax", ptr(gpre), B, J, J, 0.0, 1, mg.data_ptr(), stream())
+    if with_dense:
+        call("mdnvae_absmax", ptr(dense), B, H, H, 0.0, 1, md.data_ptr(), stream())
+    call("mdnvae_dgrad_bound", mg.data_ptr(), ptr(w), J, H, md.data_ptr() if with_dense else None, 1, mb.data_ptr(), stream())
+    prod64 = gpre.double() @ w.double() + (dense.double() if with_dense else 0.0)
+    true_max = float(prod64.abs().max())
+    bound = ops.absmax_value(mb)
+    assert true_max <= bound <= (J + 1) * true_max * 4
+    Kp = _up(B, 16)
+    got, want = _operand(H, Kp), _operand(H, Kp)
+    call("mdnvae_split_cols_dgrad_f16", ptr(gpre), ptr(w), ptr(dense), ptr(gate), B, H, J, 0, mb.data_ptr(), got.data_ptr(),
+         stream())
+    # the same operand from the float64 product rounded to fp32: parts differ only by the fp32 product's own rounding
+    full = prod64.float().contiguous()
+    call("mdnvae_split_cols_f16", ptr(full), ptr(gate), B, H, H, 0, 0, mb.data_ptr(), want.data_ptr(), stream())
+    # read both operands back through the product with an identity-like probe: multiply by a random matrix
+    probe = torch.randn(256, B, generator=g).to(DEV)
+    mp = _amax_slot()
+    call("mdnvae_absmax", ptr(probe), 256, B, B, 0.0, 1, mp.data_ptr(), stream())
+    pa = _operand(256, Kp)
+    call("mdnvae_split_rows_f16", ptr(probe), 256, B, B, 0, mp.data_ptr(), pa.data_ptr(), stream())
+    outs = []
+    for op in (got, want):
+        out = torch.empty(256, H, device=DEV)
+        call("mdnvae_split_gemm_f16", pa.data_ptr(), op.data_ptr(), mp.data_ptr(), mb.data_ptr(), 256, H, Kp, 256, H, None, None,
+             0, 0, ptr(out), None, H, H, 128, -1, stream())
+        outs.append(out.double().cpu())
+    ref = probe.double().cpu() @ (prod64 * (gate > 0)).cpu()
+    mag = probe.double().abs().cpu() @ (prod64.abs() * (gate > 0)).cpu()
+    for out in outs:
+        assert float(((out - ref).abs() / mag).max()) <= 2e-6
+
+
+@pytest.mark.parametrize("wgrad", ["f16x2", "bf16x3", "bf16x6"])
+@pytest.mark.parametrize("B,n", [(1024, 68), (1500, 87), (4200, 68)])
+def test_first_layer_pair_against_float64_and_the_library_path(B, n, wgrad):
     """ops.sym_linear_pair (one split product for both layers, forward and weight gradients) against
-    float64 on the full N*N inputs and against ops.sym_linear_act (library fp32 GEMMs).  With six terms the
-    weight and bias gradients are as good as the fp32 library's; with three (the default) they are held to 5e-5 of
-    the largest entry, half the gradient bar."""
-    monkeypatch.setattr(ops, "SPLIT_WGRAD_TERMS", terms)
+    float64 on the full N*N inputs and against ops.sym_linear_act (library fp32 GEMMs).  With two fp16 parts
+    (the default) or six bf16 terms the weight and bias gradients are as good as the fp32 library's; with three
+    bf16 terms (Trainer(fast_wgrad=True)) they are held to 5e-5 of the largest entry, half the gradient bar."""
+    with ops.arithmetic(wgrad=wgrad):
+        _first_layer_pair_case(B, n, wgrad)
+
+
+def _first_layer_pair_case(B, n, wgrad):
     torch.manual_seed(B)
     H, D = 1024, n * n
     x = M.data.synthetic_sc(B, n, seed=3, device=DEV)
@@ -233,7 +325,7 @@ def test_first_layer_pair_against_float64_and_the_library_path(B, n, terms, monk
         err = float((g_.double().cpu() - w_).abs().max() / w_.abs().max())
         err_lib = float((l_.double().cpu() - wl_).abs().max() / wl_.abs().max())
         assert err <= bar, (name, err)
-        if name.startswith("g") and terms == 3:      # weight and bias gradients come out of one product
+        if name.startswith("g") and wgrad == "bf16x3":      # weight and bias gradients come out of one product
             assert err <= 5e-5, (name, err)
         else:
             assert err <= max(4 * err_lib, 1e-6), (name, err, err_lib)  # no worse than the fp32 library GEMM
@@ -303,10 +395,7 @@ def test_full_first_layer_pair_against_float64_and_the_library_path(B, n):
         err = float((g_.double().cpu() - w_).abs().max() / w_.abs().max())
         err_lib = float((l_.double().cpu() - w_).abs().max() / w_.abs().max())
         assert err <= bar, (name, err)
-        if name.startswith("gw") and ops.SPLIT_WGRAD_TERMS == 3:
-            assert err <= 5e-5, (name, err)                             # three-term weight gradient
-        else:
-            assert err <= max(4 * err_lib, 1e-6), (name, err, err_lib)
+        assert err <= max(4 * err_lib, 1e-6), (name, err, err_lib)
 
 
 @pytest.mark.parametrize("act", [None, "sigmoid", "relu"])
@@ -350,7 +439,8 @@ def test_large_dense_layer_on_the_split_product(act):
 
 
 @pytest.mark.parametrize("B,n,J", [(1024, 68, 128), (1100, 87, 64)])
-def test_next_layer_data_gradient_is_formed_inside_the_operand_split(B, n, J, monkeypatch):
+@pytest.mark.parametrize("wgrad", ["f16x2", "bf16x6"])
+def test_next_layer_data_gradient_is_formed_inside_the_operand_split(B, n, J, wgrad, monkeypatch):
     """The dense layer after the first-layer pair leaves its data gradient as (grad_pre, weight); the pair's
     backward forms the product under the ReLU gate while it splits the operand (mdnvae_split_cols_dgrad).
     Same towers with the protocol switched off must give the same gradients to fp32 rounding, and the
@@ -366,10 +456,13 @@ def test_next_layer_data_gradient_is_formed_inside_the_operand_split(B, n, J, mo
     extra = torch.randn(B, H, device=DEV) * 0.1              # a second consumer of the first tower's output
     asym = torch.zeros(1, dtype=torch.int32, device=DEV)
     xt = ops.tri_pack(x, n, asym)
-    monkeypatch.setattr(ops, "SPLIT_WGRAD_TERMS", 6)
+    fused_call = "mdnvae_split_cols_dgrad_f16" if wgrad == "f16x2" else "mdnvae_split_cols_dgrad"
 
     def run(factored, with_extra):
-        monkeypatch.setattr(ops, "FACTORED_DGRAD", factored)
+        with ops.arithmetic(wgrad=wgrad, factored_dgrad=factored):
+            return run_(with_extra)
+
+    def run_(with_extra):
         for t in w + b + wa + ba:
             t.grad = None
         calls = []
@@ -393,6 +486,82 @@ def test_next_layer_data_gradient_is_formed_inside_the_operand_split(B, n, J, mo
     for with_extra in (False, True):
         got, calls = run(True, with_extra)
         want, calls_plain = run(False, with_extra)
-        assert calls.count("mdnvae_split_cols_dgrad") == 2 and "mdnvae_split_cols_dgrad" not in calls_plain
+        assert calls.count(fused_call) == 2 and fused_call not in calls_plain
         for g_, w_ in zip(got, want):
             assert float((g_ - w_).abs().max() / w_.abs().max()) <= 2e-6
+
+
+def test_a_view_of_the_first_layer_output_does_not_take_the_factored_hand_off():
+    """The dense layer after the pair may leave its data gradient as a product only when it consumes the pair's
+    output tensor itself.  A row slice, a reshape or a detached alias starts at the same address but is another
+    tensor: it must get the ordinary dense gradient (right values, no out-of-range reads), and an output that is
+    observed (hook, retain_grad) must see its true gradient."""
+    torch.manual_seed(9)
+    B, n, H, J = 1024, 68, 1024, 128
+    D = n * n
+    x = M.data.synthetic_sc(B, n, seed=5, device=DEV)
+    w = [(torch.randn(H, D) / D ** 0.5).to(DEV).requires_grad_(True) for _ in range(2)]
+    b = [(torch.randn(H) * 0.05).to(DEV).requires_grad_(True) for _ in range(2)]
+    wa = (torch.randn(J, H) / H ** 0.5).to(DEV).requires_grad_(True)
+    wa_half = (torch.randn(J, H // 2) / H ** 0.5).to(DEV).requires_grad_(True)
+    ba = (torch.randn(J) * 0.05).to(DEV).requires_grad_(True)
+    asym = torch.zeros(1, dtype=torch.int32, device=DEV)
+    xt = ops.tri_pack(x, n, asym)
+    params = w + b + [wa, wa_half, ba]
+
+    def run(consume, factored):
+        for t in params:
+            t.grad = None
+        calls = []
+        orig = ops.call
+
+        def spy(name, *a):
+            calls.append(name)
+            return orig(name, *a)
+
+        ops.call = spy
+        try:
+            with ops.arithmetic(factored_dgrad=factored):
+                y = ops.sym_linear_pair(xt, w[0], b[0], w[1], b[1], n)
+                seen = consume(y)
+        finally:
+            ops.call = orig
+        return [None if t.grad is None else t.grad.clone() for t in params], calls, seen
+
+    def sliced(y):                         # the first 600 rows: same address, fewer rows
+        up = torch.randn(600, J, device=DEV, generator=torch.Generator(device=DEV).manual_seed(1))
+        torch.autograd.backward([ops.linear_act(y[0][:600], wa, ba, "relu"), y[1]], [up, torch.zeros_like(y[1])])
+
+    def reshaped(y):                       # [2B, H/2]: same address, same bytes, other shape
+        up = torch.randn(2 * B, J, device=DEV, generator=torch.Generator(device=DEV).manual_seed(2))
+        torch.autograd.backward([ops.linear_act(y[0].view(2 * B, H // 2), wa_half, ba, "relu"), y[1]], [up, torch.zeros_like(y[1])])
+
+    def hooked(y):                         # the output itself, but observed
+        seen = []
+        y[0].register_hook(lambda g: seen.append(g.detach().clone()))
+        up = torch.randn(B, J, device=DEV, generator=torch.Generator(device=DEV).manual_seed(3))
+        torch.autograd.backward([ops.linear_act(y[0], wa, ba, "relu"), y[1]], [up, torch.zeros_like(y[1])])
+        return seen
+
+    def retained(y):
+        y[0].retain_grad()
+        up = torch.randn(B, J, device=DEV, generator=torch.Generator(device=DEV).manual_seed(3))
+        torch.autograd.backward([ops.linear_act(y[0], wa, ba, "relu"), y[1]], [up, torch.zeros_like(y[1])])
+        return [y[0].grad.detach().clone()]
+
+    def direct(y):                         # the case the hand-off is for
+        up = torch.randn(B, J, device=DEV, generator=torch.Generator(device=DEV).manual_seed(3))
+        torch.autograd.backward([ops.linear_act(y[0], wa, ba, "relu"), y[1]], [up, torch.zeros_like(y[1])])
+
+    for consume, expect_fused in ((sliced, False), (reshaped, False), (hooked, False), (retained, False), (direct, True)):
+        got, calls, seen = run(consume, True)
+        want, calls_plain, seen_plain = run(consume, False)
+        fused = calls.count("mdnvae_split_cols_dgrad_f16")
+        assert fused == (1 if expect_fused else 0), (consume.__name__, fused)
+        assert "mdnvae_split_cols_dgrad_f16" not in calls_plain
+        for g_, w_ in zip(got, want):
+            assert (g_ is None) == (w_ is None)
+            if g_ is not None:
+                assert float((g_ - w_).abs().max()) <= 2e-6 * float(w_.abs().max()), consume.__name__
+        if seen:
+            assert float(seen[0].abs().max()) > 0 and torch.equal(seen[0], seen_plain[0])

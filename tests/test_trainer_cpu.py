@@ -250,7 +250,7 @@ def _symmetric_batch(B, n, seed):
     return (x + x.transpose(1, 2)).reshape(B, n * n).contiguous()
 
 
-def _toy_trainer(n, H, **kw):
+def _toy_trainer(n, H, seed=21, **kw):
     class CpuTrainer(M.Trainer):
         def _forward_backward(self, inputs, target, eps=None):        # torch loss in place of the HIP loss kernels
             self._folded.clear()
@@ -259,7 +259,7 @@ def _toy_trainer(n, H, **kw):
             loss.backward()
             return loss.detach()
 
-    torch.manual_seed(21)
+    torch.manual_seed(seed)
     return CpuTrainer(_ToySym(n, H), "mse", **kw)
 
 
@@ -277,7 +277,11 @@ def _fold_worker(rank, world, port, case, out):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     _patch_kernels()
     n, H, B = 6, 8, 10
-    tr = _toy_trainer(n, H, **FOLD_CASES[case])
+    # every rank initialises from its own seed: the trainer's broadcast makes the replicas rank 0's model
+    tr = _toy_trainer(n, H, seed=21 + 7 * rank, **FOLD_CASES[case])
+    torch.manual_seed(21)
+    first = _ToySym(n, H)
+    assert all(torch.equal(a, b) for a, b in zip(tr.model.state_dict().values(), first.state_dict().values()))
     if case in ("hooked", "late"):
         assert tr._fold_end > 0 and all(lo >= tr._fold_end for lo, _ in tr._rest)   # the unfolded region is never exchanged
     x = _symmetric_batch(B, n, 5)

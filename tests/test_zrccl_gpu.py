@@ -30,12 +30,19 @@ def test_one_rank_rccl_step_equals_the_local_step():
     eps = torch.from_numpy(fix["eps"]).to(DEV)
     adjacency = [list(map(int, r)) for r in fix["adjacency"]]
 
-    def run(distributed, overlap=True):
+    def run(distributed, overlap=True, graph=False):
         model = M.GCNVAE(R=5, n_nodes=68, k=32, n_layers=3, latent_dim=68, symmetric_input=True)
         model.load_state_dict(params, strict=False)
         trainer = M.Trainer(model.to(DEV), "poisson_log", **({} if overlap else {"overlap_floats": 0}))
         assert bool(trainer._hook_of) == (distributed and overlap)   # the big first-layer matrices reduce early
         losses = []
+        if graph:
+            # the captured step of a data-parallel trainer: backward graph, exchange, Adam graph
+            trainer.capture((x, adjacency), x, eps)
+            assert (trainer._graph_adam is not None) == distributed
+            losses = [float(trainer.replay((x, adjacency), x, eps).item()) for _ in range(3)]
+            torch.cuda.synchronize()
+            return losses, {k: v.detach().clone() for k, v in model.named_parameters()}
         for _ in range(3):
             loss = trainer.forward_backward((x, adjacency), x, eps=eps)
             # both first-layer weight gradients travel folded (half size), unfolded after the sum
@@ -52,6 +59,7 @@ def test_one_rank_rccl_step_equals_the_local_step():
         return losses, {k: v.detach().clone() for k, v in model.named_parameters()}
 
     local = run(False)
+    local_graph = run(False, graph=True)
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{_free_port()}", world_size=1, rank=0,
                             device_id=torch.device(DEV))
@@ -60,6 +68,7 @@ def test_one_rank_rccl_step_equals_the_local_step():
         dist.barrier()
         exchanged = run(True)
         late = run(True, overlap=False)                       # everything reduced after backward
+        replayed = run(True, graph=True)
         stats = M.FeatureStats(8, torch.zeros(8, device=DEV), DEV).update(torch.rand(64, 8, device=DEV)).allreduce()
         assert stats.n == 64
     finally:
@@ -67,6 +76,8 @@ def test_one_rank_rccl_step_equals_the_local_step():
         dist.destroy_process_group()
     assert exchanged[0] == local[0]
     assert late[0] == local[0]
+    assert replayed[0] == local_graph[0]
     for name, value in local[1].items():
         assert torch.equal(exchanged[1][name], value), name
         assert torch.equal(late[1][name], value), name
+        assert torch.equal(replayed[1][name], local_graph[1][name]), name
