@@ -6,7 +6,7 @@ TAG=$1; shift
 O=$R/gpurun_out/prof_$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --also "" --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-clock --no-n68 --no-script-batch --no-full-variant "$@" > $O/stats.log 2>&1 || { tail -5 $O/stats.log; exit 1; }
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --also "" --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-clock --no-n68 --no-script-batch --no-full-variant --no-variants "$@" > $O/stats.log 2>&1 || { tail -5 $O/stats.log; exit 1; }
 f=$(ls $O/stats/*/*kernel_stats.csv | head -1)
 cp $f $O/kernel_stats.csv
 python3 - $O/kernel_stats.csv <<'PY'

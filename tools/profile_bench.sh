@@ -4,7 +4,7 @@
 # usage: tools/profile_bench.sh [tag] [extra bench.py arguments...]
 R=${GRAFT_REPO_ROOT:-$PWD}
 TAG=${1:-final}; shift
-ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-kernel-clock --no-n68 --no-script-batch --no-full-variant $*"
+ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-kernel-clock --no-n68 --no-script-batch --no-full-variant --no-variants $*"
 O=$R/gpurun_out/prof_$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
