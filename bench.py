@@ -281,29 +281,42 @@ ABI_TAGS.update({
 # rows per side (the padded grid, two more, for the stride-1 data gradient)
 _CB_KIND = {0: "cb_conv_kernel<forward>", 1: "cb_conv_kernel<forward, stride 2>", 2: "cb_conv_kernel<data gradient>",
             3: "cb_conv_kernel<data gradient, stride 2>"}
+# parts (argument 13 of both products) = 2: two fp16 parts per operand, three matrix-core products per multiply-add; such a
+# launch is rated like the other split products: fp32-equivalent flops against a third of the 16-bit peak
+_TWO = ", two fp16 parts"
+
+
+def _cb_tag(base, parts):
+    return base if parts == 1 else base[:-1] + _TWO + ">" if base.endswith(">") else base + "<" + _TWO[2:] + ">"
+
+
 ABI_TAGS.update({
-    "mdnvae_cb_conv": (lambda a: _CB_KIND[a[9]],
+    "mdnvae_cb_conv": (lambda a: _cb_tag(_CB_KIND[a[9]], a[13]),
                        lambda a: 18.0 * a[6] * a[7] * a[8] * (a[10] - (2 if a[9] == 2 else 0)) ** 2),
-    # (g, act, workspace, grad_w, B, Cout, Cin, planes, PPg, PPa, kbeg, kend, pitch, ...)
-    "mdnvae_cb_wgrad": (lambda a: "cb_wgrad_kernel" if a[7] == 1 else "cb_wgrad_kernel<stride 2>",
+    # (g, act, workspace, grad_w, B, Cout, Cin, planes, PPg, PPa, kbeg, kend, pitch, parts, ...)
+    "mdnvae_cb_wgrad": (lambda a: _cb_tag("cb_wgrad_kernel" if a[7] == 1 else "cb_wgrad_kernel<stride 2>", a[13]),
                         lambda a: 18.0 * a[4] * a[5] * a[6] * (a[12] - (2 if a[7] == 1 else 1)) ** 2),
-    # (y, y16, stats, compute, skip, stream_out, act, part_stride, B, C, H, W, pitch_y, Qy, relu, mode, PP, ...): every
-    # buffer once, as laid out (padding included)
+    # (y, y16, stats, compute, skip, stream_out, act, part_stride, B, C, H, W, pitch_y, Qy, relu, mode, PP, parts, ...):
+    # every buffer once, as laid out (padding included)
     "mdnvae_cb_norm_fwd": ("cb_norm_fwd_kernel",
                            lambda a: 1.0 * a[8] * a[9] * (a[13] * (2 if a[1] else 4) + (4 * a[10] * a[11] if a[4] is not None else 0)
                                                           + (4 * a[10] * a[11] if a[5] is not None else 0)
-                                                          + (2 * a[16] * (4 if a[15] == 1 else 1) if a[6] is not None else 0))),
-    # (g, gmode, pitch_g, Qg, base, sum_out, y, y16, stats, pitch_y, Qy, relu, B, C, H, W, omode, dc, part_stride, PP, ...)
-    "mdnvae_cb_norm_bwd": ("cb_norm_bwd_kernel",
+                                                          + (2 * a[17] * a[16] * (4 if a[15] == 1 else 1) if a[6] is not None else 0))),
+    # (g, gmode, pitch_g, Qg, base, sum_out, y, y16, stats, pitch_y, Qy, relu, B, C, H, W, omode, dc, part_stride, PP, parts,
+    #  scale, gsum, absmax_dc, absmax_probe, ...); a probe run reads its inputs and writes a record only
+    "mdnvae_cb_norm_bwd": (lambda a: "cb_norm_bwd_kernel" if a[24] is None else "cb_norm_bwd_kernel<probe of the largest entry>",
                            lambda a: 1.0 * a[12] * a[13] * ((4 * a[3] * (4 if a[1] == 2 else 1) if a[0] is not None else 0)
                                                             + (4 * a[14] * a[15] if a[4] is not None else 0)
-                                                            + (4 * a[14] * a[15] if a[5] is not None else 0)
+                                                            + (0 if a[24] is not None else 4 * a[14] * a[15] if a[5] is not None else 0)
                                                             + a[10] * (2 if a[7] else 4)
-                                                            + (4 * a[14] * a[15] if a[16] == 2 else 2 * a[19]))),
+                                                            + (0 if a[24] is not None else 4 * a[14] * a[15] if a[16] == 2
+                                                               else 2 * a[20] * a[19]))),
 })
-BF16_TAGS |= set(_CB_KIND.values()) | {"cb_wgrad_kernel", "cb_wgrad_kernel<stride 2>"}
-HBM_TAGS |= {"cb_norm_fwd_kernel", "cb_norm_bwd_kernel"}
-ELEMENTWISE_TAGS = {"cb_norm_fwd_kernel", "cb_norm_bwd_kernel"}
+_CB_PRODUCTS = set(_CB_KIND.values()) | {"cb_wgrad_kernel", "cb_wgrad_kernel<stride 2>"}
+BF16_TAGS |= _CB_PRODUCTS | {_cb_tag(t, 2) for t in _CB_PRODUCTS}
+SPLIT_PRODUCTS.update({_cb_tag(t, 2): 3 for t in _CB_PRODUCTS})
+ELEMENTWISE_TAGS = {"cb_norm_fwd_kernel", "cb_norm_bwd_kernel", "cb_norm_bwd_kernel<probe of the largest entry>"}
+HBM_TAGS |= ELEMENTWISE_TAGS
 
 
 def install_clock(clock):
@@ -566,7 +579,8 @@ def headline_dtype(args):
     if args.model in ("mm_gate", "mdn_gate"):
         wg = "bf16x3" if args.fast_wgrad else ops.ARITH_WGRAD
         return f"f32 (first-layer products: {ops.ARITH_FWD} forward / {wg} weight gradients on the 16-bit MFMA, f32 accumulate)"
-    return {"fp32": "f32 (3x3 convolutions: bf16x3 / bf16x2 split MFMA, f32 accumulate)", "fp32_mfma": "f32",
+    return {"fp32": "f32 (3x3 convolutions: two fp16 parts per operand, three MFMA products, f32 accumulate)", "fp32_mfma": "f32",
+            "fp32_planar": "f32 (3x3 convolutions: bf16x3 / bf16x2 split MFMA, f32 accumulate)",
             "bf16x2": "f32 (3x3 convolutions: bf16x2 split MFMA, f32 accumulate)"}.get(
                 args.precision, "bf16 operands, f32 accumulate (3x3 convolutions); f32 elsewhere")
 

@@ -445,9 +445,13 @@ size_t mdnvae_cb_packed_bytes(int Cout, int Cin, int kind, int parts);
  * amax (MDNVAE_ABSMAX_SLOTS partial maxima of |w| as bit patterns) is read for parts = 2 only. */
 int mdnvae_cb_pack_weights(const float* w, int Cout, int Cin, int kind, int parts, const unsigned* amax,
                            void* packed, void* stream);
+/* Two-part operands (parts = 2; fp32-accurate: three fp16 products per multiply-add, error <= 3 * 2^-22 of sum |a||w|):
+ * the accumulators are multiplied by out_scale and divided by the power-of-two scales of the records absmax_act (NULL:
+ * the input was written with a fixed scale, whose inverse is out_scale) and absmax_w (the record the weights were packed
+ * with). */
 int mdnvae_cb_conv(const void* act, long part_stride, const void* packed_w, const float* bias, void* out, int out16,
                    int B, int Cout, int Cin, int kind, int rows, int pitch, int PP, int parts, float out_scale,
-                   void* stream);
+                   const unsigned* absmax_act, const unsigned* absmax_w, void* stream);
 /* stats[plane] = {mean, 1/sqrt(var + 1e-5)} (nn.InstanceNorm2d defaults) over the H x W valid entries of
  * planes stored with a row pitch (planes of at most 2048 positions). */
 int mdnvae_cb_plane_stats(const float* y, long nplanes, int H, int W, int pitch, long plane_stride, float* stats,
@@ -459,7 +463,9 @@ int mdnvae_cb_plane_stats(const float* y, long nplanes, int H, int W, int pitch,
  * compute_stats = 1: stats [B * C][2] is an output - the pass stages its planes in LDS and takes
  * {mean, rstd} from them first (planes of a multiple of 4 and at most 5000 positions);
  * compute_stats = 0: stats is read (mdnvae_plane_stats / mdnvae_cb_plane_stats).
- * y16 = 1 (here and in mdnvae_cb_norm_bwd): y holds fp16 planes (mdnvae_cb_conv with out16). */
+ * y16 = 1 (here and in mdnvae_cb_norm_bwd): y holds fp16 planes (mdnvae_cb_conv with out16).
+ * parts = 2: the operand is written as two fp16 parts of a * scale (a power of two with |a| * scale < 65504: a
+ * normalised plane is bounded by sqrt(H W), each residual block adds as much). */
 int mdnvae_cb_norm_fwd(const void* y, int y16, float* stats, int compute_stats, const float* skip, float* stream_out,
                        void* act, long part_stride, int B, int C, int H, int W, int pitch_y, long Qy, int relu, int mode,
                        int PP, int parts, float scale, void* stream);
@@ -472,19 +478,25 @@ int mdnvae_cb_norm_fwd(const void* y, int y16, float* stats, int compute_stats, 
  * and the result leaves as the operand of the layer's own data / weight gradient (omode 0: zero
  * border of 2, pitch W + 2, H + 4 rows, for kind 2;  omode 1: zero row / column behind, pitch W + 1,
  * for kind 3) or as fp32 planes [B][C][H * W] (omode 2).  gsum [B * C]: plane sums of dc (the
- * convolution-bias gradient before the sum over the batch). */
+ * convolution-bias gradient before the sum over the batch).
+ * parts = 2: dc leaves as two fp16 parts scaled by the power of two of the record absmax_dc, the largest |dc|:
+ * run the pass once with absmax_probe (a cleared record; nothing else is written) and again with that record as
+ * absmax_dc; the same record goes to the products that read dc.  (The exact maximum keeps all 22 bits of the two
+ * parts; a bound from the inputs' magnitudes would give away one bit per factor of two it is loose by.) */
 int mdnvae_cb_norm_bwd(const float* g, int gmode, int pitch_g, long Qg, const float* base, float* sum_out,
                        const void* y, int y16, const float* stats, int pitch_y, long Qy, int relu, int B, int C, int H,
                        int W, int omode, void* dc, long part_stride, int PP, int parts, float scale, float* gsum,
-                       void* stream);
+                       const unsigned* absmax_dc, unsigned* absmax_probe, void* stream);
 /* dW [Cout][Cin][3][3] from the channel-blocked output gradient g (as mdnvae_cb_norm_bwd leaves it) and the
  * layer's channel-blocked input.  planes = 1: stride-1 reflection layer (g: omode 0, act: mode 0, same
  * pitch); planes = 4: stride-2 layer (g: omode 1, act: mode 1).  [kbeg, kend): the positions of g that
- * hold output pixels, widened to multiples of 32 (everything else in g is zero). */
-size_t mdnvae_cb_wgrad_workspace_floats(int B, int Cout, int Cin, int planes);
+ * hold output pixels, widened to multiples of 32 (everything else in g is zero).
+ * parts = 2: both operands hold two fp16 parts (part strides in bytes); the result is multiplied by out_scale (the
+ * inverse of the activations' fixed scale) and divided by the scale of absmax_g. */
+size_t mdnvae_cb_wgrad_workspace_floats(int B, int Cout, int Cin, int planes, int parts);
 int mdnvae_cb_wgrad(const void* g, const void* act, float* workspace, float* grad_w, int B, int Cout, int Cin,
                     int planes, int PPg, int PPa, int kbeg, int kend, int pitch, int parts, float out_scale,
-                    void* stream);
+                    long g_part_stride, long act_part_stride, const unsigned* absmax_g, void* stream);
 
 /* ---- optimiser ---------------------------------------------------------------------------
  * torch.optim.Adam(lr=1e-3) of function/VAE_CNN_NN.py:204,219 over one flat buffer of n floats

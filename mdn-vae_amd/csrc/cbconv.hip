@@ -37,6 +37,28 @@ constexpr int CB_MAXTAPS = 9;
 constexpr int CB_NBUF = 4;            // weight stage buffers: three stages in flight
 constexpr int CB_ROWS = 256;          // output rows (positions) per workgroup
 
+// Largest-magnitude records (MDNVAE_ABSMAX_SLOTS partial maxima, bit patterns of floats) give the power-of-two scales of
+// tensors stored as two fp16 parts: the scale brings the recorded magnitude into [2^14, 2^15).
+__device__ __forceinline__ float cb_pow2_scale(unsigned bits) {
+    const int e = (int)((bits >> 23) & 0xffu);
+    if (e == 0 || e == 255) return 1.0f;
+    const int se = 268 - e;
+    return __uint_as_float((unsigned)(se < 253 ? se : 253) << 23);
+}
+static_assert(MDNVAE_ABSMAX_SLOTS == 64, "one slot per lane");
+__device__ __forceinline__ unsigned cb_slot_max(const unsigned* __restrict__ slots) {      // whole waves only
+    unsigned m = slots[threadIdx.x & 63];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+    return m;
+}
+// record of a wave's largest magnitude: one atomic per wave, spread over the slots
+__device__ __forceinline__ void cb_record_max(unsigned* __restrict__ slots, unsigned m, unsigned spread) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(slots + (spread & (MDNVAE_ABSMAX_SLOTS - 1)), m);
+}
+
 struct CbConv {
     const char* act;        // channel-blocked input, part 0
     long part_stride;       // bytes between parts
@@ -49,7 +71,9 @@ struct CbConv {
     int halo;               // largest tap offset in positions
     int ntot;               // output planes per sample
     int tap_lds[CB_MAXTAPS + 3];   // byte offset of tap t in the slab: (plane * 2 * slab positions + offset) * 16
-    float out_scale;        // accumulators are multiplied by this (undoes the power-of-two scales of fp16 parts)
+    float out_scale;        // accumulators are multiplied by this (undoes a fixed power-of-two scale of fp16 parts)
+    const unsigned* amax_a; // records the input / the weights were scaled by (their scales are undone too), or null
+    const unsigned* amax_w;
 };
 
 template <int N>
@@ -67,7 +91,8 @@ __device__ __forceinline__ void cb_wait_vm() {
 // weight stages, and a younger slab, in flight) and every LDS read of stage s is complete; the barrier makes both
 // true for all waves.  Fragments are read one tap ahead of the MFMAs that use them, across stage boundaries too.
 // Past the end the last stage / chunk is fetched again into buffers nobody reads any more, which keeps the counts
-// the same in every iteration.
+// the same in every iteration.  NSB = 1 (one slab buffer, where two do not fit): the next chunk's slab is requested
+// after the chunk's last gate and waited for on the spot.
 //
 // PERSIST: one workgroup per CU walks tiles blockIdx.x, + gridDim.x, ...: the first operands of the next tile are
 // requested before this tile's epilogue, and the epilogue's stores drain to memory under the next tile's MFMAs
@@ -102,6 +127,9 @@ __global__ __launch_bounds__(512) void cb_conv_kernel(CbConv p, int nblk, int nt
     const int nstage = p.nchunk * SPC;
     const long chunk_stride = (long)NGP * p.B * p.PP * 16;
     const long Rend = (long)p.B * p.Qr;
+    float oscale = p.out_scale;
+    if (p.amax_a) oscale /= cb_pow2_scale(cb_slot_max(p.amax_a));
+    if (p.amax_w) oscale /= cb_pow2_scale(cb_slot_max(p.amax_w));
 
     int taps[TPS * SPC];
 #pragma unroll
@@ -211,7 +239,7 @@ __global__ __launch_bounds__(512) void cb_conv_kernel(CbConv p, int nblk, int nt
     };
     // gate of a stage whose position in its chunk is r (see the head comment)
     auto gate = [&](int r) {
-        const bool slab_young = (r == 1 || r == 2);
+        const bool slab_young = NSB > 1 && (r == 1 || r == 2);
         if (NSW < 8 && wid >= NSW) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         } else if (WREM && wid < WREM) {
@@ -252,7 +280,7 @@ __global__ __launch_bounds__(512) void cb_conv_kernel(CbConv p, int nblk, int nt
                 for (int e = 0; e < 16; ++e) acc[m][n][e] = 0.0f;
 
         gate(0);
-        stage_slab(min(NSB - 1, p.nchunk - 1), NSB - 1);
+        if (NSB > 1) stage_slab(min(NSB - 1, p.nchunk - 1), NSB - 1);
         stage_w(min(CB_NBUF - 1, nstage - 1), CB_NBUF - 1);
         Frags cur, nxt;
         load_tap(cur, wring, slabs, 0, 0);
@@ -274,6 +302,12 @@ __global__ __launch_bounds__(512) void cb_conv_kernel(CbConv p, int nblk, int nt
                 gate(r1);
                 if (r1 == 0) stage_slab(min(c + NSB, p.nchunk - 1), c % NSB);
                 stage_w(min(s + CB_NBUF, nstage - 1), s % CB_NBUF);
+                if (NSB == 1 && r1 == 0 && s + 1 < nstage) {
+                    // one slab buffer (slabs too large for two): the next chunk is requested only now that nobody reads
+                    // this one any more, and has to land before its first tap is read
+                    cb_wait_vm<0>();
+                    __builtin_amdgcn_s_barrier();
+                }
                 if (s + 1 < nstage)
                     load_tap(nxt, wring + ((s + 1) % CB_NBUF) * WSTAGE, slabs + ((r1 == 0 ? c + 1 : c) % NSB) * SLAB, r1 * TPS, 0);
                 __builtin_amdgcn_sched_barrier(0);
@@ -319,10 +353,10 @@ __global__ __launch_bounds__(512) void cb_conv_kernel(CbConv p, int nblk, int nt
 #pragma unroll
                             for (int g = 0; g < 4; ++g) {
                                 cb_f4 o;
-                                o.x = acc[m][n][4 * g] * p.out_scale + bv[n];
-                                o.y = acc[m][n][4 * g + 1] * p.out_scale + bv[n];
-                                o.z = acc[m][n][4 * g + 2] * p.out_scale + bv[n];
-                                o.w = acc[m][n][4 * g + 3] * p.out_scale + bv[n];
+                                o.x = acc[m][n][4 * g] * oscale + bv[n];
+                                o.y = acc[m][n][4 * g + 1] * oscale + bv[n];
+                                o.z = acc[m][n][4 * g + 2] * oscale + bv[n];
+                                o.w = acc[m][n][4 * g + 3] * oscale + bv[n];
                                 *reinterpret_cast<cb_f4*>(ep + (wn * 32 + l32) * ROWP + (wm * WROWS) % ROWS_P + m * 32 + 8 * g + 4 * h) = o;
                             }
                     }
@@ -575,6 +609,8 @@ struct CbNormBwd {
     int PP, opitch;
     float scale;
     float* gsum;             // [B * C] plane sums of the result (conv bias gradient), or null
+    const unsigned* amax_dc; // two fp16 parts: the record of the largest |dc| (a probe run of this pass); its scale replaces `scale`
+    unsigned* amax_probe;    // probe run: nothing is written but the largest |dc| into this record
 };
 
 __device__ __forceinline__ float cb_fold_gather(const float* __restrict__ gp, int y, int x, int H, int W, int Wp) {
@@ -601,6 +637,8 @@ __global__ __launch_bounds__(256) void cb_norm_bwd_kernel(CbNormBwd p) {
     __shared__ float red[4][3 * CH];
     const int cg = blockIdx.x, b = blockIdx.y;
     const int HW = p.H * p.W;
+    const float dc_scale = (PARTS == 2 && p.amax_dc) ? cb_pow2_scale(cb_slot_max(p.amax_dc)) : p.scale;
+    unsigned smax = 0;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ndom = p.omode == 2 ? HW : p.PP;
     const unsigned mop = (unsigned)(0x100000000ull / (unsigned)p.opitch) + 1u;
@@ -637,7 +675,7 @@ __global__ __launch_bounds__(256) void cb_norm_bwd_kernel(CbNormBwd p) {
                 else if (p.gmode == 2)
                     gv = p.g[((long)b * 4 * p.C + ((r & 1) * 2 + (c & 1)) * p.C + cg * CH + e) * p.Qg + (r >> 1) * p.pitch_g + (c >> 1)];
                 if (p.base) gv += p.base[pl * HW + r * p.W + c];
-                if (p.sum_out) p.sum_out[pl * HW + r * p.W + c] = gv;
+                if (p.sum_out && !p.amax_probe) p.sum_out[pl * HW + r * p.W + c] = gv;
                 const float x = (static_cast<const float*>(p.y)[pl * p.Qy + r * p.pitch_y + c] - mean[e]) * rstd[e];
                 if (p.relu && !(x > 0.0f)) gv = 0.0f;
                 dn[i][e] = gv;
@@ -671,6 +709,7 @@ __global__ __launch_bounds__(256) void cb_norm_bwd_kernel(CbNormBwd p) {
     float gs[CH];
 #pragma unroll
     for (int e = 0; e < CH; ++e) gs[e] = 0.0f;
+    smax = 0;
 #pragma unroll
     for (int i = 0; i < NPOS; ++i) {
         const int pos = threadIdx.x + 256 * i;
@@ -684,7 +723,9 @@ __global__ __launch_bounds__(256) void cb_norm_bwd_kernel(CbNormBwd p) {
         for (int e = 0; e < CH; ++e) {
             o[e] = ok ? rstd[e] * (dn[i][e] - m1[e] - xh[i][e] * m2[e]) : 0.0f;
             gs[e] += o[e];
+            smax = max(smax, __float_as_uint(o[e]) & 0x7fffffffu);
         }
+        if (p.amax_probe) continue;
         if (p.omode == 2) {
 #pragma unroll
             for (int e = 0; e < CH; ++e)
@@ -694,9 +735,13 @@ __global__ __launch_bounds__(256) void cb_norm_bwd_kernel(CbNormBwd p) {
                 float o8[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o8[e] = o[e];
-                cb_store8<PARTS>(o8, p.scale, p.dc + (((long)cg * p.B + b) * p.PP + pos) * 16, p.part_stride);
+                cb_store8<PARTS>(o8, dc_scale, p.dc + (((long)cg * p.B + b) * p.PP + pos) * 16, p.part_stride);
             }
         }
+    }
+    if (p.amax_probe) {
+        cb_record_max(p.amax_probe, smax, (blockIdx.x + blockIdx.y * gridDim.x) * 4 + wave);
+        return;
     }
     if (p.gsum) {
 #pragma unroll
@@ -870,6 +915,7 @@ __global__ __launch_bounds__(NT) void cb_norm_bwd_lds_kernel(CbNormBwd p) {
     const int g8 = blockIdx.x, b = blockIdx.y;
     const int HW = p.H * p.W;
     const long pl0 = (long)b * p.C + g8 * 8;
+    const float dc_scale = (PARTS == 2 && p.amax_dc) ? cb_pow2_scale(cb_slot_max(p.amax_dc)) : p.scale;
     cb_dma_bytes<NT>(reinterpret_cast<const char*>(static_cast<const YT*>(p.y) + pl0 * Qy), reinterpret_cast<char*>(ybuf),
                      8 * Qy * (int)sizeof(YT));
     if (GMODE == 2) {
@@ -954,7 +1000,7 @@ __global__ __launch_bounds__(NT) void cb_norm_bwd_lds_kernel(CbNormBwd p) {
             s2[e] += gv * x;
         }
     }
-    if (BASE && p.sum_out) {
+    if (BASE && p.sum_out && !p.amax_probe) {
 #pragma unroll
         for (int i = 0; i < NPOS; ++i)
             if (ysrc[i] >= 0) {
@@ -968,6 +1014,7 @@ __global__ __launch_bounds__(NT) void cb_norm_bwd_lds_kernel(CbNormBwd p) {
     float gs[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) gs[e] = 0.0f;
+    unsigned omax = 0;
 #pragma unroll
     for (int i = 0; i < NPOS; ++i) {
         const int pos = threadIdx.x + NT * i;
@@ -978,8 +1025,13 @@ __global__ __launch_bounds__(NT) void cb_norm_bwd_lds_kernel(CbNormBwd p) {
         for (int e = 0; e < 8; ++e) {
             o[e] = ok ? rstd[e] * (dn[i][e] - s1[e] * inv - xh[i][e] * (s2[e] * inv)) : 0.0f;
             gs[e] += o[e];
+            omax = max(omax, __float_as_uint(o[e]) & 0x7fffffffu);
         }
-        cb_store8<PARTS>(o, p.scale, p.dc + (((long)g8 * p.B + b) * p.PP + pos) * 16, p.part_stride);
+        if (!p.amax_probe) cb_store8<PARTS>(o, dc_scale, p.dc + (((long)g8 * p.B + b) * p.PP + pos) * 16, p.part_stride);
+    }
+    if (p.amax_probe) {
+        cb_record_max(p.amax_probe, omax, (blockIdx.x + blockIdx.y * gridDim.x) * (NT / 64) + (threadIdx.x >> 6));
+        return;
     }
     if (p.gsum) {
         cb_block_sum8<NT>(gs, red);
@@ -1001,10 +1053,10 @@ __global__ __launch_bounds__(NT) void cb_norm_bwd_lds_kernel(CbNormBwd p) {
 // LDS through the transposing read (ds_read_b64_tr_b16: a 16-lane group reads 4 positions x 16 channels and each lane
 // receives 4 consecutive positions of its channel).  G is the output gradient in the zero-bordered layout the
 // instance-norm backward pass writes (zeros wherever there is no output pixel), so border and scratch positions add
-// nothing and a chunk of the reduction is simply 128 consecutive positions; the activation slab of a chunk carries the
-// span of the tap shifts as a halo.  v_mfma_f32_16x16x32: a wave owns 16 output channels x (CIT x 16) input channels
-// x 9 taps.  Workgroup: 8 waves as 4 (co) x 2 (ci) = 64 co x CIT * 32 ci.  Two chunk buffers, the next chunk's LDS-DMA
-// runs under the current chunk's MFMAs.  partial [Z][9][Cout][Cin], summed by conv_wgrad_reduce_kernel.
+// nothing and a chunk of the reduction is simply KC consecutive positions; the activation slab of a chunk carries the
+// span of the tap shifts as a halo.  v_mfma_f32_16x16x32 (bf16, or fp16 for two-part operands).  Two chunk buffers, the
+// next chunk's LDS-DMA runs under the current chunk's MFMAs.  partial [Z][9][Cout][Cin], summed in fixed order by
+// cb_wgrad_reduce_kernel.
 typedef short cb_s4 __attribute__((ext_vector_type(4)));
 typedef short cb_s8 __attribute__((ext_vector_type(8)));
 
@@ -1020,6 +1072,7 @@ struct CbWgrad {
     int tap_plane[9];
     int spg;                  // samples per z group
     float out_scale;
+    const unsigned* amax_g;   // two fp16 parts: the record G was scaled by (undone in the result), or null
 };
 
 // A wave owns COT x 16 output channels x 16 input channels x 9 taps (the nine shifted activation fragments of a k step
@@ -1028,14 +1081,14 @@ struct CbWgrad {
 // the four groups a half-wave's transposed read touches fall on different banks.
 template <int PARTS, int NPL, int COT, int WCO, int WCI, int KC>
 __global__ __launch_bounds__(512) void cb_wgrad_kernel(CbWgrad p) {
-    static_assert(PARTS == 1, "fp16 parts of the weight gradient: not built yet");
     static_assert(WCO * WCI == 8 && KC % 64 == 0, "eight waves; chunks of whole 64-position blocks");
     constexpr int GSG = KC + 4, GSA = KC + 68;
     constexpr int GG = WCO * COT * 2;                 // channel groups of the G tile
     constexpr int GA = WCI * 2;                       // channel groups of the activation tile
     constexpr int GBUF = GG * GSG * 16;               // bytes: G tile of one chunk
     constexpr int ABUF = NPL * GA * GSA * 16;
-    constexpr int BUF = GBUF + ABUF;
+    constexpr int PBUF = GBUF + ABUF;                 // one part of a chunk
+    constexpr int BUF = PARTS * PBUF;
     constexpr int GBL = KC / 64, ABL = KC / 64 + 1;   // 64-position blocks per group
     constexpr int GP = GG * GBL, AP = NPL * GA * ABL; // 1 KiB pieces per chunk
     constexpr int NP = GP + AP;
@@ -1085,8 +1138,11 @@ __global__ __launch_bounds__(512) void cb_wgrad_kernel(CbWgrad p) {
                 const int PPx = isg[i] ? p.PPg : p.PPa;
                 const int pos = min(max(kc + rel[i], 0), PPx - 1);
                 const char* base = isg[i] ? p.g : p.act;
-                __builtin_amdgcn_global_load_lds(CB_GLOBAL_PTR(base + (src0[i] + (long)b * PPx + pos) * 16),
-                                                 CB_LDS_PTR(smem + buf * BUF + dst[i]), 16, 0, 0);
+                const long pstride = isg[i] ? p.g_part_stride : p.a_part_stride;
+#pragma unroll
+                for (int pt = 0; pt < PARTS; ++pt)
+                    __builtin_amdgcn_global_load_lds(CB_GLOBAL_PTR(base + pt * pstride + (src0[i] + (long)b * PPx + pos) * 16),
+                                                     CB_LDS_PTR(smem + buf * BUF + pt * PBUF + dst[i]), 16, 0, 0);
             }
         }
     };
@@ -1131,20 +1187,33 @@ __global__ __launch_bounds__(512) void cb_wgrad_kernel(CbWgrad p) {
         const int kc = p.kbeg + (ci % ncs) * KC;
         const int nks = min(KC, p.kend - kc) >> 5;
         for (int ks = 0; ks < nks; ++ks) {
-            cb_bf8 A[COT];
+            cb_bf8 A[PARTS][COT];
 #pragma unroll
-            for (int c = 0; c < COT; ++c) A[c] = frag(buf + ga_addr[c] + ks * 512);
+            for (int pt = 0; pt < PARTS; ++pt)
+#pragma unroll
+                for (int c = 0; c < COT; ++c) A[pt][c] = frag(buf + pt * PBUF + ga_addr[c] + ks * 512);
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
-                const cb_bf8 Bv = frag(buf + aa_addr + toff[t] + ks * 512);
+                cb_bf8 Bv[PARTS];
 #pragma unroll
-                for (int c = 0; c < COT; ++c)
-                    acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[c], Bv, acc[t][c], 0, 0, 0);
+                for (int pt = 0; pt < PARTS; ++pt) Bv[pt] = frag(buf + pt * PBUF + aa_addr + toff[t] + ks * 512);
+#pragma unroll
+                for (int c = 0; c < COT; ++c) {
+                    if constexpr (PARTS == 2) {
+                        // two fp16 parts per operand: high x low, low x high, high x high
+                        acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(cb_h8, A[0][c]), __builtin_bit_cast(cb_h8, Bv[PARTS - 1]), acc[t][c], 0, 0, 0);
+                        acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(cb_h8, A[PARTS - 1][c]), __builtin_bit_cast(cb_h8, Bv[0]), acc[t][c], 0, 0, 0);
+                        acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(cb_h8, A[0][c]), __builtin_bit_cast(cb_h8, Bv[0]), acc[t][c], 0, 0, 0);
+                    } else {
+                        acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[0][c], Bv[0], acc[t][c], 0, 0, 0);
+                    }
+                }
             }
         }
     }
     // acc[t][c][reg]: row (co) = 4 (lane >> 4) + reg, column (ci) = lane & 15
     float* dstp = p.partial + (long)blockIdx.z * 9 * p.Cout * p.Cin;
+    const float oscale = p.amax_g ? p.out_scale / cb_pow2_scale(cb_slot_max(p.amax_g)) : p.out_scale;
     const int cin = ci0 + wb * 16 + li;
     if (cin < p.Cin) {
 #pragma unroll
@@ -1154,7 +1223,7 @@ __global__ __launch_bounds__(512) void cb_wgrad_kernel(CbWgrad p) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int co = co0 + (wa * COT + c) * 16 + 4 * q4 + r;
-                    if (co < p.Cout) dstp[((long)t * p.Cout + co) * p.Cin + cin] = acc[t][c][r] * p.out_scale;
+                    if (co < p.Cout) dstp[((long)t * p.Cout + co) * p.Cin + cin] = acc[t][c][r] * oscale;
                 }
     }
 }
@@ -1191,12 +1260,15 @@ static int cb_round_up(int v, int m) { return (v + m - 1) / m * m; }
 struct CbShape {
     int NT, TPS, SPC, NGP, NJ, pmode, nout, kch;
 };
-static bool cb_shape(int kind, int Cout, int Cin, CbShape& sh) {
-    if (kind == 0) { sh = {6, 3, 3, 2, 8, 0, Cout, Cin}; return true; }
-    if (kind == 1 && Cout > 96) { sh = {6, 3, 3, 8, 5, 0, Cout, Cin}; return true; }
-    if (kind == 1) { sh = {3, 3, 3, 8, 6, 0, Cout, Cin}; return true; }
-    if (kind == 2) { sh = {6, 3, 3, 2, 8, 1, Cin, Cout}; return true; }
-    if (kind == 3) { sh = {6, 2, 2, 2, 8, 2, 4 * Cin, Cout}; return true; }
+static bool cb_shape(int kind, int Cout, int Cin, int parts, CbShape& sh) {
+    // two-part operands: one tap per stage (the stage ring holds both parts)
+    const int tps9 = parts == 2 ? 1 : 3, spc9 = parts == 2 ? 9 : 3;
+    const int tps4 = parts == 2 ? 1 : 2, spc4 = parts == 2 ? 4 : 2;
+    if (kind == 0) { sh = {6, tps9, spc9, 2, 8, 0, Cout, Cin}; return true; }
+    if (kind == 1 && Cout > 96) { sh = {6, tps9, spc9, 8, 5, 0, Cout, Cin}; return true; }
+    if (kind == 1) { sh = {3, tps9, spc9, 8, 6, 0, Cout, Cin}; return true; }
+    if (kind == 2) { sh = {6, tps9, spc9, 2, 8, 1, Cin, Cout}; return true; }
+    if (kind == 3) { sh = {6, tps4, spc4, 2, 8, 2, 4 * Cin, Cout}; return true; }
     return false;
 }
 
@@ -1225,7 +1297,7 @@ static int cb_launch_conv(const CbConv& a, int nblk, hipStream_t st) {
 
 template <int PARTS, int NPL, int COT, int WCO, int WCI, int KC>
 static int cb_launch_wgrad(const CbWgrad& a, int ntiles, int Gz, hipStream_t st) {
-    constexpr size_t lds = (size_t)2 * ((size_t)WCO * COT * 2 * (KC + 4) * 16 + (size_t)NPL * WCI * 2 * (KC + 68) * 16);
+    constexpr size_t lds = (size_t)2 * PARTS * ((size_t)WCO * COT * 2 * (KC + 4) * 16 + (size_t)NPL * WCI * 2 * (KC + 68) * 16);
     static_assert(lds <= 160 * 1024, "two chunk buffers must fit the LDS");
     auto kern = cb_wgrad_kernel<PARTS, NPL, COT, WCO, WCI, KC>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1236,10 +1308,9 @@ static int cb_launch_wgrad(const CbWgrad& a, int ntiles, int Gz, hipStream_t st)
 
 // tile shapes of the weight gradient: one plane: 96 co x 64 ci, chunks of 128 positions; four parity planes: 192 co x
 // 32 ci, chunks of 64 (sixteen group-planes of activations per chunk)
-static void cb_wgrad_tiles(int planes, int Cout, int Cin, int& tco, int& tci) {
-    tco = planes == 4 ? 192 : 96;
-    tci = planes == 4 ? 32 : 64;
-    (void)Cout; (void)Cin;
+static void cb_wgrad_tiles(int planes, int parts, int& tco, int& tci) {
+    tco = planes == 4 ? (parts == 2 ? 128 : 192) : 96;
+    tci = planes == 4 ? (parts == 2 ? 16 : 32) : 64;      // two parts of sixteen group-planes: one ci tile per workgroup fits
 }
 static int cb_wgrad_groups(int B, int ntiles) {
     int G = 256 / ntiles;
@@ -1255,7 +1326,7 @@ extern "C" {
 
 size_t mdnvae_cb_packed_bytes(int Cout, int Cin, int kind, int parts) {
     CbShape sh;
-    if (parts < 1 || parts > 2 || !cb_shape(kind, Cout, Cin, sh) || sh.kch % 16 || Cout % 8 || Cin % 8) return 0;
+    if (parts < 1 || parts > 2 || !cb_shape(kind, Cout, Cin, parts, sh) || sh.kch % 16 || Cout % 8 || Cin % 8) return 0;
     const int nblk = (sh.nout + sh.NT * 32 - 1) / (sh.NT * 32);
     return (size_t)nblk * (sh.kch / 16) * sh.SPC * sh.TPS * sh.NT * parts * 1024;
 }
@@ -1267,7 +1338,7 @@ int mdnvae_cb_pack_weights(const float* w, int Cout, int Cin, int kind, int part
     MV_REQUIRE(bytes > 0, E_SHAPE, "mdnvae_cb_pack_weights: unsupported shape (%d -> %d, kind %d, parts %d)", Cin, Cout, kind, parts);
     MV_REQUIRE(parts == 1 || amax, E_ARG, "mdnvae_cb_pack_weights: two fp16 parts need the tensor's largest magnitude");
     CbShape sh;
-    cb_shape(kind, Cout, Cin, sh);
+    cb_shape(kind, Cout, Cin, parts, sh);
     const int nblk = (sh.nout + sh.NT * 32 - 1) / (sh.NT * 32);
     const long total = (long)(bytes / 2);
     hipLaunchKernelGGL(cb_pack_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w,
@@ -1277,14 +1348,16 @@ int mdnvae_cb_pack_weights(const float* w, int Cout, int Cin, int kind, int part
 }
 
 int mdnvae_cb_conv(const void* act, long part_stride, const void* packed_w, const float* bias, void* out, int out16, int B,
-                   int Cout, int Cin, int kind, int rows, int pitch, int PP, int parts, float out_scale, void* stream) {
+                   int Cout, int Cin, int kind, int rows, int pitch, int PP, int parts, float out_scale,
+                   const unsigned* absmax_act, const unsigned* absmax_w, void* stream) {
     MV_REQUIRE(B >= 0, E_ARG, "mdnvae_cb_conv: negative batch");
     if (B == 0) return 0;
     MV_REQUIRE(act && packed_w && out, E_ARG, "mdnvae_cb_conv: null pointer");
     MV_REQUIRE(parts == 1 || parts == 2, E_ARG, "mdnvae_cb_conv: parts = %d (1 or 2)", parts);
     CbShape sh;
-    MV_REQUIRE(cb_shape(kind, Cout, Cin, sh) && sh.kch % 16 == 0, E_SHAPE, "mdnvae_cb_conv: unsupported product (%d -> %d, kind %d)",
+    MV_REQUIRE(cb_shape(kind, Cout, Cin, parts, sh) && sh.kch % 16 == 0, E_SHAPE, "mdnvae_cb_conv: unsupported product (%d -> %d, kind %d)",
                Cin, Cout, kind);
+    MV_REQUIRE(parts == 1 || (absmax_w && !out16), E_ARG, "mdnvae_cb_conv: two-part operands need the weights' record and fp32 output");
     MV_REQUIRE(rows >= 1 && pitch >= 2, E_SHAPE, "mdnvae_cb_conv: bad grid %d x %d", rows, pitch);
     CbConv a{};
     a.act = static_cast<const char*>(act);
@@ -1298,6 +1371,7 @@ int mdnvae_cb_conv(const void* act, long part_stride, const void* packed_w, cons
     a.ntot = sh.nout;
     MV_REQUIRE(!out16 || kind <= 1, E_ARG, "mdnvae_cb_conv: fp16 output is for the forward products");
     a.out_scale = out_scale;
+    a.amax_a = absmax_act; a.amax_w = absmax_w;
     const int slabpos = sh.NJ * 64;
     int ntaps = 0;
     if (kind == 0 || kind == 2) {
@@ -1318,9 +1392,14 @@ int mdnvae_cb_conv(const void* act, long part_stride, const void* packed_w, cons
     MV_REQUIRE(CB_ROWS + 2 * a.halo <= slabpos, E_SHAPE, "mdnvae_cb_conv: pitch %d needs a slab of %d positions (%d fit)", pitch,
                CB_ROWS + 2 * a.halo, slabpos);
     MV_REQUIRE(PP >= a.Qr + a.halo, E_SHAPE, "mdnvae_cb_conv: input planes of %d positions are shorter than %d", PP, a.Qr + a.halo);
-    MV_REQUIRE(parts == 1, E_SHAPE, "mdnvae_cb_conv: two-part operands are not built yet");
     const int nblk = (sh.nout + sh.NT * 32 - 1) / (sh.NT * 32);
     hipStream_t st = (hipStream_t)stream;
+    if (parts == 2) {
+        if (kind == 0 || kind == 2) return cb_launch_conv<2, 2, 8, 4, 2, 2, 3, 1, 9, true, 8, 2, false>(a, nblk, st);
+        if (kind == 3) return cb_launch_conv<2, 2, 8, 4, 2, 2, 3, 1, 4, true, 8, 2, false>(a, nblk, st);
+        if (sh.NT == 6) return cb_launch_conv<2, 8, 5, 4, 2, 2, 3, 1, 9, false, 8, 1, false>(a, nblk, st);
+        return cb_launch_conv<2, 8, 6, 8, 1, 1, 3, 1, 9, false, 8, 1, false>(a, nblk, st);
+    }
     if (kind == 0 && out16) return cb_launch_conv<1, 2, 8, 4, 2, 2, 3, 3, 3, true, 8, 2, true>(a, nblk, st);
     if (kind == 0 || kind == 2) return cb_launch_conv<1, 2, 8, 4, 2, 2, 3, 3, 3, true, 8, 2, false>(a, nblk, st);
     if (kind == 3) return cb_launch_conv<1, 2, 8, 4, 2, 2, 3, 2, 2, true, 8, 2, false>(a, nblk, st);
@@ -1402,10 +1481,11 @@ int mdnvae_cb_norm_fwd(const void* y, int y16, float* stats, int compute_stats, 
 
 int mdnvae_cb_norm_bwd(const float* g, int gmode, int pitch_g, long Qg, const float* base, float* sum_out, const void* y,
                        int y16, const float* stats, int pitch_y, long Qy, int relu, int B, int C, int H, int W, int omode,
-                       void* dc, long part_stride, int PP, int parts, float scale, float* gsum, void* stream) {
+                       void* dc, long part_stride, int PP, int parts, float scale, float* gsum, const unsigned* absmax_dc,
+                       unsigned* absmax_probe, void* stream) {
     MV_REQUIRE(B >= 0 && C >= 1 && H >= 3 && W >= 3, E_SHAPE, "mdnvae_cb_norm_bwd: bad shape");
     if (B == 0) return 0;
-    MV_REQUIRE(y && stats && dc && (g || gmode == 3), E_ARG, "mdnvae_cb_norm_bwd: null pointer");
+    MV_REQUIRE(y && stats && (dc || absmax_probe) && (g || gmode == 3), E_ARG, "mdnvae_cb_norm_bwd: null pointer");
     MV_REQUIRE(gmode >= 0 && gmode <= 3 && omode >= 0 && omode <= 2, E_ARG, "mdnvae_cb_norm_bwd: gmode %d / omode %d", gmode, omode);
     MV_REQUIRE(gmode != 3 || base, E_ARG, "mdnvae_cb_norm_bwd: no gradient source");
     MV_REQUIRE(parts == 1 || parts == 2, E_ARG, "mdnvae_cb_norm_bwd: parts = %d", parts);
@@ -1416,6 +1496,9 @@ int mdnvae_cb_norm_bwd(const float* g, int gmode, int pitch_g, long Qg, const fl
     a.B = B; a.C = C; a.H = H; a.W = W; a.omode = omode;
     a.dc = static_cast<char*>(dc);
     a.part_stride = part_stride; a.PP = PP; a.scale = scale; a.gsum = gsum;
+    a.amax_dc = absmax_dc; a.amax_probe = absmax_probe;
+    MV_REQUIRE(parts == 1 || omode == 2 || absmax_dc || absmax_probe, E_ARG,
+               "mdnvae_cb_norm_bwd: two fp16 parts need the record of the result's largest magnitude (a probe run)");
     a.opitch = omode == 0 ? W + 2 : (omode == 1 ? W + 1 : W);
     hipStream_t st = (hipStream_t)stream;
     if (omode == 2) {
@@ -1434,17 +1517,18 @@ int mdnvae_cb_norm_bwd(const float* g, int gmode, int pitch_g, long Qg, const fl
     const size_t gfl = gmode == 3 ? 0 : (gmode == 2 ? (size_t)32 * Qg : (size_t)8 * Qg + 4);
     const size_t lds = (size_t)64 * 4 + 8 * (size_t)Qy * (y16 ? 2 : 4) + gfl * 4;
     const bool aligned = Qy % (y16 ? 8 : 4) == 0 && (gmode == 3 || gmode == 0 || Qg % 4 == 0);
-    if (parts == 1 && aligned && lds <= 160 * 1024 && PP <= 2048 && (!sum_out || base) && gmode != 3) {
-#define MV_BWD(G_, O_, B_, NT_, NP_, T_)                                                                                      \
+    if (aligned && lds <= 160 * 1024 && PP <= 2048 && (!sum_out || base) && gmode != 3 && !(parts == 2 && y16)) {
+#define MV_BWD(P_, G_, O_, B_, NT_, NP_, T_)                                                                                  \
     do {                                                                                                                      \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cb_norm_bwd_lds_kernel<1, G_, O_, B_, NT_, NP_, T_>),         \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cb_norm_bwd_lds_kernel<P_, G_, O_, B_, NT_, NP_, T_>),        \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                                    \
-        hipLaunchKernelGGL((cb_norm_bwd_lds_kernel<1, G_, O_, B_, NT_, NP_, T_>), grid, dim3(NT_), lds, st, a);               \
+        hipLaunchKernelGGL((cb_norm_bwd_lds_kernel<P_, G_, O_, B_, NT_, NP_, T_>), grid, dim3(NT_), lds, st, a);              \
     } while (0)
 #define MV_BWD_T(G_, O_, B_, NT_, NP_)                          \
     do {                                                        \
-        if (y16) MV_BWD(G_, O_, B_, NT_, NP_, _Float16);        \
-        else MV_BWD(G_, O_, B_, NT_, NP_, float);               \
+        if (parts == 2) MV_BWD(2, G_, O_, B_, NT_, NP_, float); \
+        else if (y16) MV_BWD(1, G_, O_, B_, NT_, NP_, _Float16);\
+        else MV_BWD(1, G_, O_, B_, NT_, NP_, float);            \
     } while (0)
 #define MV_BWD_SZ(G_, O_, B_)                                   \
     do {                                                        \
@@ -1481,19 +1565,21 @@ int mdnvae_cb_norm_bwd(const float* g, int gmode, int pitch_g, long Qg, const fl
     return 0;
 }
 
-size_t mdnvae_cb_wgrad_workspace_floats(int B, int Cout, int Cin, int planes) {
+size_t mdnvae_cb_wgrad_workspace_floats(int B, int Cout, int Cin, int planes, int parts) {
     int tco, tci;
-    cb_wgrad_tiles(planes, Cout, Cin, tco, tci);
+    cb_wgrad_tiles(planes, parts, tco, tci);
     const int ntiles = ((Cout + tco - 1) / tco) * ((Cin + tci - 1) / tci);
     return (size_t)cb_wgrad_groups(B, ntiles) * 9 * Cout * Cin;
 }
 
 int mdnvae_cb_wgrad(const void* g, const void* act, float* workspace, float* grad_w, int B, int Cout, int Cin, int planes,
-                    int PPg, int PPa, int kbeg, int kend, int pitch, int parts, float out_scale, void* stream) {
+                    int PPg, int PPa, int kbeg, int kend, int pitch, int parts, float out_scale, long g_part_stride,
+                    long act_part_stride, const unsigned* absmax_g, void* stream) {
     MV_REQUIRE(B >= 1, E_ARG, "mdnvae_cb_wgrad: empty batch");
     MV_REQUIRE(g && act && workspace && grad_w, E_ARG, "mdnvae_cb_wgrad: null pointer");
     MV_REQUIRE(planes == 1 || planes == 4, E_ARG, "mdnvae_cb_wgrad: planes = %d (1 or 4)", planes);
-    MV_REQUIRE(parts == 1, E_SHAPE, "mdnvae_cb_wgrad: two-part operands are not built yet");
+    MV_REQUIRE(parts == 1 || parts == 2, E_ARG, "mdnvae_cb_wgrad: parts = %d (1 or 2)", parts);
+    MV_REQUIRE(parts == 1 || absmax_g, E_ARG, "mdnvae_cb_wgrad: two fp16 parts need the record the gradient was scaled by");
     MV_REQUIRE(Cout % 8 == 0 && Cin % 8 == 0, E_SHAPE, "mdnvae_cb_wgrad: channel counts must be multiples of 8");
     MV_REQUIRE(kbeg >= 0 && kbeg % 32 == 0 && kend % 32 == 0 && kend > kbeg && kend <= PPg, E_SHAPE,
                "mdnvae_cb_wgrad: position range [%d, %d) must be whole 32-position steps inside the %d-position plane", kbeg, kend, PPg);
@@ -1503,6 +1589,7 @@ int mdnvae_cb_wgrad(const void* g, const void* act, float* workspace, float* gra
     a.partial = workspace;
     a.B = B; a.Cout = Cout; a.Cin = Cin; a.PPg = PPg; a.PPa = PPa; a.kbeg = kbeg; a.kend = kend;
     a.out_scale = out_scale;
+    a.g_part_stride = g_part_stride; a.a_part_stride = act_part_stride; a.amax_g = parts == 2 ? absmax_g : nullptr;
     int smax;
     if (planes == 1) {
         a.smin = -2 * pitch - 2; smax = 0;
@@ -1520,14 +1607,17 @@ int mdnvae_cb_wgrad(const void* g, const void* act, float* workspace, float* gra
     }
     MV_REQUIRE(smax - a.smin <= 64, E_SHAPE, "mdnvae_cb_wgrad: pitch %d: the taps span %d positions (64 fit)", pitch, smax - a.smin);
     int tco, tci;
-    cb_wgrad_tiles(planes, Cout, Cin, tco, tci);
+    cb_wgrad_tiles(planes, parts, tco, tci);
     const int ntiles = ((Cout + tco - 1) / tco) * ((Cin + tci - 1) / tci);
     const int Gz0 = cb_wgrad_groups(B, ntiles);
     a.spg = (B + Gz0 - 1) / Gz0;
     const int Gz = (B + a.spg - 1) / a.spg;
     hipStream_t st = (hipStream_t)stream;
     int rc;
-    if (planes == 1) rc = cb_launch_wgrad<1, 1, 3, 2, 4, 128>(a, ntiles, Gz, st);
+    if (parts == 2) {
+        if (planes == 1) rc = cb_launch_wgrad<2, 1, 3, 2, 4, 64>(a, ntiles, Gz, st);
+        else rc = cb_launch_wgrad<2, 4, 1, 8, 1, 64>(a, ntiles, Gz, st);
+    } else if (planes == 1) rc = cb_launch_wgrad<1, 1, 3, 2, 4, 128>(a, ntiles, Gz, st);
     else rc = cb_launch_wgrad<1, 4, 3, 4, 2, 64>(a, ntiles, Gz, st);
     if (rc) return rc;
     const long total = 9L * Cout * Cin;

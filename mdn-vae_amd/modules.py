@@ -117,8 +117,8 @@ def _dev_int(a, device):
 # ---------------------------------------------------------------------------------------
 # conv-encoder VAE family
 # ---------------------------------------------------------------------------------------
-CONV_PRECISIONS = {"fp32_mfma": 0, "bf16": 1, "bf16_planar": 1, "bf16x2": 2, "fp32": 3}
-CONV_BLOCKED = {"bf16"}          # precisions whose activations live in the channel-blocked 16-bit layout
+CONV_PRECISIONS = {"fp32_mfma": 0, "bf16": 1, "bf16_planar": 1, "bf16x2": 2, "fp32": 2, "fp32_planar": 3}
+CONV_BLOCKED = {"bf16", "fp32"}  # precisions whose activations live in the channel-blocked 16-bit layout
 
 
 class ConvVAE(nn.Module):
@@ -126,10 +126,12 @@ class ConvVAE(nn.Module):
     function_FC/MM_Gate_test.py) + five-branch rank-1 decoder.
 
     precision: how the encoder's 3x3 convolutions multiply (CONV_PRECISIONS): 'fp32_mfma' the fp32 matrix
-              instruction; 'fp32' fp32 accuracy from three bf16 parts per operand on the bf16 matrix cores;
-              'bf16x2' two parts (2^-16 per product); 'bf16' operands rounded to bf16, kept between the convolutions
-              in the channel-blocked layout the matrix cores read directly ('bf16_planar': the same rounding with fp32
-              planes between the layers).  fp32 accumulation always.
+              instruction; 'fp32' (default) fp32 accuracy from two fp16 parts per operand (three fp16 matrix-core
+              products, 3 * 2^-22 per product), activations kept between the convolutions in the channel-blocked
+              layout the matrix cores read directly; 'fp32_planar' fp32 accuracy from three bf16 parts with fp32 planes
+              between the layers (weight gradients from two parts: 6e-6 of their norm); 'bf16x2' two bf16 parts
+              (2^-16 per product); 'bf16' operands rounded to bf16, channel-blocked ('bf16_planar': the same rounding
+              with fp32 planes between the layers).  fp32 accumulation always.
     decoder:  'nn'   plain second layers                          (VAE_CNN_NN scripts)
               'gcn'  GraphCNN second layers + diagonal intercept  (VAE-CNN-GCN scripts)
     intercept: 'dense' | 'diag' | 'none';  final: 'exp' | 'none';  dropout: p or 0

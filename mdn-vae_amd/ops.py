@@ -1367,6 +1367,18 @@ def _wgrad_parts(parts):
     return 2 if parts == 3 else parts
 
 
+# A list here receives, from every conv-encoder forward, which entries each ReLU passed (one bool [B,C,H,W] per ReLU
+# in network order): what a comparison against a higher-precision run needs to tell arithmetic apart from the side of
+# zero a rounding-level normalised value fell on.
+RELU_GATE_SINK = None
+
+
+def _relu_gate(y, stats, H, W, pitch):
+    B, C = y.shape[0], y.shape[1]
+    v = y.reshape(B, C, -1)[:, :, :H * pitch].reshape(B, C, H, pitch)[..., :W].float()
+    return v > stats.view(B, C, 2)[:, :, 0, None, None]
+
+
 class _ConvEncoder(torch.autograd.Function):
     """x [B, n*n] -> pooled features [B, 192*(h/8)^2]; every arithmetic step is a HIP kernel."""
 
@@ -1393,10 +1405,15 @@ class _ConvEncoder(torch.autograd.Function):
         xk, st3 = _inorm_fwd(raw3, None, 1)
         saved = [x, raw1, st1, raw2, st2, raw3, st3, xk]
         nres = (len(layers) - 3) // 2
+        sink = RELU_GATE_SINK
+        if sink is not None:
+            sink += [_relu_gate(r, s_, ly.oh, ly.oh, ly.oh) for r, s_, ly in ((raw1, st1, layers[0]), (raw2, st2, layers[1]), (raw3, st3, layers[2]))]
         for k in range(nres):
             la, lb = layers[3 + 2 * k], layers[4 + 2 * k]
             ra = la.fwd(xk, None, 0, packed[3 + 2 * k][0], bs[3 + 2 * k], B, mp[3 + 2 * k])
             sa = _plane_stats(ra)
+            if sink is not None:
+                sink.append(_relu_gate(ra, sa, la.oh, la.oh, la.oh))
             rb = lb.fwd(ra, sa, 1, packed[4 + 2 * k][0], bs[4 + 2 * k], B, mp[4 + 2 * k])
             xk, sb = _inorm_fwd(rb, xk, 0)
             saved += [ra, sa, rb, sb, xk]
@@ -1496,22 +1513,29 @@ def _cb_alloc(groups, B, PP, dev, parts=1):
     return torch.empty(parts * groups * B * PP * 16 + 4096, dtype=torch.uint8, device=dev), groups * B * PP * 16
 
 
-def _cb_pack(w, kind, dev):
+def _cb_pack(w, kind, dev, parts=1, amax=None):
     cout, cin = w.shape[0], w.shape[1]
-    n = _lib.load().mdnvae_cb_packed_bytes(cout, cin, kind, 1)
+    n = _lib.load().mdnvae_cb_packed_bytes(cout, cin, kind, parts)
     if n == 0:
-        raise RuntimeError(f"channel-blocked convolution: unsupported layer {cin} -> {cout} (kind {kind})")
+        raise RuntimeError(f"channel-blocked convolution: unsupported layer {cin} -> {cout} (kind {kind}, parts {parts})")
     out = torch.empty(n, dtype=torch.uint8, device=dev)
-    call("mdnvae_cb_pack_weights", ptr(_c(w), "conv weight"), cout, cin, kind, 1, None, out.data_ptr(), stream())
+    call("mdnvae_cb_pack_weights", ptr(_c(w), "conv weight"), cout, cin, kind, parts, None if amax is None else amax.data_ptr(),
+         out.data_ptr(), stream())
     return out
 
 
-def _cb_conv(act, part_stride, wp, bias, B, cout, cin, kind, rows, pitch, PP, out16=False):
-    """out16: the planes leave as fp16 (forward kinds; what reads them normalises and rounds to bf16 anyway)."""
+def _slot(t):
+    return None if t is None else t.data_ptr()
+
+
+def _cb_conv(act, part_stride, wp, bias, B, cout, cin, kind, rows, pitch, PP, out16=False, parts=1, out_scale=1.0,
+             amax_a=None, amax_w=None):
+    """out16: the planes leave as fp16 (forward kinds of the bf16 mode; what reads them normalises and rounds to bf16
+    anyway).  parts = 2: two fp16 parts per operand; out_scale and the records amax_a / amax_w undo their scales."""
     nout = {0: cout, 1: cout, 2: cin, 3: 4 * cin}[kind]
     out = torch.empty(B, nout, _ru(rows * pitch, 8), dtype=torch.float16 if out16 else torch.float32, device=act.device)
     call("mdnvae_cb_conv", act.data_ptr(), part_stride, wp.data_ptr(), ptr(bias, "conv bias"), out.data_ptr(), int(out16), B, cout,
-         cin, kind, rows, pitch, PP, 1, 1.0, stream())
+         cin, kind, rows, pitch, PP, parts, float(out_scale), _slot(amax_a), _slot(amax_w), stream())
     return out
 
 
@@ -1522,27 +1546,29 @@ def _cb_stats(y, H, W, pitch):
     return st
 
 
-def _cb_norm_fwd(y, stats, H, W, pitch_y, relu, mode, PP, skip=None, want_stream=False, want_act=True):
-    """(channel-blocked activation, fp32 residual stream [B,C,H,W] if asked, statistics) of a raw conv output;
-    stats = None: the pass computes them itself."""
+def _cb_norm_fwd(y, stats, H, W, pitch_y, relu, mode, PP, skip=None, want_stream=False, want_act=True, parts=1, scale=1.0):
+    """(channel-blocked activation, its part stride, fp32 residual stream [B,C,H,W] if asked, statistics) of a raw conv
+    output; stats = None: the pass computes them itself."""
     B, C = y.shape[0], y.shape[1]
     Qy = y.numel() // (B * C)
     dev = y.device
     act, ps = (None, 0)
     if want_act:
-        act, ps = _cb_alloc((C // 8) * (4 if mode == 1 else 1), B, PP, dev)
+        act, ps = _cb_alloc((C // 8) * (4 if mode == 1 else 1), B, PP, dev, parts)
     so = torch.empty(B, C, H, W, dtype=torch.float32, device=dev) if want_stream else None
     compute = stats is None
     if compute:
         stats = torch.empty(B * C, 2, dtype=torch.float32, device=dev)
     y16 = y.dtype == torch.float16
     call("mdnvae_cb_norm_fwd", ptr(y, "raw conv output", y.dtype), int(y16), ptr(stats), int(compute), ptr(skip), ptr(so),
-         None if act is None else act.data_ptr(), ps, B, C, H, W, pitch_y, Qy, int(relu), mode, PP, 1, 1.0, stream())
-    return act, so, stats
+         None if act is None else act.data_ptr(), ps, B, C, H, W, pitch_y, Qy, int(relu), mode, PP, parts, float(scale), stream())
+    return act, ps, so, stats
 
 
-def _cb_norm_bwd(g, gmode, pitch_g, y, stats, pitch_y, relu, C, H, W, omode, PP, base=None, want_sum=False):
-    """(dc, plane sums [B,C], base + gradient or None)."""
+def _cb_norm_bwd(g, gmode, pitch_g, y, stats, pitch_y, relu, C, H, W, omode, PP, base=None, want_sum=False, parts=1,
+                 amax_dc=None):
+    """(dc, its part stride, plane sums [B,C], base + gradient or None).  parts = 2: amax_dc is a cleared record; a
+    probe run of the pass fills it with the largest |dc| first, and the pass proper scales its two fp16 parts by it."""
     B = y.shape[0]
     dev = y.device
     Qy = y.numel() // (B * C)
@@ -1551,56 +1577,91 @@ def _cb_norm_bwd(g, gmode, pitch_g, y, stats, pitch_y, relu, C, H, W, omode, PP,
         dc = torch.empty(B, C, H, W, dtype=torch.float32, device=dev)
         ps = 0
     else:
-        dc, ps = _cb_alloc(C // 8, B, PP, dev)
+        dc, ps = _cb_alloc(C // 8, B, PP, dev, parts)
     gsum = torch.empty(B, C, dtype=torch.float32, device=dev)
     so = torch.empty(B, C, H, W, dtype=torch.float32, device=dev) if want_sum else None
     y16 = y.dtype == torch.float16
-    call("mdnvae_cb_norm_bwd", ptr(g), gmode, pitch_g, Qg, ptr(base), ptr(so), ptr(y, "raw conv output", y.dtype), int(y16),
-         ptr(stats), pitch_y, Qy, int(relu), B, C, H, W, omode, dc.data_ptr(), ps, PP, 1, 1.0, ptr(gsum), stream())
-    return dc, gsum, so
+    p_ = 1 if omode == 2 else parts
+    args = (ptr(g), gmode, pitch_g, Qg, ptr(base), ptr(so), ptr(y, "raw conv output", y.dtype), int(y16), ptr(stats), pitch_y, Qy,
+            int(relu), B, C, H, W, omode, dc.data_ptr(), ps, PP, p_, 1.0, ptr(gsum))
+    if p_ == 2:
+        call("mdnvae_cb_norm_bwd", *args, None, amax_dc.data_ptr(), stream())
+    call("mdnvae_cb_norm_bwd", *args, _slot(amax_dc) if p_ == 2 else None, None, stream())
+    return dc, ps, gsum, so
 
 
-def _cb_wgrad(g, act, B, cout, cin, planes, PPg, PPa, krange, pitch):
+def _cb_wgrad(g, act, B, cout, cin, planes, PPg, PPa, krange, pitch, parts=1, out_scale=1.0, g_ps=0, a_ps=0, amax_g=None):
     lib = _lib.load()
-    ws = torch.empty(lib.mdnvae_cb_wgrad_workspace_floats(B, cout, cin, planes), dtype=torch.float32, device=g.device)
+    ws = torch.empty(lib.mdnvae_cb_wgrad_workspace_floats(B, cout, cin, planes, parts), dtype=torch.float32, device=g.device)
     gw = torch.empty(cout, cin, 3, 3, dtype=torch.float32, device=g.device)
     call("mdnvae_cb_wgrad", g.data_ptr(), act.data_ptr(), ptr(ws), ptr(gw), B, cout, cin, planes, PPg, PPa, krange[0], krange[1],
-         pitch, 1, 1.0, stream())
+         pitch, parts, float(out_scale), g_ps, a_ps, _slot(amax_g), stream())
     return gw
 
 
+def _pow2_below(v):
+    """The largest power of two that keeps v * scale under 2^15 (half of fp16's range)."""
+    import math
+    return 2.0 ** math.floor(math.log2(32768.0 / max(float(v), 1e-30)))
+
+
 class _ConvEncoderCB(torch.autograd.Function):
-    """The encoder of _ConvEncoder with bf16 operands in the channel-blocked layout: x [B, n*n] -> pooled
-    features.  The 7x7 single-channel stem and the max pool are the fp32 kernels of _ConvEncoder."""
+    """The encoder of _ConvEncoder with 16-bit operands in the channel-blocked layout: x [B, n*n] -> pooled features.
+    parts = 1: bf16 operands (the reduced-precision mode).  parts = 2: every operand as two fp16 parts, three
+    matrix-core products per multiply-add (fp32-accurate): activations carry a fixed power-of-two scale (a normalised
+    plane is bounded by sqrt(H W), the residual stream by that times the number of blocks + 1), weights the scale of
+    their largest magnitude, gradient operands the scale of theirs, which a probe run of the instance-norm backward
+    pass records on the device before the pass proper writes them.  The 7x7 single-channel stem and the max pool are
+    the fp32 kernels of _ConvEncoder."""
 
     @staticmethod
-    def forward(ctx, x, n_nodes, *wb):
+    def forward(ctx, x, n_nodes, parts, *wb):
         x = _c(x)
         B, dev = x.shape[0], x.device
         ptr(x, "x")
         G = _CBGeom(n_nodes)
         nres = (len(wb) // 2 - 3) // 2
-        need_bwd = any(ctx.needs_input_grad[2:])
+        need_bwd = any(ctx.needs_input_grad[3:])
         ws, bs = list(wb[0::2]), list(wb[1::2])
+        two = parts == 2
         stem = _ConvLayer(1, 48, 7, 1, 3, True, n_nodes)
         wstem, _ = stem.pack(ws[0], dev, False)
         kinds = [1, 1] + [0] * (2 * nres)
-        wf = [_cb_pack(w, k, dev) for w, k in zip(ws[1:], kinds)]
+        # records of the largest weight magnitudes (two parts)
+        nlayers = 2 + 2 * nres
+        rec = torch.zeros(nlayers, ABSMAX_SLOTS, dtype=torch.int32, device=dev) if two else None
+        wmax = [None] * nlayers
+        if two:
+            for i in range(nlayers):
+                wmax[i] = rec[i]
+                _absmax(_c(ws[1 + i]).reshape(ws[1 + i].shape[0], -1), wmax[i], reset=False)
+        wf = [_cb_pack(w, k, dev, parts, wm) for w, k, wm in zip(ws[1:], kinds, wmax)]
+        # fixed scales of the activation tensors
+        s1 = _pow2_below(n_nodes) if two else 1.0
+        s2 = _pow2_below(G.h2) if two else 1.0
+        sr = _pow2_below((nres + 1) * G.h3) if two else 1.0
+        o16 = not two
         raw1 = stem.fwd(x, None, 0, wstem, bs[0], B)                                   # [B,48,n,n]
         st1 = _plane_stats(raw1)
-        a1, _, _ = _cb_norm_fwd(raw1, st1, n_nodes, n_nodes, n_nodes, True, 1, G.pp_a1)
-        y2 = _cb_conv(a1, 0, wf[0], bs[1], B, 96, 48, 1, G.h2, G.p2, G.pp_a1, out16=True)
-        a2, _, st2 = _cb_norm_fwd(y2, None, G.h2, G.h2, G.p2, True, 1, G.pp_a2)
-        y3 = _cb_conv(a2, 0, wf[1], bs[2], B, 192, 96, 1, G.h3, G.p3, G.pp_a2, out16=True)
+        a1, p1, _, _ = _cb_norm_fwd(raw1, st1, n_nodes, n_nodes, n_nodes, True, 1, G.pp_a1, parts=parts, scale=s1)
+        y2 = _cb_conv(a1, p1, wf[0], bs[1], B, 96, 48, 1, G.h2, G.p2, G.pp_a1, out16=o16, parts=parts, out_scale=1.0 / s1, amax_w=wmax[0])
+        a2, p2, _, st2 = _cb_norm_fwd(y2, None, G.h2, G.h2, G.p2, True, 1, G.pp_a2, parts=parts, scale=s2)
+        y3 = _cb_conv(a2, p2, wf[1], bs[2], B, 192, 96, 1, G.h3, G.p3, G.pp_a2, out16=o16, parts=parts, out_scale=1.0 / s2, amax_w=wmax[1])
         H = G.h3
-        xp, xs, st3 = _cb_norm_fwd(y3, None, H, H, G.p3, True, 0, G.pp_r, want_stream=True)
+        xp, pr, xs, st3 = _cb_norm_fwd(y3, None, H, H, G.p3, True, 0, G.pp_r, want_stream=True, parts=parts, scale=sr)
         saved = [x, raw1, st1, a1, y2, st2, a2, y3, st3]
+        sink = RELU_GATE_SINK
+        if sink is not None:
+            sink += [_relu_gate(raw1, st1, n_nodes, n_nodes, n_nodes), _relu_gate(y2, st2, G.h2, G.h2, G.p2), _relu_gate(y3, st3, H, H, G.p3)]
         for k in range(nres):
-            ia, ib = 2 + 2 * k, 3 + 2 * k           # index into wf / (ws[1:], bs[1:])
-            ya = _cb_conv(xp, 0, wf[ia], bs[ia + 1], B, 192, 192, 0, H, G.pr, G.pp_r, out16=True)
-            aa, _, sa = _cb_norm_fwd(ya, None, H, H, G.pr, True, 0, G.pp_r)
-            yb = _cb_conv(aa, 0, wf[ib], bs[ib + 1], B, 192, 192, 0, H, G.pr, G.pp_r, out16=True)
-            xp_next, xs, sb = _cb_norm_fwd(yb, None, H, H, G.pr, False, 0, G.pp_r, skip=xs, want_stream=True, want_act=k + 1 < nres)
+            ia, ib = 2 + 2 * k, 3 + 2 * k
+            ya = _cb_conv(xp, pr, wf[ia], bs[ia + 1], B, 192, 192, 0, H, G.pr, G.pp_r, out16=o16, parts=parts, out_scale=1.0 / sr, amax_w=wmax[ia])
+            aa, _, _, sa = _cb_norm_fwd(ya, None, H, H, G.pr, True, 0, G.pp_r, parts=parts, scale=sr)
+            if sink is not None:
+                sink.append(_relu_gate(ya, sa, H, H, G.pr))
+            yb = _cb_conv(aa, pr, wf[ib], bs[ib + 1], B, 192, 192, 0, H, G.pr, G.pp_r, out16=o16, parts=parts, out_scale=1.0 / sr, amax_w=wmax[ib])
+            xp_next, _, xs, sb = _cb_norm_fwd(yb, None, H, H, G.pr, False, 0, G.pp_r, skip=xs, want_stream=True, want_act=k + 1 < nres,
+                                              parts=parts, scale=sr)
             saved += [xp, ya, sa, aa, yb, sb]
             xp = xp_next
         K = 8
@@ -1610,13 +1671,16 @@ class _ConvEncoderCB(torch.autograd.Function):
         call("mdnvae_maxpool_fwd", ptr(xs), B * 192, H, H, K, ptr(feat), ptr(argmax, "argmax", torch.int32), stream())
         if need_bwd:
             ctx.save_for_backward(*saved, argmax, *ws[1:])
-            ctx.n_nodes, ctx.nres = n_nodes, nres
+            ctx.geom = (n_nodes, nres, parts, (s1, s2, sr), (p1, p2, pr))
+            ctx.wmax = wmax
         return feat
 
     @staticmethod
     def backward(ctx, gfeat):
+        n, nres, parts, (s1, s2, sr), (p1, p2, pr) = ctx.geom
+        wmax = ctx.wmax                             # wmax[layer - 1] (layer 0 = stem)
+        two = parts == 2
         sv = ctx.saved_tensors
-        nres, n = ctx.nres, ctx.n_nodes
         G = _CBGeom(n)
         x, raw1, st1, a1, y2, st2, a2, y3, st3 = sv[:9]
         blocks = [sv[9 + 6 * k: 15 + 6 * k] for k in range(nres)]
@@ -1624,48 +1688,66 @@ class _ConvEncoderCB(torch.autograd.Function):
         ws = sv[10 + 6 * nres:]                     # weights of layers 1.. (the two stride-2 layers, then the blocks)
         B, dev = x.shape[0], x.device
         H = G.h3
-        kinds = [3, 3] + [2] * (2 * nres)
-        wt = [_cb_pack(w, k, dev) for w, k in zip(ws, kinds)]
+        wt = [_cb_pack(w, 3 if i < 2 else 2, dev, parts, wmax[i]) for i, w in enumerate(ws)]
         gfeat = _c(gfeat)
         Gs = torch.empty(B, 192, H, H, dtype=torch.float32, device=dev)
         call("mdnvae_maxpool_bwd", ptr(gfeat), ptr(argmax, "argmax", torch.int32), B * 192, H, H, 8, ptr(Gs), stream())
         nl = 3 + 2 * nres
         gw, gb = [None] * nl, [None] * nl
-        dcb = None
+        # records of this pass (two parts): the largest magnitude of every gradient operand, left by a probe run of
+        # the pass that writes it
+        rec = torch.zeros(nl + 1, ABSMAX_SLOTS, dtype=torch.int32, device=dev) if two else None
+        nrec = [0]
+
+        def slot():
+            if not two:
+                return None
+            nrec[0] += 1
+            return rec[nrec[0] - 1]
+
+        dcb = dmax = pd = None
         for k in range(nres - 1, -1, -1):
             xp, ya, sa, aa, yb, sb = blocks[k]
-            ia, ib = 3 + 2 * k, 4 + 2 * k           # layer numbers (0 = stem)
+            La, Lb = 3 + 2 * k, 4 + 2 * k           # layer numbers (0 = stem)
             if dcb is None:
-                dcb, gs, _ = _cb_norm_bwd(Gs, 0, H, yb, sb, G.pr, False, 192, H, H, 0, G.pp_dr)
-                gb[ib] = _colsum(gs)
-            gw[ib] = _cb_wgrad(dcb, aa, B, 192, 192, 1, G.pp_dr, G.pp_r, G.k_r, G.pr)
-            dap = _cb_conv(dcb, 0, wt[ib - 1], None, B, 192, 192, 2, H + 2, G.pr, G.pp_dr)
-            dca, gs, _ = _cb_norm_bwd(dap, 1, G.pr, ya, sa, G.pr, True, 192, H, H, 0, G.pp_dr)
-            gb[ia] = _colsum(gs)
-            gw[ia] = _cb_wgrad(dca, xp, B, 192, 192, 1, G.pp_dr, G.pp_r, G.k_r, G.pr)
-            dxp = _cb_conv(dca, 0, wt[ia - 1], None, B, 192, 192, 2, H + 2, G.pr, G.pp_dr)
+                dmax = slot()
+                dcb, pd, gs, _ = _cb_norm_bwd(Gs, 0, H, yb, sb, G.pr, False, 192, H, H, 0, G.pp_dr, parts=parts, amax_dc=dmax)
+                gb[Lb] = _colsum(gs)
+            gw[Lb] = _cb_wgrad(dcb, aa, B, 192, 192, 1, G.pp_dr, G.pp_r, G.k_r, G.pr, parts, 1.0 / sr, pd, pr, dmax)
+            dap = _cb_conv(dcb, pd, wt[Lb - 1], None, B, 192, 192, 2, H + 2, G.pr, G.pp_dr, parts=parts, amax_a=dmax,
+                           amax_w=wmax[Lb - 1])
+            dmax = slot()
+            dca, pd, gs, _ = _cb_norm_bwd(dap, 1, G.pr, ya, sa, G.pr, True, 192, H, H, 0, G.pp_dr, parts=parts, amax_dc=dmax)
+            gb[La] = _colsum(gs)
+            gw[La] = _cb_wgrad(dca, xp, B, 192, 192, 1, G.pp_dr, G.pp_r, G.k_r, G.pr, parts, 1.0 / sr, pd, pr, dmax)
+            dxp = _cb_conv(dca, pd, wt[La - 1], None, B, 192, 192, 2, H + 2, G.pr, G.pp_dr, parts=parts, amax_a=dmax,
+                           amax_w=wmax[La - 1])
+            dmax = slot()
             if k > 0:
                 # the stream's gradient in front of this block, and straight on into the block before it
                 ybp, sbp = blocks[k - 1][4], blocks[k - 1][5]
-                dcb, gs, Gs = _cb_norm_bwd(dxp, 1, G.pr, ybp, sbp, G.pr, False, 192, H, H, 0, G.pp_dr, base=Gs, want_sum=True)
-                gb[ib - 2] = _colsum(gs)
+                dcb, pd, gs, Gs = _cb_norm_bwd(dxp, 1, G.pr, ybp, sbp, G.pr, False, 192, H, H, 0, G.pp_dr, base=Gs, want_sum=True,
+                                               parts=parts, amax_dc=dmax)
+                gb[Lb - 2] = _colsum(gs)
             else:
-                dc3, gs, _ = _cb_norm_bwd(dxp, 1, G.pr, y3, st3, G.p3, True, 192, H, H, 1, G.pp_d3, base=Gs)
+                dc3, pd, gs, _ = _cb_norm_bwd(dxp, 1, G.pr, y3, st3, G.p3, True, 192, H, H, 1, G.pp_d3, base=Gs, parts=parts,
+                                              amax_dc=dmax)
                 gb[2] = _colsum(gs)
-        gw[2] = _cb_wgrad(dc3, a2, B, 192, 96, 4, G.pp_d3, G.pp_a2, G.k_3, G.p3)
-        da2 = _cb_conv(dc3, 0, wt[1], None, B, 192, 96, 3, G.h3, G.p3, G.pp_d3)
-        dc2, gs, _ = _cb_norm_bwd(da2, 2, G.p3, y2, st2, G.p2, True, 96, G.h2, G.h2, 1, G.pp_d2)
+        gw[2] = _cb_wgrad(dc3, a2, B, 192, 96, 4, G.pp_d3, G.pp_a2, G.k_3, G.p3, parts, 1.0 / s2, pd, p2, dmax)
+        da2 = _cb_conv(dc3, pd, wt[1], None, B, 192, 96, 3, G.h3, G.p3, G.pp_d3, parts=parts, amax_a=dmax, amax_w=wmax[1])
+        dmax = slot()
+        dc2, pd, gs, _ = _cb_norm_bwd(da2, 2, G.p3, y2, st2, G.p2, True, 96, G.h2, G.h2, 1, G.pp_d2, parts=parts, amax_dc=dmax)
         gb[1] = _colsum(gs)
-        gw[1] = _cb_wgrad(dc2, a1, B, 96, 48, 4, G.pp_d2, G.pp_a1, G.k_2, G.p2)
-        da1 = _cb_conv(dc2, 0, wt[0], None, B, 96, 48, 3, G.h2, G.p2, G.pp_d2)
-        g_r1, gs, _ = _cb_norm_bwd(da1, 2, G.p2, raw1, st1, n, True, 48, n, n, 2, 0)
+        gw[1] = _cb_wgrad(dc2, a1, B, 96, 48, 4, G.pp_d2, G.pp_a1, G.k_2, G.p2, parts, 1.0 / s1, pd, p1, dmax)
+        da1 = _cb_conv(dc2, pd, wt[0], None, B, 96, 48, 3, G.h2, G.p2, G.pp_d2, parts=parts, amax_a=dmax, amax_w=wmax[0])
+        g_r1, _, gs, _ = _cb_norm_bwd(da1, 2, G.p2, raw1, st1, n, True, 48, n, n, 2, 0)
         gb[0] = _colsum(gs)
         stem = _ConvLayer(1, 48, 7, 1, 3, True, n)
         gw[0] = stem.wgrad(x.view(B, 1, n, n), None, 0, g_r1, B)
         grads = []
         for w_, b_ in zip(gw, gb):
             grads += [w_, b_]
-        return (None, None, *grads)
+        return (None, None, None, *grads)
 
 
 def conv_encoder(x, n_nodes, weights_and_biases, parts=0, blocked=False):
@@ -1673,14 +1755,15 @@ def conv_encoder(x, n_nodes, weights_and_biases, parts=0, blocked=False):
     block convs, in network order.  parts: 0 = the fp32 matrix instruction; 1..3 = the 3x3 convolutions on
     the bf16 matrix cores with operands split into that many bf16 parts (1: operands rounded to bf16,
     3: fp32 accuracy); the stem, the norms and the pool are fp32 in every mode.  blocked: activations between
-    the 3x3 convolutions in the channel-blocked 16-bit layout (_ConvEncoderCB) instead of fp32 planes."""
+    the 3x3 convolutions in the channel-blocked 16-bit layout (_ConvEncoderCB) instead of fp32 planes; parts is then
+    1 (bf16) or 2 (two fp16 parts per operand, fp32-accurate)."""
     flat = []
     for w, b in weights_and_biases:
         flat += [w, b]
     if blocked:
-        if int(parts) != 1:
-            raise ValueError("the channel-blocked encoder is built for bf16 operands (parts = 1)")
-        return _ConvEncoderCB.apply(x, n_nodes, *flat)
+        if int(parts) not in (1, 2):
+            raise ValueError("the channel-blocked encoder takes bf16 operands (parts = 1) or two fp16 parts (parts = 2)")
+        return _ConvEncoderCB.apply(x, n_nodes, int(parts), *flat)
     return _ConvEncoder.apply(x, n_nodes, int(parts), *flat)
 
 

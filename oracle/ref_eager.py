@@ -89,24 +89,34 @@ def _in(x):
     return F.instance_norm(x, eps=1e-5)
 
 
-def conv_features(p: dict, x: torch.Tensor, n_nodes: int = 68, n_res: int = 5) -> torch.Tensor:
+def conv_features(p: dict, x: torch.Tensor, n_nodes: int = 68, n_res: int = 5, gates=None, normed=None) -> torch.Tensor:
     """x [B, n*n] -> pooled feature [B, 768].  Stem, two stride-2 convs, n_res residual
-    blocks, 8x8 max pool; parameter indices follow the reference nn.Sequential."""
+    blocks, 8x8 max pool; parameter indices follow the reference nn.Sequential.
+    gates: 3 + n_res boolean masks, one per ReLU in network order: those ReLUs pass exactly the masked entries (the ones
+    another run passed), so that a comparison with that run measures arithmetic and not which side of zero a
+    rounding-level normalised value fell.  normed: a list that receives every ReLU's input (detached)."""
+    it = iter(gates) if gates is not None else None
+
+    def relu(t):
+        if normed is not None:
+            normed.append(t.detach())
+        return F.relu(t) if it is None else t * next(it).to(t.dtype)
+
     h = x.view(-1, 1, n_nodes, n_nodes)
-    h = F.relu(_in(F.conv2d(F.pad(h, (3, 3, 3, 3), mode="reflect"), p["ec.1.weight"], p["ec.1.bias"])))
-    h = F.relu(_in(F.conv2d(h, p["ec.4.weight"], p["ec.4.bias"], stride=2, padding=1)))
-    h = F.relu(_in(F.conv2d(h, p["ec.7.weight"], p["ec.7.bias"], stride=2, padding=1)))
+    h = relu(_in(F.conv2d(F.pad(h, (3, 3, 3, 3), mode="reflect"), p["ec.1.weight"], p["ec.1.bias"])))
+    h = relu(_in(F.conv2d(h, p["ec.4.weight"], p["ec.4.bias"], stride=2, padding=1)))
+    h = relu(_in(F.conv2d(h, p["ec.7.weight"], p["ec.7.bias"], stride=2, padding=1)))
     for i in range(10, 10 + n_res):
         a = F.conv2d(F.pad(h, (1, 1, 1, 1), mode="reflect"), p[f"ec.{i}.block.1.weight"], p[f"ec.{i}.block.1.bias"])
-        a = F.relu(_in(a))
+        a = relu(_in(a))
         b = F.conv2d(F.pad(a, (1, 1, 1, 1), mode="reflect"), p[f"ec.{i}.block.5.weight"], p[f"ec.{i}.block.5.bias"])
         h = h + _in(b)
     h = F.max_pool2d(h, kernel_size=8, stride=8)
     return h.reshape(h.shape[0], -1)
 
 
-def conv_encode(p, x, n_nodes=68):
-    f = conv_features(p, x, n_nodes)
+def conv_encode(p, x, n_nodes=68, gates=None, normed=None):
+    f = conv_features(p, x, n_nodes, gates=gates, normed=normed)
     return F.linear(f, p["fc_mean.weight"], p["fc_mean.bias"]), F.linear(f, p["fc_log_var.weight"], p["fc_log_var.bias"])
 
 
@@ -286,13 +296,13 @@ VARIANTS = {
 }
 
 
-def vae_forward(variant, p, x, eps, mask=None, adjacency=None, n_nodes=68):
+def vae_forward(variant, p, x, eps, mask=None, adjacency=None, n_nodes=68, conv_gates=None, conv_normed=None):
     if variant == "mm_gate":                                                          # function/MM_Gate.py:172-177
         mu, logvar = fnn_encode(p, x)
         z = reparameterize(mu, logvar, eps)
         return gcn_decode(p, z, adjacency), mu, logvar, z, None
     enc, dkw, _ = VARIANTS[variant]
-    mu, logvar = fnn_encode(p, x) if enc == "fnn" else conv_encode(p, x, n_nodes)
+    mu, logvar = fnn_encode(p, x) if enc == "fnn" else conv_encode(p, x, n_nodes, conv_gates, conv_normed)
     z = reparameterize(mu, logvar, eps)
     recon, x_latent = rank1_decode(p, z, mask=mask, n_nodes=n_nodes, **dkw)
     return recon, mu, logvar, z, x_latent

@@ -168,6 +168,110 @@ def test_stride2_forward_dgrad_wgrad(cin, cout, h, n, B):
     assert _rel(gw, wd.grad) <= 1e-5
 
 
+# ---- two fp16 parts per operand (the fp32-accurate mode): three products per multiply-add carry 22 bits of each
+# operand, so the float64 reference runs on the unrounded fp32 operands; 2e-6 of the largest entry covers the
+# parts' 3 * 2^-22 and the fp32 accumulation
+TWO_PART_BAR = 2e-6
+
+
+def _two_parts(blocked, scale):
+    """[groups][B][PP][8] float -> device bytes [2][groups][B][PP][8] fp16 (high part, then what it left) + part stride"""
+    v = blocked.float() * scale
+    hi = v.to(torch.float16)
+    lo = (v - hi.float()).to(torch.float16)
+    t = torch.stack([hi, lo]).contiguous().view(torch.uint8).reshape(-1)
+    return torch.cat([t, torch.zeros(4096, dtype=torch.uint8)]).to(DEV), hi.numel() * 2
+
+
+def _record(t):
+    """(record of the largest magnitude of a tensor, the power-of-two scale the kernels derive from it)"""
+    rec = torch.zeros(ops.ABSMAX_SLOTS, dtype=torch.int32, device=DEV)
+    ops._absmax(t.to(DEV).reshape(t.shape[0], -1).contiguous(), rec, reset=False)
+    top = float(t.abs().max())
+    assert ops.absmax_value(rec) == top
+    return rec, 2.0 ** (14 - int(np.floor(np.log2(top))))
+
+
+@pytest.mark.parametrize("h,B", [(22, 3), (17, 1)])
+def test_stride1_two_fp16_parts(h, B):
+    C = 192
+    g = torch.Generator().manual_seed(h * 10 + B + 1)
+    a = torch.randn(B, C, h, h, generator=g).relu() * 3.0
+    w = torch.randn(C, C, 3, 3, generator=g) / (C * 9) ** 0.5
+    b = torch.randn(C, generator=g)
+    cot = torch.randn(B, C, h, h, generator=g) * 37.0
+    G = ops._CBGeom(87 if h == 22 else 68)
+    ap = F.pad(a.double(), (1, 1, 1, 1), mode="reflect").requires_grad_(True)
+    wd = w.double().requires_grad_(True)
+    want = F.conv2d(ap, wd, b.double())
+    (want * cot.double()).sum().backward()
+    sa = ops._pow2_below(6 * h)
+    act, pa = _two_parts(cb_reflect(a, G.pp_r), sa)
+    wrec, _ = _record(w)
+    wf = ops._cb_pack(w.to(DEV), 0, DEV, 2, wrec)
+    y = ops._cb_conv(act, pa, wf, b.to(DEV), B, C, C, 0, h, G.pr, G.pp_r, parts=2, out_scale=1.0 / sa, amax_w=wrec)
+    got = y[:, :, :h * G.pr].reshape(B, C, h, G.pr)[:, :, :, :h]
+    tag = f"h{h} B{B}"
+    recipe.record("conv blocked, two fp16 parts", "forward vs float64", tag, _rel(got, want), TWO_PART_BAR)
+    assert _rel(got, want) <= TWO_PART_BAR
+
+    grec, sg = _record(cot)
+    dc, pd = _two_parts(cb_zero2(cot, G.pp_dr), sg)
+    wt = ops._cb_pack(w.to(DEV), 2, DEV, 2, wrec)
+    dp = ops._cb_conv(dc, pd, wt, None, B, C, C, 2, h + 2, G.pr, G.pp_dr, parts=2, amax_a=grec, amax_w=wrec)
+    gotp = dp[:, :, :(h + 2) * G.pr].reshape(B, C, h + 2, G.pr)
+    recipe.record("conv blocked, two fp16 parts", "data gradient (padded grid) vs float64", tag, _rel(gotp, ap.grad), TWO_PART_BAR)
+    assert _rel(gotp, ap.grad) <= TWO_PART_BAR
+
+    gw = ops._cb_wgrad(dc, act, B, C, C, 1, G.pp_dr, G.pp_r, G.k_r, G.pr, 2, 1.0 / sa, pd, pa, grec)
+    recipe.record("conv blocked, two fp16 parts", "weight gradient vs float64", tag, _rel(gw, wd.grad), TWO_PART_BAR)
+    assert _rel(gw, wd.grad) <= TWO_PART_BAR
+
+
+@pytest.mark.parametrize("cin,cout,h,n,B", [(48, 96, 87, 87, 1), (48, 96, 68, 68, 3), (96, 192, 44, 87, 3), (96, 192, 34, 68, 1)])
+def test_stride2_two_fp16_parts(cin, cout, h, n, B):
+    g = torch.Generator().manual_seed(h * 10 + B + cin + 1)
+    a = torch.randn(B, cin, h, h, generator=g).relu() * 2.0
+    w = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    b = torch.randn(cout, generator=g)
+    G = ops._CBGeom(n)
+    first = cin == 48
+    oh, pitch = (G.h2, G.p2) if first else (G.h3, G.p3)
+    PPa, PPd = (G.pp_a1, G.pp_d2) if first else (G.pp_a2, G.pp_d3)
+    kr = G.k_2 if first else G.k_3
+    cot = torch.randn(B, cout, oh, oh, generator=g) * 0.011
+    ad = a.double().requires_grad_(True)
+    wd = w.double().requires_grad_(True)
+    want = F.conv2d(ad, wd, b.double(), stride=2, padding=1)
+    (want * cot.double()).sum().backward()
+    sa = ops._pow2_below(h)
+    act, pa = _two_parts(cb_parity(a, PPa), sa)
+    wrec, _ = _record(w)
+    wf = ops._cb_pack(w.to(DEV), 1, DEV, 2, wrec)
+    y = ops._cb_conv(act, pa, wf, b.to(DEV), B, cout, cin, 1, oh, pitch, PPa, parts=2, out_scale=1.0 / sa, amax_w=wrec)
+    got = y[:, :, :oh * pitch].reshape(B, cout, oh, pitch)[:, :, :, :oh]
+    tag = f"{cin}->{cout} h{h} B{B}"
+    recipe.record("conv blocked, two fp16 parts", "stride-2 forward vs float64", tag, _rel(got, want), TWO_PART_BAR)
+    assert _rel(got, want) <= TWO_PART_BAR
+
+    grec, sg = _record(cot)
+    dc, pd = _two_parts(cb_zero_behind(cot, PPd), sg)
+    wt = ops._cb_pack(w.to(DEV), 3, DEV, 2, wrec)
+    dp = ops._cb_conv(dc, pd, wt, None, B, cout, cin, 3, oh, pitch, PPd, parts=2, amax_a=grec, amax_w=wrec)
+    par = dp[:, :, :oh * pitch].reshape(B, 4, cin, oh, pitch).cpu()
+    gin = torch.zeros(B, cin, 2 * oh, 2 * oh)
+    for py in range(2):
+        for px in range(2):
+            gin[:, :, py::2, px::2] = par[:, py * 2 + px, :, :, :oh]
+    gin = gin[:, :, :h, :h]
+    recipe.record("conv blocked, two fp16 parts", "stride-2 data gradient vs float64", tag, _rel(gin, ad.grad), TWO_PART_BAR)
+    assert _rel(gin, ad.grad) <= TWO_PART_BAR
+
+    gw = ops._cb_wgrad(dc, act, B, cout, cin, 4, PPd, PPa, kr, pitch, 2, 1.0 / sa, pd, pa, grec)
+    recipe.record("conv blocked, two fp16 parts", "stride-2 weight gradient vs float64", tag, _rel(gw, wd.grad), TWO_PART_BAR)
+    assert _rel(gw, wd.grad) <= TWO_PART_BAR
+
+
 def _pitched(t, pitch, Q):
     """[B,C,H,W] -> [B,C,Q] with row pitch (scratch columns filled with a large finite value)"""
     B, C, H, W = t.shape
@@ -206,7 +310,7 @@ def test_norm_forward_pass(C, H, relu, mode, y16):
         want = want.relu()
     if mode == 0:
         PP = ops._ru((H + 2) * (H + 2) + 5, 4)
-        act, so, st2 = ops._cb_norm_fwd(y, st, H, H, pitch, relu, 0, PP, skip=skip.to(DEV), want_stream=True)
+        act, _, so, st2 = ops._cb_norm_fwd(y, st, H, H, pitch, relu, 0, PP, skip=skip.to(DEV), want_stream=True)
         assert _rel(st2[:, 0], mean) <= 1e-6 and _rel(st2[:, 1], rstd) <= 1e-6
         want = want + skip.double()
         assert _rel(so, want) <= 2e-6
@@ -216,7 +320,7 @@ def test_norm_forward_pass(C, H, relu, mode, y16):
     else:
         oh = (H + 1) // 2
         PP = ops._ru((oh + 1) * (oh + 1) + 3, 4)
-        act, _, _ = ops._cb_norm_fwd(y, st, H, H, pitch, relu, 1, PP)
+        act, _, _, _ = ops._cb_norm_fwd(y, st, H, H, pitch, relu, 1, PP)
         got = unblock(act, (C // 8) * 4, B, PP)
         ref = cb_parity(want.float(), PP).to(torch.bfloat16).double()
     # bf16 rounding of values that differ in the last fp32 bit may land one bf16 step apart
@@ -280,7 +384,7 @@ def test_norm_backward_pass(C, H, relu, gmode, omode, y16):
         PP = ops._ru((H + 1) * (H + 1) + 3, 4)
     else:
         PP = 0
-    dc, gsum, total = ops._cb_norm_bwd(gt, gmode, pitch_g, y, st, pitch_y, relu, C, H, H, omode, PP,
+    dc, _, gsum, total = ops._cb_norm_bwd(gt, gmode, pitch_g, y, st, pitch_y, relu, C, H, H, omode, PP,
                                        base=None if base is None else base.to(DEV), want_sum=base is not None)
     want = rd.grad
     if omode == 2:
@@ -295,6 +399,75 @@ def test_norm_backward_pass(C, H, relu, gmode, omode, y16):
         folded = torch.zeros(B, C, H, H, dtype=torch.float64, requires_grad=True)
         (F.pad(folded, (1, 1, 1, 1), mode="reflect") * cotp.double()).sum().backward()
         assert _rel(total, folded.grad + base.double()) <= 2e-6
+
+
+def unblock2(buf, part_stride, groups, B, PP, scale):
+    """two fp16 parts on the device -> [groups][B][PP][8] float64 (high part + what it left, scale undone)"""
+    n = groups * B * PP * 8
+    hi = buf[:2 * n].view(torch.float16).double()
+    lo = buf[part_stride:part_stride + 2 * n].view(torch.float16).double()
+    return ((hi + lo) / scale).reshape(groups, B, PP, 8).cpu()
+
+
+@pytest.mark.parametrize("C,H,mode", [(16, 22, 0), (16, 44, 1), (16, 87, 1)])
+def test_norm_passes_with_two_fp16_parts(C, H, mode):
+    """The normalisation passes writing their operand as two fp16 parts: the forward pass with a fixed scale, the
+    backward pass with the scale of the largest |dc|, which its probe run leaves in a record.  Decoded, both match
+    float64 at the bars of the fp32 arithmetic of the passes (2e-6 forward, 2e-5 backward) -- the parts themselves
+    lose nothing at that level."""
+    g = torch.Generator().manual_seed(C * H + mode + 5)
+    B = 2
+    raw = torch.randn(B, C, H, H, generator=g) * 2 + 0.5
+    rd = raw.double().requires_grad_(True)
+    a = F.instance_norm(rd, eps=1e-5).relu()
+    pitch = H + 2
+    Q = ops._ru(H * pitch, 8)
+    if Q <= 2048:
+        y = _pitched(raw, pitch, Q).to(DEV)
+        st = ops._cb_stats(y, H, H, pitch)
+    else:
+        y, pitch = raw.to(DEV), H
+        st = ops._plane_stats(y)
+    scale = ops._pow2_below(H)
+    if mode == 0:
+        PP = ops._ru((H + 2) * (H + 2) + 5, 4)
+        act, ps, _, _ = ops._cb_norm_fwd(y, st, H, H, pitch, True, 0, PP, parts=2, scale=scale)
+        got = unblock2(act, ps, C // 8, B, PP, scale)
+        ref = cb_reflect(a.detach().float(), PP).double()
+    else:
+        oh = (H + 1) // 2
+        PP = ops._ru((oh + 1) * (oh + 1) + 3, 4)
+        act, ps, _, _ = ops._cb_norm_fwd(y, st, H, H, pitch, True, 1, PP, parts=2, scale=scale)
+        got = unblock2(act, ps, (C // 8) * 4, B, PP, scale)
+        ref = cb_parity(a.detach().float(), PP).double()
+    assert float((got - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
+
+    if H > 44:
+        return                                  # the stem's planes: their backward pass leaves fp32 planes, not an operand
+    # backward: the gradient arrives on the grid of this layer's own consumer
+    if mode == 0:
+        cotp = torch.randn(B, C, H + 2, H + 2, generator=g) * 91.0
+        base = torch.randn(B, C, H, H, generator=g) * 55.0
+        (F.pad(a, (1, 1, 1, 1), mode="reflect") * cotp.double()).sum().backward(retain_graph=True)
+        (a * base.double()).sum().backward()
+        gt = _pitched(cotp, H + 2, ops._ru((H + 2) * (H + 2), 8)).to(DEV)
+        PPd = ops._ru((H + 4) * (H + 2) + 3, 4)
+        rec = torch.zeros(ops.ABSMAX_SLOTS, dtype=torch.int32, device=DEV)
+        dc, pd, _, total = ops._cb_norm_bwd(gt, 1, H + 2, y, st, pitch, True, C, H, H, 0, PPd, base=base.to(DEV), want_sum=True,
+                                            parts=2, amax_dc=rec)
+        ref = cb_zero2(rd.grad.float(), PPd).double()
+    else:
+        cot = torch.randn(B, C, H, H, generator=g) * 0.003
+        (a * cot.double()).sum().backward()
+        rec = torch.zeros(ops.ABSMAX_SLOTS, dtype=torch.int32, device=DEV)
+        PPd = ops._ru((H + 1) * (H + 1) + 3, 4)
+        dc, pd, _, _ = ops._cb_norm_bwd(cot.to(DEV), 0, H, y, st, pitch, True, C, H, H, 1, PPd, parts=2, amax_dc=rec)
+        ref = cb_zero_behind(rd.grad.float(), PPd).double()
+    top = ops.absmax_value(rec)
+    assert abs(top - float(rd.grad.abs().max())) <= 2e-5 * top            # the probe run's record: the largest |dc|
+    got = unblock2(dc, pd, C // 8, B, PPd, 2.0 ** (14 - int(np.floor(np.log2(top)))))
+    assert float((got - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+    assert torch.equal(got == 0, ref == 0) or float(((got == 0) != (ref == 0)).double().mean()) < 1e-4
 
 
 @pytest.mark.parametrize("variant", ["cnn_gcn_fc", "cnn_gcn_sc"])

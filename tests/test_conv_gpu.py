@@ -227,6 +227,54 @@ def _check_grads(fix, model, skip_prefix=()):
         recipe.check_grad(fix, name, g, 1e-4, "hip")
 
 
+# A ReLU gate may differ from the float64 run's only where that run's normalised value is this close to zero, and in
+# at most this many entries of the whole encoder.
+GATE_TIE = 1e-5
+GATE_FLIPS = 4
+
+
+def _check_grads_under_device_gates(variant, fix, model, gates, first):
+    """The fixture's float64 gradients take each ReLU's gate from the float64 forward.  A normalised value within
+    rounding of zero falls on either side in fp32 arithmetic (the reference's own fp32 run included), and one such
+    entry moves the gradient of every layer in front of it by about 1/sqrt(entries of the plane stack) of its norm:
+    3e-3 for the 19x19 stacks, far above the fixture bars.  When that is what happened -- and only then: the device's
+    gates differ from the float64 run's in at most GATE_FLIPS entries, each with a float64 value under GATE_TIE --
+    the gradients are checked against the float64 run of the oracle with the device's gates, at 1e-4 of each norm."""
+    p = {k: v.clone().requires_grad_(True) for k, v in fixture_params(fix, torch.float64).items()}
+    mask = torch.from_numpy(fix["mask"]).double() if "mask" in fix.files else None
+    if mask is not None:
+        with torch.no_grad():
+            for n in ("fc4", "fc5", "fc6", "fc7", "fc8"):
+                p[n + ".weight"].mul_(mask)
+            p["fcintercept.weight"].mul_(torch.eye(68 * 68, dtype=torch.float64))
+    x = torch.from_numpy(fix["x"]).double()
+    eps = torch.from_numpy(fix["eps"]).double()
+    cpu_gates = [g.cpu() for g in gates]
+    normed = []
+    with torch.no_grad():
+        R.vae_forward(variant, p, x, eps, mask=mask, conv_normed=normed)
+    assert len(normed) == len(cpu_gates), first
+    flips = 0
+    for g, v in zip(cpu_gates, normed):
+        differ = g != (v > 0)
+        flips += int(differ.sum())
+        assert float(v[differ].abs().max()) <= GATE_TIE if differ.any() else True, first
+    assert 1 <= flips <= GATE_FLIPS, (flips, first)
+    recon, mu, logvar, _, _ = R.vae_forward(variant, p, x, eps, mask=mask, conv_gates=cpu_gates)
+    R.vae_loss(recon, x, mu, logvar, R.loss_mode(variant)).backward()
+    for name, q in model.named_parameters():
+        if name.startswith("ec.") and name.endswith(".bias"):
+            continue
+        ref = p[name].grad
+        got = q.grad.detach().double().cpu()
+        if name == "fcintercept.weight" and got.dim() == 1:
+            ref = torch.diagonal(ref)
+        err = float((got - ref).norm() / ref.norm())
+        recipe.record(fix, f"hip, float64 oracle with the device's ReLU gates ({flips} differ from the float64 run's)", name, err, 1e-4,
+                      "L2 distance / norm")
+        assert err <= 1e-4, (name, err, first)
+
+
 def test_encoder_87_against_reference_fixture():
     fix = load_fixture("ec87")
     params = fixture_params(fix)
@@ -265,13 +313,23 @@ def test_conv_vae_against_reference_fixture(variant):
     if "mask" in fix.files:
         model.set_mask([torch.from_numpy(fix["mask"])] * 5 + [torch.eye(68 * 68)])
     x = torch.from_numpy(fix["x"]).to(DEV)
-    recon, mu, logvar, x_latent = model(x, eps=torch.from_numpy(fix["eps"]).to(DEV))
+    gates = []
+    ops.RELU_GATE_SINK = gates
+    try:
+        recon, mu, logvar, x_latent = model(x, eps=torch.from_numpy(fix["eps"]).to(DEV))
+    finally:
+        ops.RELU_GATE_SINK = None
     loss = M.vae_loss(recon, x, mu, logvar, R.loss_mode(variant))
     loss.backward()
     assert _rel(mu, fix["mu"]) <= 1e-5 and _rel(logvar, fix["logvar"]) <= 1e-5
     assert _rel(recon, fix["recon"]) <= 1e-5 and _rel(x_latent, fix["x_latent"]) <= 1e-5
     assert abs(loss.item() - float(fix["loss"])) <= 1e-5 * abs(float(fix["loss"]))
-    _check_grads(fix, model)
+    try:
+        _check_grads(fix, model)
+    except AssertionError as first:
+        if not gates:
+            raise
+        _check_grads_under_device_gates(variant, fix, model, gates, first)
 
 
 # bars of the bf16 mode against the fp32 reference fixture: every 3x3 convolution rounds its operands to

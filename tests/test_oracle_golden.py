@@ -192,3 +192,18 @@ def test_resnet_mlp_vae():
     _close(recon.detach(), fix["recon"], OUT_RTOL, "recon")
     assert abs(loss.item() - float(fix["loss"])) <= LOSS_RTOL * abs(float(fix["loss"]))
     _check_grads(fix, p)
+
+
+def test_conv_encoder_with_its_own_relu_gates_passed_back_in():
+    """conv_features(gates=...) with the masks of its own forward is the same function, gradients included."""
+    fix = load_fixture("cnn_nn_fc")
+    x = torch.from_numpy(fix["x"]).double()
+    runs = []
+    for gated in (False, True):
+        p = {k: v.clone().requires_grad_(True) for k, v in fixture_params(fix, torch.float64).items()}
+        normed = []
+        f = R.conv_features(p, x, normed=normed, gates=[v > 0 for v in runs[0][2]] if gated else None)
+        (f * torch.linspace(-1, 1, f.numel(), dtype=torch.float64).view_as(f)).sum().backward()
+        runs.append((f.detach(), p["ec.1.weight"].grad, normed))
+    assert len(runs[0][2]) == 8
+    assert torch.equal(runs[0][0], runs[1][0]) and torch.allclose(runs[0][1], runs[1][1], rtol=1e-12, atol=0)

@@ -49,20 +49,20 @@ def blocked():
     kinds = [1, 1] + [0] * 10
     wf = [ops._cb_pack(w, k, DEV) for w, k in zip(ws[1:], kinds)]
     raw1 = stem.fwd(x, None, 0, wstem, bs[0], B); st1 = ops._plane_stats(raw1)
-    a1, _, _ = ops._cb_norm_fwd(raw1, st1, n, n, n, True, 1, G.pp_a1)
+    a1, _, _, _ = ops._cb_norm_fwd(raw1, st1, n, n, n, True, 1, G.pp_a1)
     y2 = ops._cb_conv(a1, 0, wf[0], bs[1], B, 96, 48, 1, G.h2, G.p2, G.pp_a1); st2 = ops._cb_stats(y2, G.h2, G.h2, G.p2)
-    a2, _, _ = ops._cb_norm_fwd(y2, st2, G.h2, G.h2, G.p2, True, 1, G.pp_a2)
+    a2, _, _, _ = ops._cb_norm_fwd(y2, st2, G.h2, G.h2, G.p2, True, 1, G.pp_a2)
     y3 = ops._cb_conv(a2, 0, wf[1], bs[2], B, 192, 96, 1, G.h3, G.p3, G.pp_a2); st3 = ops._cb_stats(y3, G.h3, G.h3, G.p3)
     H = G.h3
-    xp, xs, _ = ops._cb_norm_fwd(y3, st3, H, H, G.p3, True, 0, G.pp_r, want_stream=True)
+    xp, _, xs, _ = ops._cb_norm_fwd(y3, st3, H, H, G.p3, True, 0, G.pp_r, want_stream=True)
     crop = lambda y, h, p: y[:, :, :h * p].reshape(B, -1, h, p)[:, :, :, :h]
     out.update(raw1=raw1, raw2=crop(y2, G.h2, G.p2), raw3=crop(y3, G.h3, G.p3), x0=xs)
     for k in range(5):
         ia, ib = 2 + 2 * k, 3 + 2 * k
         ya = ops._cb_conv(xp, 0, wf[ia], bs[ia + 1], B, 192, 192, 0, H, G.pr, G.pp_r); sa = ops._cb_stats(ya, H, H, G.pr)
-        aa, _, _ = ops._cb_norm_fwd(ya, sa, H, H, G.pr, True, 0, G.pp_r)
+        aa, _, _, _ = ops._cb_norm_fwd(ya, sa, H, H, G.pr, True, 0, G.pp_r)
         yb = ops._cb_conv(aa, 0, wf[ib], bs[ib + 1], B, 192, 192, 0, H, G.pr, G.pp_r); sb = ops._cb_stats(yb, H, H, G.pr)
-        xp, xs, _ = ops._cb_norm_fwd(yb, sb, H, H, G.pr, False, 0, G.pp_r, skip=xs, want_stream=True)
+        xp, _, xs, _ = ops._cb_norm_fwd(yb, sb, H, H, G.pr, False, 0, G.pp_r, skip=xs, want_stream=True)
         out[f"ra{k}"] = crop(ya, H, G.pr); out[f"rb{k}"] = crop(yb, H, G.pr); out[f"x{k+1}"] = xs
     return out
 
