@@ -52,11 +52,16 @@ __device__ __forceinline__ unsigned cb_slot_max(const unsigned* __restrict__ slo
     for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
     return m;
 }
-// record of a wave's largest magnitude: one atomic per wave, spread over the slots
+// record of a wave's largest magnitude, spread over the slots: an atomic only when the slot (read past the L1, which
+// may hold an older, smaller value) does not hold as much already -- tens of thousands of waves share 64 words, and
+// after the first few almost none of them has anything to add
 __device__ __forceinline__ void cb_record_max(unsigned* __restrict__ slots, unsigned m, unsigned spread) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
-    if ((threadIdx.x & 63) == 0) atomicMax(slots + (spread & (MDNVAE_ABSMAX_SLOTS - 1)), m);
+    if ((threadIdx.x & 63) == 0) {
+        unsigned* slot = slots + (spread & (MDNVAE_ABSMAX_SLOTS - 1));
+        if (__hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < m) atomicMax(slot, m);
+    }
 }
 
 struct CbConv {
@@ -611,6 +616,7 @@ struct CbNormBwd {
     float* gsum;             // [B * C] plane sums of the result (conv bias gradient), or null
     const unsigned* amax_dc; // two fp16 parts: the record of the largest |dc| (a probe run of this pass); its scale replaces `scale`
     unsigned* amax_probe;    // probe run: nothing is written but the largest |dc| into this record
+    int lds_gfloats;         // LDS-staged kernel: floats reserved for the gradient planes / the result's image
 };
 
 __device__ __forceinline__ float cb_fold_gather(const float* __restrict__ gp, int y, int x, int H, int W, int Wp) {
@@ -781,99 +787,178 @@ __device__ __forceinline__ void cb_dma_floats(const float* __restrict__ src, flo
     cb_dma_bytes<NT>(reinterpret_cast<const char*>(src), reinterpret_cast<char*>(dst), n * 4);
 }
 
-// sums of 8 values over the workgroup (NT / 64 waves, in wave order), result in every thread; red: [NT / 64][8] floats
+// ---- the LDS-staged passes, arithmetic by (channel, four positions) --------------------------
+// The passes above spend their time on instructions, not on memory: a thread that owns a position reads eight
+// 2- or 4-byte values from eight planes and carries eight-fold statistics.  Here thread t owns channel t & 7 and the
+// position quads (t >> 3) + (NT / 8) k, k < KQ: one 8- or 16-byte LDS read brings four values of its plane, they stay
+// in registers through the statistics (mean, then squared deviations: two plane reductions over the lanes of a channel)
+// and the arithmetic, and leave as 16-bit values into an LDS image [position][8 channels] of the plane stack.  A
+// second phase walks the output positions (reflection border, zero border or parity planes) and copies 16 bytes per
+// position from that image.
 template <int NT>
-__device__ __forceinline__ void cb_block_sum8(float (&v)[8], float* red) {
+__device__ __forceinline__ float cb_chan_sum(float s, float* red) {       // sum over the threads of a channel (t & 7)
+    s += __shfl_xor(s, 8);
+    s += __shfl_xor(s, 16);
+    s += __shfl_xor(s, 32);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = wave_sum_all(v[e]);
     __syncthreads();
-    if (lane == 0) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) red[wave * 8 + e] = v[e];
-    }
+    if (lane < 8) red[wave * 8 + lane] = s;
     __syncthreads();
+    float t = 0.0f;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        float t = 0.0f;
+    for (int w = 0; w < NT / 64; ++w) t += red[w * 8 + (threadIdx.x & 7)];
+    return t;
+}
+
+// four consecutive values of a plane in LDS (index a multiple of 4)
+__device__ __forceinline__ void cb_load_quad(const float* pl, int i, float (&v)[4]) {
+    const cb_f4 t = *reinterpret_cast<const cb_f4*>(pl + i);
 #pragma unroll
-        for (int w = 0; w < NT / 64; ++w) t += red[w * 8 + e];
-        v[e] = t;
+    for (int j = 0; j < 4; ++j) v[j] = t[j];
+}
+typedef _Float16 cb_h4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void cb_load_quad(const _Float16* pl, int i, float (&v)[4]) {
+    const cb_h4 t = *reinterpret_cast<const cb_h4*>(pl + i);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = (float)t[j];
+}
+
+// one value into the image: bf16, or two fp16 parts of v * scale (second image `stride` bytes behind)
+template <int PARTS>
+__device__ __forceinline__ void cb_image_put(char* img, int stride, int pos, int e, float v, float scale) {
+    if constexpr (PARTS == 1) {
+        reinterpret_cast<__bf16*>(img)[pos * 8 + e] = (__bf16)v;
+    } else {
+        const float t = v * scale;
+        const _Float16 hi = (_Float16)t;
+        reinterpret_cast<_Float16*>(img)[pos * 8 + e] = hi;
+        reinterpret_cast<_Float16*>(img + stride)[pos * 8 + e] = (_Float16)(t - (float)hi);
     }
 }
 
-template <int PARTS, int MODE, typename YT>
-__global__ __launch_bounds__(256) void cb_norm_fwd_lds_kernel(CbNormFwd p, float* __restrict__ stats_out) {
+// bit `i` of a mask as a predicate
+__device__ __forceinline__ bool cb_bit(unsigned m, int i) { return (m >> i) & 1u; }
+
+// STREAM (MODE 0): the residual stream is read (skip, may be null) and / or written (stream_out, may be null)
+template <int PARTS, int MODE, bool STREAM, typename YT, int NT, int KQ>
+__global__ __launch_bounds__(NT) void cb_norm_fwd_q_kernel(CbNormFwd p, float* __restrict__ stats_out) {
+    static_assert(MODE == 0 || !STREAM, "the residual stream goes with the reflection-padded output");
     extern __shared__ __attribute__((aligned(16))) float fsm[];
-    float* red = fsm;                    // [64]
-    YT* ybuf = reinterpret_cast<YT*>(fsm + 64);      // [8][Qy]
+    float* red = fsm;                                   // [64]
+    YT* ybuf = reinterpret_cast<YT*>(fsm + 64);         // [8][Qy]
+    const int Qv = p.H * p.pitch_y;                     // positions of the pitched plane that hold rows
+    const int NQ = (Qv + 3) >> 2;
+    char* img = reinterpret_cast<char*>(ybuf) + 8 * (size_t)p.Qy * sizeof(YT);
+    const int img_stride = NQ * 64;
     const int g8 = blockIdx.x, b = blockIdx.y;
     const int HW = p.H * p.W;
     const long pl0 = (long)b * p.C + g8 * 8;
-    cb_dma_bytes<256>(reinterpret_cast<const char*>(static_cast<const YT*>(p.y) + pl0 * p.Qy), reinterpret_cast<char*>(ybuf),
-                      8 * p.Qy * (int)sizeof(YT));
+    const int e = threadIdx.x & 7, q0 = threadIdx.x >> 3;
+    constexpr int QS = NT / 8;
+    cb_dma_bytes<NT>(reinterpret_cast<const char*>(static_cast<const YT*>(p.y) + pl0 * p.Qy), reinterpret_cast<char*>(ybuf),
+                     8 * p.Qy * (int)sizeof(YT));
     const unsigned mpy = (unsigned)(0x100000000ull / (unsigned)p.pitch_y) + 1u;
-    const unsigned mop = (unsigned)(0x100000000ull / (unsigned)p.opitch) + 1u;
-    cb_wait_vm<0>();
-    __syncthreads();
-    // statistics over the valid entries of the pitched planes
-    const int Qv = p.H * p.pitch_y;
-    float mean[8], rstd[8];
-    {
-        float s[8];
+    const int gap = p.pitch_y - p.W;                    // pitched index - gap * row = index in the [H * W] planes
+    // the residual stream's 8 planes [8][H * W] are one contiguous run in memory: staged in LDS like y, updated in
+    // place by the threads that own the entries, and written back as one contiguous run
+    float* sbuf = reinterpret_cast<float*>(img + (p.act ? PARTS * img_stride : 0));
+    if (STREAM && p.skip) cb_dma_floats<NT>(p.skip + pl0 * HW, sbuf, 8 * HW);
+    float* sbe = sbuf + e * HW;
+    // which of this thread's entries are output pixels (okm), which quads are four pixels of one row (rowm)
+    unsigned okm = 0, rowm = 0;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) s[e] = 0.0f;
-        for (int i = threadIdx.x; i < Qv; i += 256) {
-            const int r = (int)__umulhi((unsigned)i, mpy), c = i - r * p.pitch_y;
-            if (c < p.W) {
+    for (int k = 0; k < KQ; ++k) {
+        const int i0 = (q0 + QS * k) * 4;
+        const int r0 = (int)__umulhi((unsigned)i0, mpy), c0 = i0 - r0 * p.pitch_y;
+        rowm |= (i0 + 3 < Qv && c0 + 3 < p.W) ? 1u << k : 0u;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) s[e] += (float)ybuf[e * p.Qy + i];
-            }
-        }
-        cb_block_sum8<256>(s, red);
-        const float inv = 1.0f / (float)HW;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) mean[e] = s[e] * inv;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) s[e] = 0.0f;
-        for (int i = threadIdx.x; i < Qv; i += 256) {
-            const int r = (int)__umulhi((unsigned)i, mpy), c = i - r * p.pitch_y;
-            if (c < p.W) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float d = (float)ybuf[e * p.Qy + i] - mean[e];
-                    s[e] += d * d;
-                }
-            }
-        }
-        cb_block_sum8<256>(s, red);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) rstd[e] = 1.0f / sqrtf(s[e] * inv + CB_IN_EPS);
-        if (threadIdx.x < 8) {
-            const int e = threadIdx.x;
-            float m = mean[0], r = rstd[0];
-#pragma unroll
-            for (int k = 1; k < 8; ++k) {
-                m = e == k ? mean[k] : m;
-                r = e == k ? rstd[k] : r;
-            }
-            stats_out[2 * (pl0 + e)] = m;
-            stats_out[2 * (pl0 + e) + 1] = r;
+        for (int j = 0; j < 4; ++j) {
+            const bool wrap = c0 + j >= p.pitch_y;
+            const bool ok = i0 + j < Qv && (wrap ? c0 + j - p.pitch_y : c0 + j) < p.W;
+            okm |= ok ? 1u << (k * 4 + j) : 0u;
         }
     }
+    cb_wait_vm<0>();
+    __syncthreads();
+    float v[KQ][4];
+    float s = 0.0f;
+    const YT* ype = ybuf + (size_t)e * p.Qy;
+#pragma unroll
+    for (int k = 0; k < KQ; ++k) {
+        const int q = q0 + QS * k;
+        cb_load_quad(ype, (q < NQ ? q : 0) * 4, v[k]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            v[k][j] = cb_bit(okm, k * 4 + j) ? v[k][j] : 0.0f;
+            s += v[k][j];
+        }
+    }
+    const float inv = 1.0f / (float)HW;
+    const float mean = cb_chan_sum<NT>(s, red) * inv;
+    s = 0.0f;
+#pragma unroll
+    for (int k = 0; k < KQ; ++k)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float d = cb_bit(okm, k * 4 + j) ? v[k][j] - mean : 0.0f;
+            s = fmaf(d, d, s);
+        }
+    const float rstd = 1.0f / sqrtf(cb_chan_sum<NT>(s, red) * inv + CB_IN_EPS);
+    if (threadIdx.x < 8) {
+        stats_out[2 * (pl0 + e)] = mean;
+        stats_out[2 * (pl0 + e) + 1] = rstd;
+    }
+    const float floor_ = p.relu ? 0.0f : -__builtin_huge_valf();
+#pragma unroll
+    for (int k = 0; k < KQ; ++k) {
+        const int q = q0 + QS * k;
+        const int i0 = q * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[k][j] = fmaxf((v[k][j] - mean) * rstd, floor_);
+        if (STREAM) {
+            const int r0 = (int)__umulhi((unsigned)i0, mpy), c0 = i0 - r0 * p.pitch_y;
+            const int off0 = i0 - r0 * gap;
+            if (cb_bit(rowm, k)) {
+                if (p.skip) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[k][j] += sbe[off0 + j];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) sbe[off0 + j] = v[k][j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (cb_bit(okm, k * 4 + j)) {
+                        const int off = off0 + j - (c0 + j >= p.pitch_y ? gap : 0);
+                        if (p.skip) v[k][j] += sbe[off];
+                        sbe[off] = v[k][j];
+                    }
+            }
+        }
+        if (p.act && q < NQ) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) cb_image_put<PARTS>(img, img_stride, i0 + j, e, v[k][j], p.scale);
+        }
+    }
+    __syncthreads();
+    if (STREAM && p.stream_out) {
+        float* so = p.stream_out + pl0 * HW;
+        for (int i = threadIdx.x * 4; i < 8 * HW; i += NT * 4) *reinterpret_cast<cb_f4*>(so + i) = *reinterpret_cast<const cb_f4*>(sbuf + i);
+    }
+    if (!p.act) return;
+    const unsigned mop = (unsigned)(0x100000000ull / (unsigned)p.opitch) + 1u;
     constexpr int NPL = MODE == 1 ? 4 : 1;
 #pragma unroll
     for (int plane = 0; plane < NPL; ++plane) {
         const long gp = MODE == 1 ? (long)(g8 >> 1) * 8 + plane * 2 + (g8 & 1) : g8;
-        char* dst = p.act ? p.act + ((gp * p.B + b) * p.PP) * 16 : nullptr;
-        for (int pos = threadIdx.x; pos < p.PP; pos += 256) {
+        char* dst = p.act + ((gp * p.B + b) * p.PP) * 16;
+        for (int pos = threadIdx.x; pos < p.PP; pos += NT) {
             const int pr = (int)__umulhi((unsigned)pos, mop), pc = pos - pr * p.opitch;
             int r, c;
-            bool ok, interior = false;
+            bool ok;
             if (MODE == 0) {
                 r = pr - 1; c = pc - 1;
                 ok = pr < p.H + 2 && pc < p.W + 2;
-                interior = ok && r >= 0 && r < p.H && c >= 0 && c < p.W;
                 r = r < 0 ? -r : (r >= p.H ? 2 * (p.H - 1) - r : r);
                 c = c < 0 ? -c : (c >= p.W ? 2 * (p.W - 1) - c : c);
             } else {
@@ -881,40 +966,34 @@ __global__ __launch_bounds__(256) void cb_norm_fwd_lds_kernel(CbNormFwd p, float
                 ok = pr >= 1 && pc >= 1 && r < p.H && c < p.W;
             }
             const int src = ok ? r * p.pitch_y + c : 0;
-            float v[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                float t = ((float)ybuf[e * p.Qy + src] - mean[e]) * rstd[e];
-                if (p.relu) t = fmaxf(t, 0.0f);
-                v[e] = ok ? t : 0.0f;
+            cb_u4 w0 = *reinterpret_cast<const cb_u4*>(img + src * 16);
+            if (!ok) w0 = cb_u4{0u, 0u, 0u, 0u};
+            *reinterpret_cast<cb_u4*>(dst + (long)pos * 16) = w0;
+            if (PARTS == 2) {
+                cb_u4 w1 = *reinterpret_cast<const cb_u4*>(img + img_stride + src * 16);
+                if (!ok) w1 = cb_u4{0u, 0u, 0u, 0u};
+                *reinterpret_cast<cb_u4*>(dst + p.part_stride + (long)pos * 16) = w1;
             }
-            if (MODE == 0 && p.skip && ok) {
-                const float* sk = p.skip + pl0 * HW + r * p.W + c;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] += sk[(long)e * HW];
-            }
-            if (MODE == 0 && p.stream_out && interior) {
-                float* so = p.stream_out + pl0 * HW + r * p.W + c;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) so[(long)e * HW] = v[e];
-            }
-            if (dst) cb_store8<PARTS>(v, p.scale, dst + (long)pos * 16, p.part_stride);
         }
     }
 }
 
-// GMODE / OMODE as in CbNormBwd (OMODE 0 or 1: channel-blocked output, 8 channels per workgroup); BASE: p.base is given
-// (its sum with the gathered gradient can be written to p.sum_out).  NT threads own NPOS output positions each.
-template <int PARTS, int GMODE, int OMODE, bool BASE, int NT, int NPOS, typename YT>
-__global__ __launch_bounds__(NT) void cb_norm_bwd_lds_kernel(CbNormBwd p) {
+template <int PARTS, int GMODE, int OMODE, bool BASE, typename YT, int NT, int KQ>
+__global__ __launch_bounds__(NT) void cb_norm_bwd_q_kernel(CbNormBwd p) {
     extern __shared__ __attribute__((aligned(16))) float fsm[];
-    float* red = fsm;                                  // [64]
-    YT* ybuf = reinterpret_cast<YT*>(fsm + 64);        // [8][Qy]
+    float* red = fsm;                                   // [64]
+    YT* ybuf = reinterpret_cast<YT*>(fsm + 64);         // [8][Qy]
     const int Qy = (int)p.Qy, Qg = (int)p.Qg;
-    float* gbuf = fsm + 64 + 8 * Qy * (int)sizeof(YT) / 4;    // GMODE 0, 1: [8][Qg] and one zero;  2: [4][8][Qg]
+    float* gbuf = fsm + 64 + 8 * Qy * (int)sizeof(YT) / 4;     // GMODE 0, 1: [8][Qg];  2: [4][8][Qg]
+    char* img = reinterpret_cast<char*>(gbuf);          // the result's image takes the gradient's place once that is consumed
+    const int Qv = p.H * p.pitch_y;
+    const int NQ = (Qv + 3) >> 2;
+    const int img_stride = NQ * 64;
     const int g8 = blockIdx.x, b = blockIdx.y;
     const int HW = p.H * p.W;
     const long pl0 = (long)b * p.C + g8 * 8;
+    const int e = threadIdx.x & 7, q0 = threadIdx.x >> 3;
+    constexpr int QS = NT / 8;
     const float dc_scale = (PARTS == 2 && p.amax_dc) ? cb_pow2_scale(cb_slot_max(p.amax_dc)) : p.scale;
     cb_dma_bytes<NT>(reinterpret_cast<const char*>(static_cast<const YT*>(p.y) + pl0 * Qy), reinterpret_cast<char*>(ybuf),
                      8 * Qy * (int)sizeof(YT));
@@ -922,126 +1001,246 @@ __global__ __launch_bounds__(NT) void cb_norm_bwd_lds_kernel(CbNormBwd p) {
 #pragma unroll
         for (int pl = 0; pl < 4; ++pl)
             cb_dma_floats<NT>(p.g + (((long)b * 4 + pl) * p.C + g8 * 8) * Qg, gbuf + pl * 8 * Qg, 8 * Qg);
-    } else if (GMODE != 3) {
+    } else {
         cb_dma_floats<NT>(p.g + pl0 * Qg, gbuf, 8 * Qg);
     }
-    const int zero_at = 8 * Qg;                        // GMODE 1: where absent fold terms read
-    if (GMODE == 1 && threadIdx.x == 0) gbuf[zero_at] = 0.0f;
-    const unsigned mop = (unsigned)(0x100000000ull / (unsigned)p.opitch) + 1u;
-    float mean[8], rstd[8];
+    const unsigned mpy = (unsigned)(0x100000000ull / (unsigned)p.pitch_y) + 1u;
+    const int gap = p.pitch_y - p.W;
+    const float mean = p.stats[2 * (pl0 + e)], rstd = p.stats[2 * (pl0 + e) + 1];
+    // the residual stream's gradient [8][H * W]: one contiguous run, staged in LDS, updated in place, written back whole
+    float* bbuf = gbuf + p.lds_gfloats;
+    if (BASE) cb_dma_floats<NT>(p.base + pl0 * HW, bbuf, 8 * HW);
+    float* bbe = bbuf + e * HW;
+    const bool sums = BASE && p.sum_out && !p.amax_probe;
+    unsigned okm = 0, rowm = 0;               // output pixels; quads that are four pixels of one row
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        mean[e] = p.stats[2 * (pl0 + e)];
-        rstd[e] = p.stats[2 * (pl0 + e) + 1];
-    }
-    // this thread's positions: source offsets first (no memory traffic), then everything comes from LDS
-    constexpr int NG = GMODE == 1 ? 4 : 1;
-    int ysrc[NPOS], gsrc[NPOS][NG], bsrc[NPOS];
+    for (int k = 0; k < KQ; ++k) {
+        const int i0 = (q0 + QS * k) * 4;
+        const int r0 = (int)__umulhi((unsigned)i0, mpy), c0 = i0 - r0 * p.pitch_y;
+        rowm |= (i0 + 3 < Qv && c0 + 3 < p.W) ? 1u << k : 0u;
 #pragma unroll
-    for (int i = 0; i < NPOS; ++i) {
-        const int pos = threadIdx.x + NT * i;
-        const int pr = (int)__umulhi((unsigned)pos, mop), pc = pos - pr * p.opitch;
-        const int r = OMODE == 0 ? pr - 2 : pr, c = OMODE == 0 ? pc - 2 : pc;
-        const bool ok = pos < p.PP && r >= 0 && r < p.H && c >= 0 && c < p.W;
-        ysrc[i] = ok ? r * p.pitch_y + c : -1;
-        bsrc[i] = ok ? r * p.W + c : 0;
-#pragma unroll
-        for (int k = 0; k < NG; ++k) gsrc[i][k] = -1;
-        if (GMODE == 0) {
-            gsrc[i][0] = ok ? r * p.pitch_g + c : 0;
-        } else if (GMODE == 1) {
-            // padded position (r + 1, c + 1) plus the mirrored border rows / columns that reflect onto (r, c)
-            const int Wp = p.pitch_g;
-            const int r1 = (r == 1) ? 0 : ((r == p.H - 2) ? p.H + 1 : -1);
-            const int c1 = (c == 1) ? 0 : ((c == p.W - 2) ? p.W + 1 : -1);
-            gsrc[i][0] = ok ? (r + 1) * Wp + c + 1 : -1;
-            if (ok && r1 >= 0) gsrc[i][1] = r1 * Wp + c + 1;
-            if (ok && c1 >= 0) gsrc[i][NG > 2 ? 2 : 0] = (r + 1) * Wp + c1;
-            if (ok && r1 >= 0 && c1 >= 0) gsrc[i][NG > 3 ? 3 : 0] = r1 * Wp + c1;
-        } else if (GMODE == 2) {
-            gsrc[i][0] = ok ? ((r & 1) * 2 + (c & 1)) * 8 * Qg + (r >> 1) * p.pitch_g + (c >> 1) : 0;
+        for (int j = 0; j < 4; ++j) {
+            const bool wrap = c0 + j >= p.pitch_y;
+            const bool ok = i0 + j < Qv && (wrap ? c0 + j - p.pitch_y : c0 + j) < p.W;
+            okm |= ok ? 1u << (k * 4 + j) : 0u;
         }
-    }
-    float bv[BASE ? NPOS : 1][8];
-    if (BASE) {
-#pragma unroll
-        for (int i = 0; i < NPOS; ++i)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) bv[BASE ? i : 0][e] = p.base[(pl0 + e) * HW + bsrc[i]];
     }
     cb_wait_vm<0>();
     __syncthreads();
-    float dn[NPOS][8], xh[NPOS][8];
-    float s1[8], s2[8];
+    float dn[KQ][4], xh[KQ][4];
+    float s1 = 0.0f, s2 = 0.0f;
+    const float* ge = gbuf + e * Qg;
+    const YT* ype = ybuf + (size_t)e * Qy;
+    const float shift = -mean * rstd;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.0f;
+    for (int k = 0; k < KQ; ++k) {
+        const int q = q0 + QS * k;
+        const int i0 = q * 4;
+        cb_load_quad(ype, (q < NQ ? q : 0) * 4, xh[k]);
+        const int r0 = (int)__umulhi((unsigned)i0, mpy), c0 = i0 - r0 * p.pitch_y;
+        int r = r0, c = c0;
 #pragma unroll
-    for (int i = 0; i < NPOS; ++i) {
-        const bool ok = ysrc[i] >= 0;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
+        for (int j = 0; j < 4; ++j) {
             float gv = 0.0f;
-            if (GMODE == 1) {
-                float t[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) t[k] = gbuf[gsrc[i][k % NG] >= 0 ? e * Qg + gsrc[i][k % NG] : zero_at];
-                gv = (t[0] + t[1]) + (t[2] + t[3]);
-            } else if (GMODE != 3) {
-                gv = gbuf[e * Qg + gsrc[i][0]];
+            if (cb_bit(okm, k * 4 + j)) {
+                if (GMODE == 0) {
+                    gv = ge[r * p.pitch_g + c];
+                } else if (GMODE == 1) {
+                    // padded position (r + 1, c + 1) plus the mirrored border rows / columns that reflect onto (r, c)
+                    const int Wp = p.pitch_g;
+                    const int r1 = (r == 1) ? 0 : ((r == p.H - 2) ? p.H + 1 : -1);
+                    const int c1 = (c == 1) ? 0 : ((c == p.W - 2) ? p.W + 1 : -1);
+                    gv = ge[(r + 1) * Wp + c + 1];
+                    if (r1 >= 0) gv += ge[r1 * Wp + c + 1];
+                    if (c1 >= 0) gv += ge[(r + 1) * Wp + c1];
+                    if (r1 >= 0 && c1 >= 0) gv += ge[r1 * Wp + c1];
+                } else {
+                    gv = ge[((r & 1) * 2 + (c & 1)) * 8 * Qg + (r >> 1) * p.pitch_g + (c >> 1)];
+                }
             }
-            if (BASE) gv += bv[BASE ? i : 0][e];
-            gv = ok ? gv : 0.0f;
-            const float x = ok ? ((float)ybuf[e * Qy + (ok ? ysrc[i] : 0)] - mean[e]) * rstd[e] : 0.0f;
-            if (BASE) bv[BASE ? i : 0][e] = gv;          // base + gradient, before the mask
+            dn[k][j] = gv;
+            if (++c == p.pitch_y) { c = 0; ++r; }
+        }
+        if (BASE) {                                      // base + gradient, before the mask
+            const int off0 = i0 - r0 * gap;
+            if (cb_bit(rowm, k)) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) dn[k][j] += bbe[off0 + j];
+                if (sums) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) bbe[off0 + j] = dn[k][j];
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (cb_bit(okm, k * 4 + j)) {
+                        const int off = off0 + j - (c0 + j >= p.pitch_y ? gap : 0);
+                        dn[k][j] += bbe[off];
+                        if (sums) bbe[off] = dn[k][j];
+                    }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float x = cb_bit(okm, k * 4 + j) ? fmaf(xh[k][j], rstd, shift) : 0.0f;
+            float gv = dn[k][j];
             if (p.relu && !(x > 0.0f)) gv = 0.0f;
-            dn[i][e] = gv;
-            xh[i][e] = x;
-            s1[e] += gv;
-            s2[e] += gv * x;
+            dn[k][j] = gv;
+            xh[k][j] = x;
+            s1 += gv;
+            s2 = fmaf(gv, x, s2);
         }
     }
-    if (BASE && p.sum_out && !p.amax_probe) {
-#pragma unroll
-        for (int i = 0; i < NPOS; ++i)
-            if (ysrc[i] >= 0) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) p.sum_out[(pl0 + e) * HW + bsrc[i]] = bv[BASE ? i : 0][e];
-            }
-    }
-    cb_block_sum8<NT>(s1, red);
-    cb_block_sum8<NT>(s2, red);
     const float inv = 1.0f / (float)HW;
-    float gs[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) gs[e] = 0.0f;
+    const float m1 = cb_chan_sum<NT>(s1, red) * inv;      // (its barriers: every read of the gradient planes is done)
+    const float m2 = cb_chan_sum<NT>(s2, red) * inv;
+    if (sums) {
+        float* so = p.sum_out + pl0 * HW;
+        for (int i = threadIdx.x * 4; i < 8 * HW; i += NT * 4) *reinterpret_cast<cb_f4*>(so + i) = *reinterpret_cast<const cb_f4*>(bbuf + i);
+    }
+    float gs = 0.0f;
     unsigned omax = 0;
 #pragma unroll
-    for (int i = 0; i < NPOS; ++i) {
-        const int pos = threadIdx.x + NT * i;
-        if (pos >= p.PP) continue;
-        const bool ok = ysrc[i] >= 0;
-        float o[8];
+    for (int k = 0; k < KQ; ++k) {
+        const int q = q0 + QS * k;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            o[e] = ok ? rstd[e] * (dn[i][e] - s1[e] * inv - xh[i][e] * (s2[e] * inv)) : 0.0f;
-            gs[e] += o[e];
-            omax = max(omax, __float_as_uint(o[e]) & 0x7fffffffu);
+        for (int j = 0; j < 4; ++j) {
+            const float o = cb_bit(okm, k * 4 + j) ? rstd * (dn[k][j] - m1 - xh[k][j] * m2) : 0.0f;
+            gs += o;
+            omax = max(omax, __float_as_uint(o) & 0x7fffffffu);
+            dn[k][j] = o;
         }
-        if (!p.amax_probe) cb_store8<PARTS>(o, dc_scale, p.dc + (((long)g8 * p.B + b) * p.PP + pos) * 16, p.part_stride);
+        if (!p.amax_probe && q < NQ) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) cb_image_put<PARTS>(img, img_stride, q * 4 + j, e, dn[k][j], dc_scale);
+        }
     }
     if (p.amax_probe) {
         cb_record_max(p.amax_probe, omax, (blockIdx.x + blockIdx.y * gridDim.x) * (NT / 64) + (threadIdx.x >> 6));
         return;
     }
     if (p.gsum) {
-        cb_block_sum8<NT>(gs, red);
-        if (threadIdx.x < 8) {
-            const int e = threadIdx.x;
-            float v = gs[0];
-#pragma unroll
-            for (int k = 1; k < 8; ++k) v = e == k ? gs[k] : v;
-            p.gsum[pl0 + e] = v;
+        gs = cb_chan_sum<NT>(gs, red);
+        if (threadIdx.x < 8) p.gsum[pl0 + e] = gs;
+    }
+    __syncthreads();
+    const unsigned mop = (unsigned)(0x100000000ull / (unsigned)p.opitch) + 1u;
+    char* dst = p.dc + (((long)g8 * p.B + b) * p.PP) * 16;
+    for (int pos = threadIdx.x; pos < p.PP; pos += NT) {
+        const int pr = (int)__umulhi((unsigned)pos, mop), pc = pos - pr * p.opitch;
+        const int r = OMODE == 0 ? pr - 2 : pr, c = OMODE == 0 ? pc - 2 : pc;
+        const bool ok = r >= 0 && r < p.H && c >= 0 && c < p.W;
+        const int src = ok ? r * p.pitch_y + c : 0;
+        cb_u4 w0 = *reinterpret_cast<const cb_u4*>(img + src * 16);
+        if (!ok) w0 = cb_u4{0u, 0u, 0u, 0u};
+        *reinterpret_cast<cb_u4*>(dst + (long)pos * 16) = w0;
+        if (PARTS == 2) {
+            cb_u4 w1 = *reinterpret_cast<const cb_u4*>(img + img_stride + src * 16);
+            if (!ok) w1 = cb_u4{0u, 0u, 0u, 0u};
+            *reinterpret_cast<cb_u4*>(dst + p.part_stride + (long)pos * 16) = w1;
         }
+    }
+}
+
+// The same backward pass for the layer whose planes are too large for LDS (the stem's: fp32 planes [H * W] in, fp32
+// planes out, gradient gathered from the four parity planes of its stride-2 consumer).  One workgroup per plane; a
+// thread owns KQ (row, four columns) items, loads them with 16- and 8-byte accesses that consecutive lanes make
+// contiguous, keeps them in registers through the two plane sums, and stores 16 bytes per item.
+template <int KQ>
+__global__ __launch_bounds__(256) void cb_norm_bwd_plane_kernel(CbNormBwd p) {
+    __shared__ float red[12];
+    const int ch = blockIdx.x, b = blockIdx.y;
+    const int HW = p.H * p.W;
+    const long pl = (long)b * p.C + ch;
+    const int wq = (p.W + 3) >> 2;                      // column quads per row
+    const int nitems = p.H * wq;
+    const unsigned mwq = (unsigned)(0x100000000ull / (unsigned)wq) + 1u;
+    const float* yp = static_cast<const float*>(p.y) + pl * p.Qy;
+    const float* gq = p.g + ((long)b * 4 * p.C + ch) * p.Qg;       // parity plane k: + k * C * Qg
+    const long gps = (long)p.C * p.Qg;
+    const float mean = p.stats[2 * pl], rstd = p.stats[2 * pl + 1];
+    const float shift = -mean * rstd;
+    float dn[KQ][4], xh[KQ][4];
+#pragma unroll
+    for (int k = 0; k < KQ; ++k) {
+        const int it = threadIdx.x + 256 * k;
+        const int r = (int)__umulhi((unsigned)it, mwq), c = (it - r * wq) * 4;
+        const bool in = it < nitems;
+        const bool whole = in && c + 3 < p.W;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dn[k][j] = xh[k][j] = 0.0f;
+        if (whole) {
+            const cb_f4 t = *reinterpret_cast<const cb_f4u*>(yp + r * p.pitch_y + c);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) xh[k][j] = t[j];
+        } else if (in) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (c + j < p.W) xh[k][j] = yp[r * p.pitch_y + c + j];
+        }
+        if (in) {
+            // columns c, c + 2 come from the even-column plane of this row's parity, c + 1, c + 3 from the odd one
+            const float* g0 = gq + ((r & 1) * 2) * gps + (r >> 1) * p.pitch_g + (c >> 1);
+            typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
+            const f2u e2 = *reinterpret_cast<const f2u*>(g0);
+            const f2u o2 = *reinterpret_cast<const f2u*>(g0 + gps);
+            dn[k][0] = e2[0]; dn[k][1] = o2[0]; dn[k][2] = e2[1]; dn[k][3] = o2[1];
+        }
+    }
+    float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+    for (int k = 0; k < KQ; ++k) {
+        const int it = threadIdx.x + 256 * k;
+        const int r = (int)__umulhi((unsigned)it, mwq), c = (it - r * wq) * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool ok = it < nitems && c + j < p.W;
+            const float x = ok ? fmaf(xh[k][j], rstd, shift) : 0.0f;
+            float gv = ok ? dn[k][j] : 0.0f;
+            if (p.relu && !(x > 0.0f)) gv = 0.0f;
+            dn[k][j] = gv;
+            xh[k][j] = x;
+            s1 += gv;
+            s2 = fmaf(gv, x, s2);
+        }
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    s1 = wave_sum_all(s1);
+    s2 = wave_sum_all(s2);
+    if (lane == 0) {
+        red[wave] = s1;
+        red[4 + wave] = s2;
+    }
+    __syncthreads();
+    const float inv = 1.0f / (float)HW;
+    const float m1 = ((red[0] + red[1]) + (red[2] + red[3])) * inv;
+    const float m2 = ((red[4] + red[5]) + (red[6] + red[7])) * inv;
+    float gs = 0.0f;
+    float* op = reinterpret_cast<float*>(p.dc) + pl * HW;
+#pragma unroll
+    for (int k = 0; k < KQ; ++k) {
+        const int it = threadIdx.x + 256 * k;
+        const int r = (int)__umulhi((unsigned)it, mwq), c = (it - r * wq) * 4;
+        float o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool ok = it < nitems && c + j < p.W;
+            o[j] = ok ? rstd * (dn[k][j] - m1 - xh[k][j] * m2) : 0.0f;
+            gs += o[j];
+        }
+        if (it < nitems && c + 3 < p.W) {
+            *reinterpret_cast<cb_f4u*>(op + r * p.W + c) = cb_f4{o[0], o[1], o[2], o[3]};
+        } else if (it < nitems) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (c + j < p.W) op[r * p.W + c + j] = o[j];
+        }
+    }
+    if (p.gsum) {
+        gs = wave_sum_all(gs);
+        if (lane == 0) red[8 + wave] = gs;
+        __syncthreads();
+        if (threadIdx.x == 0) p.gsum[pl] = (red[8] + red[9]) + (red[10] + red[11]);
     }
 }
 
@@ -1448,29 +1647,40 @@ int mdnvae_cb_norm_fwd(const void* y, int y16, float* stats, int compute_stats, 
     a.scale = scale;
     dim3 grid(C / 8, B);
     hipStream_t st = (hipStream_t)stream;
-    const size_t lds = (size_t)64 * 4 + 8 * (size_t)Qy * (y16 ? 2 : 4);
     if (compute_stats) {
-        MV_REQUIRE(Qy % (y16 ? 8 : 4) == 0 && lds <= 160 * 1024, E_SHAPE,
+        const int NQ = (H * pitch_y + 3) / 4;
+        const bool streams = skip || stream_out;
+        const size_t lds = (size_t)64 * 4 + 8 * (size_t)Qy * (y16 ? 2 : 4) + (act ? (size_t)parts * NQ * 64 : 0) +
+                           (streams ? (size_t)32 * H * W : 0);
+        MV_REQUIRE(Qy % (y16 ? 8 : 4) == 0 && Qy >= (long)H * pitch_y && pitch_y >= 4 && lds <= 160 * 1024 && NQ <= 512, E_SHAPE,
                    "mdnvae_cb_norm_fwd: statistics in the pass need planes of a multiple of %d positions that fit the LDS (got %ld)",
                    y16 ? 8 : 4, Qy);
-#define MV_FWD(P_, M_, T_)                                                                                                    \
+#define MV_FWD(P_, M_, S_, T_, NT_, KQ_)                                                                                      \
     do {                                                                                                                      \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cb_norm_fwd_lds_kernel<P_, M_, T_>),                          \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cb_norm_fwd_q_kernel<P_, M_, S_, T_, NT_, KQ_>),              \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                                    \
-        hipLaunchKernelGGL((cb_norm_fwd_lds_kernel<P_, M_, T_>), grid, dim3(256), lds, st, a, stats);                         \
+        hipLaunchKernelGGL((cb_norm_fwd_q_kernel<P_, M_, S_, T_, NT_, KQ_>), grid, dim3(NT_), lds, st, a, stats);             \
     } while (0)
-#define MV_FWD_T(P_, M_)                       \
-    do {                                       \
-        if (y16) MV_FWD(P_, M_, _Float16);     \
-        else MV_FWD(P_, M_, float);            \
+#define MV_FWD_S(P_, M_, S_, T_)                          \
+    do {                                                  \
+        if (NQ <= 160) MV_FWD(P_, M_, S_, T_, 256, 5);    \
+        else MV_FWD(P_, M_, S_, T_, 512, 8);              \
     } while (0)
-        if (parts == 1 && mode == 0) MV_FWD_T(1, 0);
-        else if (parts == 1) MV_FWD_T(1, 1);
-        else if (mode == 0) MV_FWD_T(2, 0);
-        else MV_FWD_T(2, 1);
+#define MV_FWD_T(P_, M_, S_)                       \
+    do {                                           \
+        if (y16) MV_FWD_S(P_, M_, S_, _Float16);   \
+        else MV_FWD_S(P_, M_, S_, float);          \
+    } while (0)
+        if (parts == 1 && mode == 0 && streams) MV_FWD_T(1, 0, true);
+        else if (parts == 1 && mode == 0) MV_FWD_T(1, 0, false);
+        else if (parts == 1) MV_FWD_T(1, 1, false);
+        else if (mode == 0 && streams) MV_FWD_T(2, 0, true);
+        else if (mode == 0) MV_FWD_T(2, 0, false);
+        else MV_FWD_T(2, 1, false);
 #undef MV_FWD_T
+#undef MV_FWD_S
 #undef MV_FWD
-        MV_LAUNCH_CHECK("cb_norm_fwd_lds_kernel");
+        MV_LAUNCH_CHECK("cb_norm_fwd_q_kernel");
         return 0;
     }
     if (parts == 1) hipLaunchKernelGGL(cb_norm_fwd_kernel<1>, grid, dim3(256), 0, st, a);
@@ -1504,6 +1714,13 @@ int mdnvae_cb_norm_bwd(const float* g, int gmode, int pitch_g, long Qg, const fl
     if (omode == 2) {
         MV_REQUIRE(!y16, E_ARG, "mdnvae_cb_norm_bwd: fp32 planes out take fp32 planes in");
         MV_REQUIRE(H * W <= 32 * 256, E_SHAPE, "mdnvae_cb_norm_bwd: plane of %d entries exceeds %d", H * W, 32 * 256);
+        const int items = H * ((W + 3) / 4);
+        if (gmode == 2 && !base && !sum_out && items <= 8 * 256 && pitch_g >= (W + 1) / 2 + 1 && Qg >= (long)((H + 1) / 2) * pitch_g) {
+            if (items <= 5 * 256) hipLaunchKernelGGL(cb_norm_bwd_plane_kernel<5>, dim3(C, B), dim3(256), 0, st, a);
+            else hipLaunchKernelGGL(cb_norm_bwd_plane_kernel<8>, dim3(C, B), dim3(256), 0, st, a);
+            MV_LAUNCH_CHECK("cb_norm_bwd_plane_kernel");
+            return 0;
+        }
         hipLaunchKernelGGL((cb_norm_bwd_kernel<1, 1, 32>), dim3(C, B), dim3(256), 0, st, a);
         MV_LAUNCH_CHECK("cb_norm_bwd_kernel");
         return 0;
@@ -1514,26 +1731,32 @@ int mdnvae_cb_norm_bwd(const float* g, int gmode, int pitch_g, long Qg, const fl
     MV_REQUIRE(PP <= 9 * 256, E_SHAPE, "mdnvae_cb_norm_bwd: %d positions per plane exceed %d", PP, 9 * 256);
     dim3 grid(C / 8, B);
     // planes staged in LDS when they fit and their runs of 8 planes are 16-byte aligned
-    const size_t gfl = gmode == 3 ? 0 : (gmode == 2 ? (size_t)32 * Qg : (size_t)8 * Qg + 4);
-    const size_t lds = (size_t)64 * 4 + 8 * (size_t)Qy * (y16 ? 2 : 4) + gfl * 4;
-    const bool aligned = Qy % (y16 ? 8 : 4) == 0 && (gmode == 3 || gmode == 0 || Qg % 4 == 0);
-    if (aligned && lds <= 160 * 1024 && PP <= 2048 && (!sum_out || base) && gmode != 3 && !(parts == 2 && y16)) {
-#define MV_BWD(P_, G_, O_, B_, NT_, NP_, T_)                                                                                  \
+    const int NQ = (H * pitch_y + 3) / 4;
+    const size_t gfl = gmode == 3 ? 0 : (gmode == 2 ? (size_t)32 * Qg : (size_t)8 * Qg);
+    const size_t img = (size_t)parts * NQ * 64;
+    a.lds_gfloats = (int)((gfl * 4 > img ? gfl * 4 : img) / 4);
+    const size_t lds = (size_t)64 * 4 + 8 * (size_t)Qy * (y16 ? 2 : 4) + (size_t)a.lds_gfloats * 4 + (base ? (size_t)32 * H * W : 0);
+    const bool aligned = Qy % (y16 ? 8 : 4) == 0 && Qy >= (long)H * pitch_y && pitch_y >= 4;      // (runs of 8 planes of g: 32 Qg bytes)
+    const bool covered = gmode == 0 ? Qg >= (long)H * pitch_g : (gmode == 1 ? Qg >= (long)(H + 2) * pitch_g && pitch_g >= W + 2
+                                                                            : Qg >= (long)((H + 1) / 2) * pitch_g);
+    if (aligned && covered && lds <= 160 * 1024 && NQ <= 512 && H >= 4 && W >= 4 && (!sum_out || base) && gmode != 3 &&
+        !(parts == 2 && y16)) {
+#define MV_BWD(P_, G_, O_, B_, T_, NT_, KQ_)                                                                                  \
     do {                                                                                                                      \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cb_norm_bwd_lds_kernel<P_, G_, O_, B_, NT_, NP_, T_>),        \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cb_norm_bwd_q_kernel<P_, G_, O_, B_, T_, NT_, KQ_>),          \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                                    \
-        hipLaunchKernelGGL((cb_norm_bwd_lds_kernel<P_, G_, O_, B_, NT_, NP_, T_>), grid, dim3(NT_), lds, st, a);              \
+        hipLaunchKernelGGL((cb_norm_bwd_q_kernel<P_, G_, O_, B_, T_, NT_, KQ_>), grid, dim3(NT_), lds, st, a);                \
     } while (0)
-#define MV_BWD_T(G_, O_, B_, NT_, NP_)                          \
+#define MV_BWD_T(G_, O_, B_, NT_, KQ_)                          \
     do {                                                        \
-        if (parts == 2) MV_BWD(2, G_, O_, B_, NT_, NP_, float); \
-        else if (y16) MV_BWD(1, G_, O_, B_, NT_, NP_, _Float16);\
-        else MV_BWD(1, G_, O_, B_, NT_, NP_, float);            \
+        if (parts == 2) MV_BWD(2, G_, O_, B_, float, NT_, KQ_); \
+        else if (y16) MV_BWD(1, G_, O_, B_, _Float16, NT_, KQ_);\
+        else MV_BWD(1, G_, O_, B_, float, NT_, KQ_);            \
     } while (0)
 #define MV_BWD_SZ(G_, O_, B_)                                   \
     do {                                                        \
-        if (PP <= 768) MV_BWD_T(G_, O_, B_, 256, 3);            \
-        else MV_BWD_T(G_, O_, B_, 512, 4);                      \
+        if (NQ <= 160) MV_BWD_T(G_, O_, B_, 256, 5);            \
+        else MV_BWD_T(G_, O_, B_, 512, 8);                      \
     } while (0)
 #define MV_BWD_B(G_, O_)                                        \
     do {                                                        \
@@ -1550,7 +1773,7 @@ int mdnvae_cb_norm_bwd(const float* g, int gmode, int pitch_g, long Qg, const fl
 #undef MV_BWD_SZ
 #undef MV_BWD_T
 #undef MV_BWD
-        MV_LAUNCH_CHECK("cb_norm_bwd_lds_kernel");
+        MV_LAUNCH_CHECK("cb_norm_bwd_q_kernel");
         return 0;
     }
     MV_REQUIRE(!y16, E_SHAPE, "mdnvae_cb_norm_bwd: fp16 planes need the LDS-staged kernel (planes too large or misaligned)");

@@ -243,6 +243,38 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restric
     argmax[i] = bi;
 }
 
+// K * K <= 64: one wave per pooling window, one entry per lane, (value, index) reduced over the wave; among equal
+// values the lowest index wins, as in the serial scan above
+__global__ __launch_bounds__(256) void maxpool_fwd_wave_kernel(const float* __restrict__ x, long nplanes, int H, int W,
+                                                               int K, int PH, int PW, float* __restrict__ feat,
+                                                               int* __restrict__ argmax) {
+    const long n = nplanes * PH * PW;
+    const long i = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const int lane = threadIdx.x & 63;
+    const long plane = i / (PH * PW);
+    const int r = (int)(i - plane * PH * PW);
+    const int py = r / PW, px = r - py * PW;
+    const int dy = lane / K, dx = lane - dy * K;
+    const bool in = lane < K * K;
+    int bi = in ? (py * K + dy) * W + px * K + dx : 0x7fffffff;
+    float best = in ? x[plane * (long)H * W + bi] : -INFINITY;
+    if (!(best == best)) best = -INFINITY;             // a NaN never wins (v > best is false for it above)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o);
+        const int oi = __shfl_xor(bi, o);
+        if (ov > best || (ov == best && oi < bi)) {
+            best = ov;
+            bi = oi;
+        }
+    }
+    if (lane == 0) {
+        feat[i] = best;
+        argmax[i] = bi;
+    }
+}
+
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ gfeat, const int* __restrict__ argmax,
                                                           long nplanes, int H, int W, int K, int PH, int PW,
                                                           float* __restrict__ gx) {
@@ -368,8 +400,12 @@ int mdnvae_maxpool_fwd(const float* x, long nplanes, int H, int W, int K, float*
     MV_REQUIRE(x && feat && argmax, E_ARG, "mdnvae_maxpool_fwd: null pointer");
     const int PH = H / K, PW = W / K;
     const long n = nplanes * PH * PW;
-    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x,
-                       nplanes, H, W, K, PH, PW, feat, argmax);
+    if (K * K <= 64 && (n + 3) / 4 <= 0x7fffffffL)
+        hipLaunchKernelGGL(maxpool_fwd_wave_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x,
+                           nplanes, H, W, K, PH, PW, feat, argmax);
+    else
+        hipLaunchKernelGGL(maxpool_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x,
+                           nplanes, H, W, K, PH, PW, feat, argmax);
     MV_LAUNCH_CHECK("maxpool_fwd_kernel");
     return 0;
 }
