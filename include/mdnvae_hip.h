@@ -593,6 +593,15 @@ int mdnvae_fid_finalize(const double* gram, const double* sum, const float* shif
  * out2 = {trace(a), ||a||_F^2} (above 256 rows summed with float64 atomics: the last bits depend on the
  * order of arrival). */
 int mdnvae_ns_residual(const double* zy, int d, double* t, void* stream);
+/* The iteration's products on the float64 matrix instruction (in place of the torch.matmul / scipy sqrtm products
+ * of function/VAE_CNN_NN.py:310-316): c = a b for d x d float64 matrices with b symmetric (read along its rows), d a
+ * multiple of 16.  upper = 1, for a product that is symmetric by its structure (a b = x s x with s symmetric, say):
+ * tiles on or above the diagonal are computed only and every value is written to (i, j) and (j, i) -- half the
+ * work, and a result symmetric to the bit.  (Not for products that are symmetric only because the factors commute:
+ * rounding breaks the commutation, and the mirrored copy keeps the commutator where an average would cancel it.)
+ * epilogue 1: c = 1.5 I - 0.5 a b.  c_transposed (upper = 0; may be NULL): the transpose of c, written as well. */
+int mdnvae_dgemm_sym(const double* a, const double* b, int d, int upper, int epilogue, double* c, double* c_transposed,
+                     void* stream);
 int mdnvae_symmetrize(const double* a, int d, double scale, double* out, void* stream);
 int mdnvae_trace_norm(const double* a, int d, double* out2, void* stream);
 /* out[0] = max_i sum_j |a_ij|: with the Frobenius norm, the two bounds of the largest eigenvalue the

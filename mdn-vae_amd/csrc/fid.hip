@@ -371,6 +371,135 @@ __global__ __launch_bounds__(256) void widen_unpad_kernel(const float* __restric
     out[idx] = (double)a[(long)i * ld + j];
 }
 
+
+// ---- float64 products of the Newton-Schulz iteration on the matrix cores -----------------------
+// C = A B for d x d matrices of which B is symmetric: C[i][j] = sum_k A[i][k] B[j][k], both operands read along their
+// rows.  v_mfma_f64_16x16x4_f64; 128 x 128 tile per workgroup (4 waves of 64 x 64), k steps of 16 staged through two LDS
+// buffers (row pitch 17 doubles: the 32 lanes a ds_read_b64 serves together fall on 64 different banks), the next
+// step's global loads in flight under the current step's 64 MFMAs per wave.
+// UPPER: the product itself is symmetric (all three matrices are polynomials of one matrix): only tiles on or above
+// the diagonal are computed, and every value is written to both (i, j) and (j, i) -- half the work, and a result that
+// is symmetric to the bit.  EPI 1: C = 1.5 I - 0.5 A B (the iteration's residual step).  CT (general form): the
+// transpose of the result is written there as well.
+typedef double f64x4_t __attribute__((ext_vector_type(4)));
+typedef double f64x2_t __attribute__((ext_vector_type(2)));
+constexpr int DG_T = 128, DG_K = 16, DG_LD = 17;
+
+template <bool UPPER, int EPI>
+__global__ __launch_bounds__(512) void dgemm_nt_kernel(const double* __restrict__ A, const double* __restrict__ B,
+                                                       double* __restrict__ C, double* __restrict__ CT, int d, int nt) {
+    __shared__ double sm[2][2][DG_T * DG_LD];          // [buffer][A, B][row][k]
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 2, wn = wave & 3;           // 2 x 4 waves of 64 x 32: two waves per SIMD, which a lone
+                                                       // workgroup needs to keep the matrix pipe busy
+    const int l16 = lane & 15, lq = lane >> 4;
+    int ti, tj;
+    if (UPPER) {
+        int id = blockIdx.x;
+        ti = 0;
+        while (id >= nt - ti) { id -= nt - ti; ++ti; }
+        tj = ti + id;
+    } else {
+        ti = blockIdx.x / nt;
+        tj = blockIdx.x - ti * nt;
+    }
+    // this thread's piece of a k step: 4 doubles of row (t >> 2) of both tiles (zeros beyond the matrix)
+    const int lrow = t >> 2, lk = (t & 3) * 4;
+    const long arow = (long)ti * DG_T + lrow, brow = (long)tj * DG_T + lrow;
+    const bool aok = arow < d, bok = brow < d;
+    const double* ap = A + (aok ? arow : 0) * d + lk;
+    const double* bp = B + (bok ? brow : 0) * d + lk;
+    f64x2_t ra[2], rb[2];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            ra[i] = *reinterpret_cast<const f64x2_t*>(ap + k0 + 2 * i);
+            rb[i] = *reinterpret_cast<const f64x2_t*>(bp + k0 + 2 * i);
+        }
+    };
+    auto lstore = [&](int buf) {
+        double* as = &sm[buf][0][lrow * DG_LD + lk];
+        double* bs = &sm[buf][1][lrow * DG_LD + lk];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            as[2 * i] = aok ? ra[i][0] : 0.0;
+            as[2 * i + 1] = aok ? ra[i][1] : 0.0;
+            bs[2 * i] = bok ? rb[i][0] : 0.0;
+            bs[2 * i + 1] = bok ? rb[i][1] : 0.0;
+        }
+    };
+    f64x4_t acc[4][2];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) acc[m][n] = f64x4_t{0.0, 0.0, 0.0, 0.0};
+    const int nk = d / DG_K;
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int ks = 0; ks < nk; ++ks) {
+        const int buf = ks & 1;
+        if (ks + 1 < nk) gload((ks + 1) * DG_K);
+        const double* as = &sm[buf][0][(wm * 64 + l16) * DG_LD + lq];
+        const double* bs = &sm[buf][1][(wn * 32 + l16) * DG_LD + lq];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            double a[4], b[2];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) a[m] = as[m * 16 * DG_LD + kk * 4];
+#pragma unroll
+            for (int n = 0; n < 2; ++n) b[n] = bs[n * 16 * DG_LD + kk * 4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n) acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m], b[n], acc[m][n], 0, 0, 0);
+        }
+        if (ks + 1 < nk) lstore(buf ^ 1);
+        __syncthreads();
+    }
+    // register r of lane l of a 16 x 16 result holds row 4 r + l / 16, column l % 16
+    const bool diag = UPPER && ti == tj;
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const long row = (long)ti * DG_T + wm * 64 + m * 16 + 4 * r + lq;
+                const long col = (long)tj * DG_T + wn * 32 + n * 16 + l16;
+                double v = acc[m][n][r];
+                if (EPI == 1) v = (row == col ? 1.5 : 0.0) - 0.5 * v;
+                if (row < d && col < d && (!diag || row <= col)) {
+                    C[row * d + col] = v;
+                    if (diag && row != col) C[col * d + row] = v;
+                }
+                acc[m][n][r] = v;
+            }
+    double* mirror = UPPER ? (diag ? nullptr : C) : CT;
+    if (mirror) {
+        // the mirror image: 16 x 32 pieces go through LDS so that it, too, leaves in 128-byte row pieces
+        double* tr = &sm[0][0][0] + wave * (32 * DG_LD);                 // [32 columns][16 rows (+1)]
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) tr[(n * 16 + l16) * DG_LD + 4 * r + lq] = acc[m][n][r];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const long row0 = (long)ti * DG_T + wm * 64 + m * 16;       // rows of the tile = columns of the mirror image
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int c = i * 4 + lq;                               // column of the tile = row of the mirror image
+                const long col = (long)tj * DG_T + wn * 32 + c;
+                if (col < d && row0 + l16 < d) mirror[col * d + row0 + l16] = tr[c * DG_LD + l16];
+            }
+        }
+    }
+}
+
 }  // namespace mdnvae
 using namespace mdnvae;
 
@@ -504,6 +633,30 @@ int mdnvae_ns_residual_gap(const double* w, int d, double* t, double* gap, void*
     const unsigned tiles = (unsigned)((d + 31) / 32);
     hipLaunchKernelGGL(ns_residual_gap_kernel, dim3(tiles, tiles), dim3(256), 0, st, w, d, t, gap);
     MV_LAUNCH_CHECK("ns_residual_gap_kernel");
+    return 0;
+}
+
+int mdnvae_dgemm_sym(const double* a, const double* b, int d, int upper, int epilogue, double* c, double* c_transposed,
+                     void* stream) {
+    MV_REQUIRE(d >= 0 && d % 16 == 0, E_SHAPE, "mdnvae_dgemm_sym: d = %d is not a multiple of 16", d);
+    MV_REQUIRE(epilogue == 0 || epilogue == 1, E_ARG, "mdnvae_dgemm_sym: epilogue %d", epilogue);
+    if (d == 0) return 0;
+    MV_REQUIRE(a && b && c, E_ARG, "mdnvae_dgemm_sym: null pointer");
+    MV_REQUIRE(c != a && c != b && c_transposed != a && c_transposed != b && c_transposed != c, E_ARG,
+               "mdnvae_dgemm_sym: the results may not overwrite an operand or each other");
+    MV_REQUIRE(!upper || !c_transposed, E_ARG, "mdnvae_dgemm_sym: a symmetric result is its own transpose");
+    const int nt = (d + DG_T - 1) / DG_T;
+    hipStream_t st = (hipStream_t)stream;
+    if (upper) {
+        dim3 grid((unsigned)(nt * (nt + 1) / 2));
+        if (epilogue) hipLaunchKernelGGL((dgemm_nt_kernel<true, 1>), grid, dim3(512), 0, st, a, b, c, c_transposed, d, nt);
+        else hipLaunchKernelGGL((dgemm_nt_kernel<true, 0>), grid, dim3(512), 0, st, a, b, c, c_transposed, d, nt);
+    } else {
+        dim3 grid((unsigned)(nt * nt));
+        if (epilogue) hipLaunchKernelGGL((dgemm_nt_kernel<false, 1>), grid, dim3(512), 0, st, a, b, c, c_transposed, d, nt);
+        else hipLaunchKernelGGL((dgemm_nt_kernel<false, 0>), grid, dim3(512), 0, st, a, b, c, c_transposed, d, nt);
+    }
+    MV_LAUNCH_CHECK("dgemm_nt_kernel");
     return 0;
 }
 

@@ -70,6 +70,35 @@ def test_sqrtm_psd_properties(M):
     assert abs(M.calculate_fid(mu, a, mu, a)) < 1e-6 * float(torch.trace(a))
 
 
+@pytest.mark.parametrize("d", [16, 272, 1040])
+def test_float64_matrix_core_products(M, d):
+    """mdnvae_dgemm_sym against torch's float64 matmul: the general form (b symmetric), the symmetric form on a pair
+    of commuting matrices (upper tiles only: the result is symmetric to the bit and agrees with the full product to
+    rounding), and the residual epilogue 1.5 I - 0.5 a b.  Sizes: one tile, ragged tiles, several k steps."""
+    from mdnvae_amd import fid
+    g = torch.Generator(device="cuda").manual_seed(d)
+    q = torch.randn(d, d, dtype=torch.float64, device="cuda", generator=g)
+    b = (q + q.T) / (2 * d ** 0.5)
+    a = torch.randn(d, d, dtype=torch.float64, device="cuda", generator=g)
+    got_t = torch.full_like(a, float("nan"))
+    got = fid._dgemm(a, b, torch.full_like(a, float("nan")), False, 0, got_t)
+    want = a @ b
+    assert float((got - want).abs().max()) <= 1e-13 * float(want.abs().max()) * d ** 0.5
+    assert torch.equal(got_t, got.T)
+    p2 = b @ b + 0.3 * b                                   # p2 b is symmetric
+    p2 = (p2 + p2.T) / 2
+    want = p2 @ b
+    got = fid._dgemm(p2, b, torch.full_like(a, float("nan")), True)
+    assert torch.equal(got, got.T)
+    assert float((got - want).abs().max()) <= 1e-13 * float(want.abs().max()) * d ** 0.5
+    got = fid._dgemm(p2, b, torch.full_like(a, float("nan")), True, 1)
+    want = 1.5 * torch.eye(d, dtype=torch.float64, device="cuda") - 0.5 * want
+    assert torch.equal(got, got.T)
+    assert float((got - want).abs().max()) <= 1e-13 * float(want.abs().max()) * d ** 0.5
+    with pytest.raises(RuntimeError):
+        fid._dgemm(a[:10, :10].contiguous(), b[:10, :10].contiguous(), torch.empty(10, 10, dtype=torch.float64, device="cuda"), False)
+
+
 def _psd(d, floor, rng):
     if floor > 0:
         q, _ = np.linalg.qr(rng.standard_normal((d, d)))

@@ -1,19 +1,29 @@
-"""Library float64 GEMM rate at the Newton-Schulz size (what bounds fid_from_stats at large d)."""
-import sys, torch
+"""Time the float64 matrix-core product against the library's at the validation size."""
+import sys, os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import mdnvae_amd as M
+from mdnvae_amd import fid
 d = int(sys.argv[1]) if len(sys.argv) > 1 else 4624
-a = torch.randn(d, d, device="cuda", dtype=torch.float64); b = torch.randn(d, d, device="cuda", dtype=torch.float64)
-for _ in range(2): torch.mm(a, b)
-torch.cuda.synchronize()
-e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-e0.record()
-for _ in range(5): torch.mm(a, b)
-e1.record(); torch.cuda.synchronize()
-ms = e0.elapsed_time(e1) / 5
-print(f"dgemm d={d}: {ms:.2f} ms  {2.0 * d ** 3 / ms / 1e9:.1f} TFLOP/s")
-a32, b32 = a.float(), b.float()
-for _ in range(2): torch.mm(a32, b32)
-e0.record()
-for _ in range(5): torch.mm(a32, b32)
-e1.record(); torch.cuda.synchronize()
-ms = e0.elapsed_time(e1) / 5
-print(f"sgemm d={d}: {ms:.2f} ms  {2.0 * d ** 3 / ms / 1e9:.1f} TFLOP/s")
+g = torch.Generator(device="cuda").manual_seed(1)
+q = torch.randn(d, d, dtype=torch.float64, device="cuda", generator=g)
+b = (q + q.T) / (2 * d ** 0.5)
+a = b @ b
+out = torch.empty_like(a)
+
+
+def timed(fn, n=5):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
+fl = 2.0 * d ** 3
+t = timed(lambda: torch.matmul(a, b, out=out)); print(f"library dgemm      {t:7.2f} ms  {fl/t/1e9:6.1f} TFLOP/s")
+t = timed(lambda: fid._dgemm(a, b, out, False)); print(f"own, all tiles     {t:7.2f} ms  {fl/t/1e9:6.1f} TFLOP/s")
+t = timed(lambda: fid._dgemm(a, b, out, True)); print(f"own, upper tiles   {t:7.2f} ms  {fl/t/1e9:6.1f} TFLOP/s of the full product's flops")
