@@ -303,9 +303,9 @@ ABI_TAGS.update({
                                                           + (4 * a[10] * a[11] if a[5] is not None else 0)
                                                           + (2 * a[17] * a[16] * (4 if a[15] == 1 else 1) if a[6] is not None else 0))),
     # (g, gmode, pitch_g, Qg, base, sum_out, y, y16, stats, pitch_y, Qy, relu, B, C, H, W, omode, dc, part_stride, PP, parts,
-    #  scale, gsum, absmax_dc, absmax_probe, ...); a probe run reads its inputs and writes a record only
+    #  scale, gsum, absmax_dc, absmax_probe, g16, ...); a probe run reads its inputs and writes a record only
     "mdnvae_cb_norm_bwd": (lambda a: "cb_norm_bwd_kernel" if a[24] is None else "cb_norm_bwd_kernel<probe of the largest entry>",
-                           lambda a: 1.0 * a[12] * a[13] * ((4 * a[3] * (4 if a[1] == 2 else 1) if a[0] is not None else 0)
+                           lambda a: 1.0 * a[12] * a[13] * (((2 if a[25] else 4) * a[3] * (4 if a[1] == 2 else 1) if a[0] is not None else 0)
                                                             + (4 * a[14] * a[15] if a[4] is not None else 0)
                                                             + (0 if a[24] is not None else 4 * a[14] * a[15] if a[5] is not None else 0)
                                                             + a[10] * (2 if a[7] else 4)

@@ -429,7 +429,8 @@ int mdnvae_maxpool_bwd(const float* grad_feat, const int* argmax, long nplanes, 
  * Qr = rows * pitch rounded up to 8, over the pitched grid of their input (columns past the plane's
  * width are scratch): fp32, or (out16 = 1, forward kinds) fp16 clamped to the finite range - a raw
  * convolution output is normalised and rounded to bf16 by the next pass, which 11 significant bits
- * do not disturb, and a workgroup's write-out is bound by bytes per CU.
+ * do not disturb, and a workgroup's write-out is bound by bytes per CU; or (out16 = 2, data-gradient kinds,
+ * parts = 1) bf16: the pass that reads a data gradient of the bf16 mode rounds its own result to bf16.
  *
  * kind of product: 0 forward of a stride-1 reflection-pad-1 layer (input: reflected border, pitch W + 2;
  *   rows = H);  1 forward of a stride-2 pad-1 layer (input: four parity planes with a zero block row /
@@ -483,10 +484,10 @@ int mdnvae_cb_norm_fwd(const void* y, int y16, float* stats, int compute_stats, 
  * run the pass once with absmax_probe (a cleared record; nothing else is written) and again with that record as
  * absmax_dc; the same record goes to the products that read dc.  (The exact maximum keeps all 22 bits of the two
  * parts; a bound from the inputs' magnitudes would give away one bit per factor of two it is loose by.) */
-int mdnvae_cb_norm_bwd(const float* g, int gmode, int pitch_g, long Qg, const float* base, float* sum_out,
+int mdnvae_cb_norm_bwd(const void* g, int gmode, int pitch_g, long Qg, const float* base, float* sum_out,
                        const void* y, int y16, const float* stats, int pitch_y, long Qy, int relu, int B, int C, int H,
                        int W, int omode, void* dc, long part_stride, int PP, int parts, float scale, float* gsum,
-                       const unsigned* absmax_dc, unsigned* absmax_probe, void* stream);
+                       const unsigned* absmax_dc, unsigned* absmax_probe, int g16, void* stream);
 /* dW [Cout][Cin][3][3] from the channel-blocked output gradient g (as mdnvae_cb_norm_bwd leaves it) and the
  * layer's channel-blocked input.  planes = 1: stride-1 reflection layer (g: omode 0, act: mode 0, same
  * pitch); planes = 4: stride-2 layer (g: omode 1, act: mode 1).  [kbeg, kend): the positions of g that

@@ -103,7 +103,7 @@ __device__ __forceinline__ void cb_wait_vm() {
 // requested before this tile's epilogue, and the epilogue's stores drain to memory under the next tile's MFMAs
 // (with one workgroup per CU and a grid of tiles, the matrix cores sat idle for the whole write-out: 28 % of the
 // kernel).  The epilogue then has an LDS region of its own behind the stage buffers.
-template <int PARTS, int NGP, int NJ, int WGM, int WGN, int WM, int WN, int TPS, int SPC, bool PERSIST, int NSW = 8, int NSB = 2, bool OUT16 = false>
+template <int PARTS, int NGP, int NJ, int WGM, int WGN, int WM, int WN, int TPS, int SPC, bool PERSIST, int NSW = 8, int NSB = 2, int OUT16 = 0>
 __global__ __launch_bounds__(512) void cb_conv_kernel(CbConv p, int nblk, int ntiles) {
     static_assert(WGM * WGN == 8 && WGM * WM * 32 == CB_ROWS, "eight waves cover 256 rows");
     constexpr int NT = WGN * WN;                              // 32-channel tiles per workgroup
@@ -379,7 +379,17 @@ __global__ __launch_bounds__(512) void cb_conv_kernel(CbConv p, int nblk, int nt
                         const long at = ((long)(Tc.s0 + sg) * p.ntot + ch) * p.Qr + q;
                         const bool live = ch < p.ntot && row_ok;
                         const cb_f4 v = *reinterpret_cast<const cb_f4*>(ep + chl * ROWP + rp);
-                        if constexpr (OUT16) {
+                        if constexpr (OUT16 == 2) {
+                            // bf16 output (data gradients of the bf16 mode: what reads them rounds its own result to bf16)
+                            const cb_f4 v2 = *reinterpret_cast<const cb_f4*>(ep + chl * ROWP + rp + 4);
+                            cb_bf8 o;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                o[e] = (__bf16)v[e];
+                                o[4 + e] = (__bf16)v2[e];
+                            }
+                            if (live) *reinterpret_cast<cb_bf8*>(reinterpret_cast<__bf16*>(p.out) + at) = o;
+                        } else if constexpr (OUT16 == 1) {
                             // fp16 output: 11 significant bits, clamped to the finite range
                             const cb_f4 v2 = *reinterpret_cast<const cb_f4*>(ep + chl * ROWP + rp + 4);
                             cb_h8 o;
@@ -553,12 +563,14 @@ __global__ __launch_bounds__(256) void cb_norm_fwd_kernel(CbNormFwd p) {
     }
     const unsigned mop = (unsigned)(0x100000000ull / (unsigned)p.opitch) + 1u;
     const int nplanes = p.mode == 1 ? 4 : 1;
-    for (int plane = 0; plane < nplanes; ++plane) {
-        // group-plane index: [chunk][plane][k half]
-        const long gp = p.mode == 1 ? (long)(g8 >> 1) * 8 + plane * 2 + (g8 & 1) : g8;
-        char* dst = p.act + ((gp * p.B + b) * p.PP) * 16;
-        for (int pos = threadIdx.x; pos < p.PP; pos += 256) {
-            const int pr = (int)__umulhi((unsigned)pos, mop), pc = pos - pr * p.opitch;
+    // the four parity planes of a position take the four pixels of one 2 x 2 block: they are written from one visit
+    // of the position, so that every line of y is fetched once (a loop over planes outside fetched it four times)
+    for (int pos = threadIdx.x; pos < p.PP; pos += 256) {
+        const int pr = (int)__umulhi((unsigned)pos, mop), pc = pos - pr * p.opitch;
+        for (int plane = 0; plane < nplanes; ++plane) {
+            // group-plane index: [chunk][plane][k half]
+            const long gp = p.mode == 1 ? (long)(g8 >> 1) * 8 + plane * 2 + (g8 & 1) : g8;
+            char* dst = p.act + ((gp * p.B + b) * p.PP) * 16;
             int r, c;
             bool ok, interior = false;
             if (p.mode == 0) {
@@ -597,7 +609,8 @@ __global__ __launch_bounds__(256) void cb_norm_fwd_kernel(CbNormFwd p) {
 }
 
 struct CbNormBwd {
-    const float* g;          // gradient w.r.t. this layer's activation, as the consumer's data gradient left it
+    const void* g;           // gradient w.r.t. this layer's activation, as the consumer's data gradient left it (fp32; bf16 for
+                             // the kernels templated on its type)
     int gmode;               // 0: planes on this layer's grid, pitch_g;  1: reflection-padded grid (H+2) x (W+2) to fold, pitch_g;
                              // 2: four parity planes [B][4 C][Qg] of a stride-2 consumer, pitch_g;  3: none (base only)
     int pitch_g; long Qg;
@@ -676,10 +689,10 @@ __global__ __launch_bounds__(256) void cb_norm_bwd_kernel(CbNormBwd p) {
             for (int e = 0; e < CH; ++e) {
                 const long pl = (long)b * p.C + cg * CH + e;
                 float gv = 0.0f;
-                if (p.gmode == 0) gv = p.g[pl * p.Qg + r * p.pitch_g + c];
-                else if (p.gmode == 1) gv = cb_fold_gather(p.g + pl * p.Qg, r, c, p.H, p.W, p.pitch_g);
+                if (p.gmode == 0) gv = static_cast<const float*>(p.g)[pl * p.Qg + r * p.pitch_g + c];
+                else if (p.gmode == 1) gv = cb_fold_gather(static_cast<const float*>(p.g) + pl * p.Qg, r, c, p.H, p.W, p.pitch_g);
                 else if (p.gmode == 2)
-                    gv = p.g[((long)b * 4 * p.C + ((r & 1) * 2 + (c & 1)) * p.C + cg * CH + e) * p.Qg + (r >> 1) * p.pitch_g + (c >> 1)];
+                    gv = static_cast<const float*>(p.g)[((long)b * 4 * p.C + ((r & 1) * 2 + (c & 1)) * p.C + cg * CH + e) * p.Qg + (r >> 1) * p.pitch_g + (c >> 1)];
                 if (p.base) gv += p.base[pl * HW + r * p.W + c];
                 if (p.sum_out && !p.amax_probe) p.sum_out[pl * HW + r * p.W + c] = gv;
                 const float x = (static_cast<const float*>(p.y)[pl * p.Qy + r * p.pitch_y + c] - mean[e]) * rstd[e];
@@ -978,13 +991,14 @@ __global__ __launch_bounds__(NT) void cb_norm_fwd_q_kernel(CbNormFwd p, float* _
     }
 }
 
-template <int PARTS, int GMODE, int OMODE, bool BASE, typename YT, int NT, int KQ>
+template <int PARTS, int GMODE, int OMODE, bool BASE, typename YT, typename GT, int NT, int KQ>
 __global__ __launch_bounds__(NT) void cb_norm_bwd_q_kernel(CbNormBwd p) {
     extern __shared__ __attribute__((aligned(16))) float fsm[];
     float* red = fsm;                                   // [64]
     YT* ybuf = reinterpret_cast<YT*>(fsm + 64);         // [8][Qy]
     const int Qy = (int)p.Qy, Qg = (int)p.Qg;
-    float* gbuf = fsm + 64 + 8 * Qy * (int)sizeof(YT) / 4;     // GMODE 0, 1: [8][Qg];  2: [4][8][Qg]
+    float* gfl = fsm + 64 + 8 * Qy * (int)sizeof(YT) / 4;
+    GT* gbuf = reinterpret_cast<GT*>(gfl);              // GMODE 0, 1: [8][Qg];  2: [4][8][Qg]
     char* img = reinterpret_cast<char*>(gbuf);          // the result's image takes the gradient's place once that is consumed
     const int Qv = p.H * p.pitch_y;
     const int NQ = (Qv + 3) >> 2;
@@ -1000,15 +1014,17 @@ __global__ __launch_bounds__(NT) void cb_norm_bwd_q_kernel(CbNormBwd p) {
     if (GMODE == 2) {
 #pragma unroll
         for (int pl = 0; pl < 4; ++pl)
-            cb_dma_floats<NT>(p.g + (((long)b * 4 + pl) * p.C + g8 * 8) * Qg, gbuf + pl * 8 * Qg, 8 * Qg);
+            cb_dma_bytes<NT>(reinterpret_cast<const char*>(static_cast<const GT*>(p.g) + (((long)b * 4 + pl) * p.C + g8 * 8) * Qg),
+                             reinterpret_cast<char*>(gbuf + pl * 8 * Qg), 8 * Qg * (int)sizeof(GT));
     } else {
-        cb_dma_floats<NT>(p.g + pl0 * Qg, gbuf, 8 * Qg);
+        cb_dma_bytes<NT>(reinterpret_cast<const char*>(static_cast<const GT*>(p.g) + pl0 * Qg), reinterpret_cast<char*>(gbuf),
+                         8 * Qg * (int)sizeof(GT));
     }
     const unsigned mpy = (unsigned)(0x100000000ull / (unsigned)p.pitch_y) + 1u;
     const int gap = p.pitch_y - p.W;
     const float mean = p.stats[2 * (pl0 + e)], rstd = p.stats[2 * (pl0 + e) + 1];
     // the residual stream's gradient [8][H * W]: one contiguous run, staged in LDS, updated in place, written back whole
-    float* bbuf = gbuf + p.lds_gfloats;
+    float* bbuf = gfl + p.lds_gfloats;
     if (BASE) cb_dma_floats<NT>(p.base + pl0 * HW, bbuf, 8 * HW);
     float* bbe = bbuf + e * HW;
     const bool sums = BASE && p.sum_out && !p.amax_probe;
@@ -1029,7 +1045,7 @@ __global__ __launch_bounds__(NT) void cb_norm_bwd_q_kernel(CbNormBwd p) {
     __syncthreads();
     float dn[KQ][4], xh[KQ][4];
     float s1 = 0.0f, s2 = 0.0f;
-    const float* ge = gbuf + e * Qg;
+    const GT* ge = gbuf + e * Qg;
     const YT* ype = ybuf + (size_t)e * Qy;
     const float shift = -mean * rstd;
 #pragma unroll
@@ -1044,18 +1060,18 @@ __global__ __launch_bounds__(NT) void cb_norm_bwd_q_kernel(CbNormBwd p) {
             float gv = 0.0f;
             if (cb_bit(okm, k * 4 + j)) {
                 if (GMODE == 0) {
-                    gv = ge[r * p.pitch_g + c];
+                    gv = (float)ge[r * p.pitch_g + c];
                 } else if (GMODE == 1) {
                     // padded position (r + 1, c + 1) plus the mirrored border rows / columns that reflect onto (r, c)
                     const int Wp = p.pitch_g;
                     const int r1 = (r == 1) ? 0 : ((r == p.H - 2) ? p.H + 1 : -1);
                     const int c1 = (c == 1) ? 0 : ((c == p.W - 2) ? p.W + 1 : -1);
-                    gv = ge[(r + 1) * Wp + c + 1];
-                    if (r1 >= 0) gv += ge[r1 * Wp + c + 1];
-                    if (c1 >= 0) gv += ge[(r + 1) * Wp + c1];
-                    if (r1 >= 0 && c1 >= 0) gv += ge[r1 * Wp + c1];
+                    gv = (float)ge[(r + 1) * Wp + c + 1];
+                    if (r1 >= 0) gv += (float)ge[r1 * Wp + c + 1];
+                    if (c1 >= 0) gv += (float)ge[(r + 1) * Wp + c1];
+                    if (r1 >= 0 && c1 >= 0) gv += (float)ge[r1 * Wp + c1];
                 } else {
-                    gv = ge[((r & 1) * 2 + (c & 1)) * 8 * Qg + (r >> 1) * p.pitch_g + (c >> 1)];
+                    gv = (float)ge[((r & 1) * 2 + (c & 1)) * 8 * Qg + (r >> 1) * p.pitch_g + (c >> 1)];
                 }
             }
             dn[k][j] = gv;
@@ -1146,7 +1162,7 @@ __global__ __launch_bounds__(NT) void cb_norm_bwd_q_kernel(CbNormBwd p) {
 // planes out, gradient gathered from the four parity planes of its stride-2 consumer).  One workgroup per plane; a
 // thread owns KQ (row, four columns) items, loads them with 16- and 8-byte accesses that consecutive lanes make
 // contiguous, keeps them in registers through the two plane sums, and stores 16 bytes per item.
-template <int KQ>
+template <int KQ, typename GT>
 __global__ __launch_bounds__(256) void cb_norm_bwd_plane_kernel(CbNormBwd p) {
     __shared__ float red[12];
     const int ch = blockIdx.x, b = blockIdx.y;
@@ -1156,7 +1172,7 @@ __global__ __launch_bounds__(256) void cb_norm_bwd_plane_kernel(CbNormBwd p) {
     const int nitems = p.H * wq;
     const unsigned mwq = (unsigned)(0x100000000ull / (unsigned)wq) + 1u;
     const float* yp = static_cast<const float*>(p.y) + pl * p.Qy;
-    const float* gq = p.g + ((long)b * 4 * p.C + ch) * p.Qg;       // parity plane k: + k * C * Qg
+    const GT* gq = static_cast<const GT*>(p.g) + ((long)b * 4 * p.C + ch) * p.Qg;       // parity plane k: + k * C * Qg
     const long gps = (long)p.C * p.Qg;
     const float mean = p.stats[2 * pl], rstd = p.stats[2 * pl + 1];
     const float shift = -mean * rstd;
@@ -1180,11 +1196,8 @@ __global__ __launch_bounds__(256) void cb_norm_bwd_plane_kernel(CbNormBwd p) {
         }
         if (in) {
             // columns c, c + 2 come from the even-column plane of this row's parity, c + 1, c + 3 from the odd one
-            const float* g0 = gq + ((r & 1) * 2) * gps + (r >> 1) * p.pitch_g + (c >> 1);
-            typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
-            const f2u e2 = *reinterpret_cast<const f2u*>(g0);
-            const f2u o2 = *reinterpret_cast<const f2u*>(g0 + gps);
-            dn[k][0] = e2[0]; dn[k][1] = o2[0]; dn[k][2] = e2[1]; dn[k][3] = o2[1];
+            const GT* g0 = gq + ((r & 1) * 2) * gps + (r >> 1) * p.pitch_g + (c >> 1);
+            dn[k][0] = (float)g0[0]; dn[k][1] = (float)g0[gps]; dn[k][2] = (float)g0[1]; dn[k][3] = (float)g0[gps + 1];
         }
     }
     float s1 = 0.0f, s2 = 0.0f;
@@ -1471,7 +1484,7 @@ static bool cb_shape(int kind, int Cout, int Cin, int parts, CbShape& sh) {
     return false;
 }
 
-template <int PARTS, int NGP, int NJ, int WGM, int WGN, int WM, int WN, int TPS, int SPC, bool PERSIST, int NSW = 8, int NSB = 2, bool OUT16 = false>
+template <int PARTS, int NGP, int NJ, int WGM, int WGN, int WM, int WN, int TPS, int SPC, bool PERSIST, int NSW = 8, int NSB = 2, int OUT16 = 0>
 static int cb_launch_conv(const CbConv& a, int nblk, hipStream_t st) {
     constexpr int NT = WGN * WN;
     constexpr size_t lds_main = (size_t)CB_NBUF * TPS * NT * PARTS * 1024 + (size_t)NSB * PARTS * NGP * NJ * 64 * 16;
@@ -1568,7 +1581,8 @@ int mdnvae_cb_conv(const void* act, long part_stride, const void* packed_w, cons
     a.nchunk = sh.kch / 16;
     a.Qr = cb_round_up(rows * pitch, 8);
     a.ntot = sh.nout;
-    MV_REQUIRE(!out16 || kind <= 1, E_ARG, "mdnvae_cb_conv: fp16 output is for the forward products");
+    MV_REQUIRE(out16 >= 0 && out16 <= 2 && (out16 != 1 || kind <= 1) && (out16 != 2 || kind >= 2), E_ARG,
+               "mdnvae_cb_conv: out16 = %d (1: fp16, the forward products; 2: bf16, the data gradients)", out16);
     a.out_scale = out_scale;
     a.amax_a = absmax_act; a.amax_w = absmax_w;
     const int slabpos = sh.NJ * 64;
@@ -1594,20 +1608,22 @@ int mdnvae_cb_conv(const void* act, long part_stride, const void* packed_w, cons
     const int nblk = (sh.nout + sh.NT * 32 - 1) / (sh.NT * 32);
     hipStream_t st = (hipStream_t)stream;
     if (parts == 2) {
-        if (kind == 0 || kind == 2) return cb_launch_conv<2, 2, 8, 4, 2, 2, 3, 1, 9, true, 8, 2, false>(a, nblk, st);
-        if (kind == 3) return cb_launch_conv<2, 2, 8, 4, 2, 2, 3, 1, 4, true, 8, 2, false>(a, nblk, st);
-        if (sh.NT == 6) return cb_launch_conv<2, 8, 5, 4, 2, 2, 3, 1, 9, false, 8, 1, false>(a, nblk, st);
-        return cb_launch_conv<2, 8, 6, 8, 1, 1, 3, 1, 9, false, 8, 1, false>(a, nblk, st);
+        if (kind == 0 || kind == 2) return cb_launch_conv<2, 2, 8, 4, 2, 2, 3, 1, 9, true, 8, 2, 0>(a, nblk, st);
+        if (kind == 3) return cb_launch_conv<2, 2, 8, 4, 2, 2, 3, 1, 4, true, 8, 2, 0>(a, nblk, st);
+        if (sh.NT == 6) return cb_launch_conv<2, 8, 5, 4, 2, 2, 3, 1, 9, false, 8, 1, 0>(a, nblk, st);
+        return cb_launch_conv<2, 8, 6, 8, 1, 1, 3, 1, 9, false, 8, 1, 0>(a, nblk, st);
     }
-    if (kind == 0 && out16) return cb_launch_conv<1, 2, 8, 4, 2, 2, 3, 3, 3, true, 8, 2, true>(a, nblk, st);
-    if (kind == 0 || kind == 2) return cb_launch_conv<1, 2, 8, 4, 2, 2, 3, 3, 3, true, 8, 2, false>(a, nblk, st);
-    if (kind == 3) return cb_launch_conv<1, 2, 8, 4, 2, 2, 3, 2, 2, true, 8, 2, false>(a, nblk, st);
+    if (kind == 0 && out16) return cb_launch_conv<1, 2, 8, 4, 2, 2, 3, 3, 3, true, 8, 2, 1>(a, nblk, st);
+    if (kind == 2 && out16) return cb_launch_conv<1, 2, 8, 4, 2, 2, 3, 3, 3, true, 8, 2, 2>(a, nblk, st);
+    if (kind == 0 || kind == 2) return cb_launch_conv<1, 2, 8, 4, 2, 2, 3, 3, 3, true, 8, 2, 0>(a, nblk, st);
+    if (kind == 3 && out16) return cb_launch_conv<1, 2, 8, 4, 2, 2, 3, 2, 2, true, 8, 2, 2>(a, nblk, st);
+    if (kind == 3) return cb_launch_conv<1, 2, 8, 4, 2, 2, 3, 2, 2, true, 8, 2, 0>(a, nblk, st);
     if (sh.NT == 6) {
-        if (out16) return cb_launch_conv<1, 8, 5, 4, 2, 2, 3, 3, 3, false, 8, 2, true>(a, nblk, st);
-        return cb_launch_conv<1, 8, 5, 4, 2, 2, 3, 3, 3, false, 8, 2, false>(a, nblk, st);
+        if (out16) return cb_launch_conv<1, 8, 5, 4, 2, 2, 3, 3, 3, false, 8, 2, 1>(a, nblk, st);
+        return cb_launch_conv<1, 8, 5, 4, 2, 2, 3, 3, 3, false, 8, 2, 0>(a, nblk, st);
     }
-    if (out16) return cb_launch_conv<1, 8, 6, 8, 1, 1, 3, 3, 3, false, 8, 2, true>(a, nblk, st);
-    return cb_launch_conv<1, 8, 6, 8, 1, 1, 3, 3, 3, false, 8, 2, false>(a, nblk, st);
+    if (out16) return cb_launch_conv<1, 8, 6, 8, 1, 1, 3, 3, 3, false, 8, 2, 1>(a, nblk, st);
+    return cb_launch_conv<1, 8, 6, 8, 1, 1, 3, 3, 3, false, 8, 2, 0>(a, nblk, st);
 }
 
 int mdnvae_cb_plane_stats(const float* y, long nplanes, int H, int W, int pitch, long plane_stride, float* stats,
@@ -1689,10 +1705,10 @@ int mdnvae_cb_norm_fwd(const void* y, int y16, float* stats, int compute_stats, 
     return 0;
 }
 
-int mdnvae_cb_norm_bwd(const float* g, int gmode, int pitch_g, long Qg, const float* base, float* sum_out, const void* y,
+int mdnvae_cb_norm_bwd(const void* g, int gmode, int pitch_g, long Qg, const float* base, float* sum_out, const void* y,
                        int y16, const float* stats, int pitch_y, long Qy, int relu, int B, int C, int H, int W, int omode,
                        void* dc, long part_stride, int PP, int parts, float scale, float* gsum, const unsigned* absmax_dc,
-                       unsigned* absmax_probe, void* stream) {
+                       unsigned* absmax_probe, int g16, void* stream) {
     MV_REQUIRE(B >= 0 && C >= 1 && H >= 3 && W >= 3, E_SHAPE, "mdnvae_cb_norm_bwd: bad shape");
     if (B == 0) return 0;
     MV_REQUIRE(y && stats && (dc || absmax_probe) && (g || gmode == 3), E_ARG, "mdnvae_cb_norm_bwd: null pointer");
@@ -1700,6 +1716,7 @@ int mdnvae_cb_norm_bwd(const float* g, int gmode, int pitch_g, long Qg, const fl
     MV_REQUIRE(gmode != 3 || base, E_ARG, "mdnvae_cb_norm_bwd: no gradient source");
     MV_REQUIRE(parts == 1 || parts == 2, E_ARG, "mdnvae_cb_norm_bwd: parts = %d", parts);
     MV_REQUIRE(B <= 65535, E_SHAPE, "mdnvae_cb_norm_bwd: batch %d exceeds the grid limit", B);
+    MV_REQUIRE(g16 == 0 || (g16 == 2 && parts == 1), E_ARG, "mdnvae_cb_norm_bwd: g16 = %d (0: fp32; 2: bf16, with bf16 operands out)", g16);
     CbNormBwd a{};
     a.g = g; a.gmode = gmode; a.pitch_g = pitch_g; a.Qg = Qg; a.base = base; a.sum_out = sum_out;
     a.y = y; a.stats = stats; a.pitch_y = pitch_y; a.Qy = Qy; a.relu = relu;
@@ -1716,11 +1733,17 @@ int mdnvae_cb_norm_bwd(const float* g, int gmode, int pitch_g, long Qg, const fl
         MV_REQUIRE(H * W <= 32 * 256, E_SHAPE, "mdnvae_cb_norm_bwd: plane of %d entries exceeds %d", H * W, 32 * 256);
         const int items = H * ((W + 3) / 4);
         if (gmode == 2 && !base && !sum_out && items <= 8 * 256 && pitch_g >= (W + 1) / 2 + 1 && Qg >= (long)((H + 1) / 2) * pitch_g) {
-            if (items <= 5 * 256) hipLaunchKernelGGL(cb_norm_bwd_plane_kernel<5>, dim3(C, B), dim3(256), 0, st, a);
-            else hipLaunchKernelGGL(cb_norm_bwd_plane_kernel<8>, dim3(C, B), dim3(256), 0, st, a);
+            if (g16) {
+                if (items <= 5 * 256) hipLaunchKernelGGL((cb_norm_bwd_plane_kernel<5, __bf16>), dim3(C, B), dim3(256), 0, st, a);
+                else hipLaunchKernelGGL((cb_norm_bwd_plane_kernel<8, __bf16>), dim3(C, B), dim3(256), 0, st, a);
+            } else {
+                if (items <= 5 * 256) hipLaunchKernelGGL((cb_norm_bwd_plane_kernel<5, float>), dim3(C, B), dim3(256), 0, st, a);
+                else hipLaunchKernelGGL((cb_norm_bwd_plane_kernel<8, float>), dim3(C, B), dim3(256), 0, st, a);
+            }
             MV_LAUNCH_CHECK("cb_norm_bwd_plane_kernel");
             return 0;
         }
+        MV_REQUIRE(!g16, E_SHAPE, "mdnvae_cb_norm_bwd: bf16 gradient planes need the plane kernel's shapes");
         hipLaunchKernelGGL((cb_norm_bwd_kernel<1, 1, 32>), dim3(C, B), dim3(256), 0, st, a);
         MV_LAUNCH_CHECK("cb_norm_bwd_kernel");
         return 0;
@@ -1733,25 +1756,27 @@ int mdnvae_cb_norm_bwd(const float* g, int gmode, int pitch_g, long Qg, const fl
     // planes staged in LDS when they fit and their runs of 8 planes are 16-byte aligned
     const int NQ = (H * pitch_y + 3) / 4;
     const size_t gfl = gmode == 3 ? 0 : (gmode == 2 ? (size_t)32 * Qg : (size_t)8 * Qg);
+    const size_t gbytes = (gfl * (g16 ? 2 : 4) + 15) / 16 * 16;
     const size_t img = (size_t)parts * NQ * 64;
-    a.lds_gfloats = (int)((gfl * 4 > img ? gfl * 4 : img) / 4);
+    a.lds_gfloats = (int)((gbytes > img ? gbytes : img) / 4);
     const size_t lds = (size_t)64 * 4 + 8 * (size_t)Qy * (y16 ? 2 : 4) + (size_t)a.lds_gfloats * 4 + (base ? (size_t)32 * H * W : 0);
     const bool aligned = Qy % (y16 ? 8 : 4) == 0 && Qy >= (long)H * pitch_y && pitch_y >= 4;      // (runs of 8 planes of g: 32 Qg bytes)
     const bool covered = gmode == 0 ? Qg >= (long)H * pitch_g : (gmode == 1 ? Qg >= (long)(H + 2) * pitch_g && pitch_g >= W + 2
                                                                             : Qg >= (long)((H + 1) / 2) * pitch_g);
     if (aligned && covered && lds <= 160 * 1024 && NQ <= 512 && H >= 4 && W >= 4 && (!sum_out || base) && gmode != 3 &&
-        !(parts == 2 && y16)) {
-#define MV_BWD(P_, G_, O_, B_, T_, NT_, KQ_)                                                                                  \
+        !(parts == 2 && y16) && (!g16 || y16)) {
+#define MV_BWD(P_, G_, O_, B_, T_, GT_, NT_, KQ_)                                                                             \
     do {                                                                                                                      \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cb_norm_bwd_q_kernel<P_, G_, O_, B_, T_, NT_, KQ_>),          \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cb_norm_bwd_q_kernel<P_, G_, O_, B_, T_, GT_, NT_, KQ_>),     \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                                    \
-        hipLaunchKernelGGL((cb_norm_bwd_q_kernel<P_, G_, O_, B_, T_, NT_, KQ_>), grid, dim3(NT_), lds, st, a);                \
+        hipLaunchKernelGGL((cb_norm_bwd_q_kernel<P_, G_, O_, B_, T_, GT_, NT_, KQ_>), grid, dim3(NT_), lds, st, a);           \
     } while (0)
-#define MV_BWD_T(G_, O_, B_, NT_, KQ_)                          \
-    do {                                                        \
-        if (parts == 2) MV_BWD(2, G_, O_, B_, float, NT_, KQ_); \
-        else if (y16) MV_BWD(1, G_, O_, B_, _Float16, NT_, KQ_);\
-        else MV_BWD(1, G_, O_, B_, float, NT_, KQ_);            \
+#define MV_BWD_T(G_, O_, B_, NT_, KQ_)                                         \
+    do {                                                                       \
+        if (parts == 2) MV_BWD(2, G_, O_, B_, float, float, NT_, KQ_);         \
+        else if (y16 && g16) MV_BWD(1, G_, O_, B_, _Float16, __bf16, NT_, KQ_);\
+        else if (y16) MV_BWD(1, G_, O_, B_, _Float16, float, NT_, KQ_);        \
+        else MV_BWD(1, G_, O_, B_, float, float, NT_, KQ_);                    \
     } while (0)
 #define MV_BWD_SZ(G_, O_, B_)                                   \
     do {                                                        \
@@ -1776,7 +1801,7 @@ int mdnvae_cb_norm_bwd(const float* g, int gmode, int pitch_g, long Qg, const fl
         MV_LAUNCH_CHECK("cb_norm_bwd_q_kernel");
         return 0;
     }
-    MV_REQUIRE(!y16, E_SHAPE, "mdnvae_cb_norm_bwd: fp16 planes need the LDS-staged kernel (planes too large or misaligned)");
+    MV_REQUIRE(!y16 && !g16, E_SHAPE, "mdnvae_cb_norm_bwd: 16-bit planes need the LDS-staged kernel (planes too large or misaligned)");
     if (parts == 1) {
         if (PP <= 3 * 256) hipLaunchKernelGGL((cb_norm_bwd_kernel<1, 8, 3>), grid, dim3(256), 0, st, a);
         else hipLaunchKernelGGL((cb_norm_bwd_kernel<1, 8, 9>), grid, dim3(256), 0, st, a);

@@ -1530,11 +1530,14 @@ def _slot(t):
 
 def _cb_conv(act, part_stride, wp, bias, B, cout, cin, kind, rows, pitch, PP, out16=False, parts=1, out_scale=1.0,
              amax_a=None, amax_w=None):
-    """out16: the planes leave as fp16 (forward kinds of the bf16 mode; what reads them normalises and rounds to bf16
-    anyway).  parts = 2: two fp16 parts per operand; out_scale and the records amax_a / amax_w undo their scales."""
+    """out16: the planes leave as 16-bit values: fp16 from the forward kinds (what reads them normalises and rounds to
+    bf16 anyway), bf16 from the data-gradient kinds (the pass that reads them rounds its result to bf16); bf16 mode only.
+    parts = 2: two fp16 parts per operand; out_scale and the records amax_a / amax_w undo their scales."""
     nout = {0: cout, 1: cout, 2: cin, 3: 4 * cin}[kind]
-    out = torch.empty(B, nout, _ru(rows * pitch, 8), dtype=torch.float16 if out16 else torch.float32, device=act.device)
-    call("mdnvae_cb_conv", act.data_ptr(), part_stride, wp.data_ptr(), ptr(bias, "conv bias"), out.data_ptr(), int(out16), B, cout,
+    code = 0 if not out16 else (1 if kind <= 1 else 2)
+    dt = (torch.float32, torch.float16, torch.bfloat16)[code]
+    out = torch.empty(B, nout, _ru(rows * pitch, 8), dtype=dt, device=act.device)
+    call("mdnvae_cb_conv", act.data_ptr(), part_stride, wp.data_ptr(), ptr(bias, "conv bias"), out.data_ptr(), code, B, cout,
          cin, kind, rows, pitch, PP, parts, float(out_scale), _slot(amax_a), _slot(amax_w), stream())
     return out
 
@@ -1581,12 +1584,14 @@ def _cb_norm_bwd(g, gmode, pitch_g, y, stats, pitch_y, relu, C, H, W, omode, PP,
     gsum = torch.empty(B, C, dtype=torch.float32, device=dev)
     so = torch.empty(B, C, H, W, dtype=torch.float32, device=dev) if want_sum else None
     y16 = y.dtype == torch.float16
+    g16 = 2 if g is not None and g.dtype == torch.bfloat16 else 0
     p_ = 1 if omode == 2 else parts
-    args = (ptr(g), gmode, pitch_g, Qg, ptr(base), ptr(so), ptr(y, "raw conv output", y.dtype), int(y16), ptr(stats), pitch_y, Qy,
+    args = (None if g is None else ptr(g, "gradient planes", g.dtype), gmode, pitch_g, Qg, ptr(base), ptr(so),
+            ptr(y, "raw conv output", y.dtype), int(y16), ptr(stats), pitch_y, Qy,
             int(relu), B, C, H, W, omode, dc.data_ptr(), ps, PP, p_, 1.0, ptr(gsum))
     if p_ == 2:
-        call("mdnvae_cb_norm_bwd", *args, None, amax_dc.data_ptr(), stream())
-    call("mdnvae_cb_norm_bwd", *args, _slot(amax_dc) if p_ == 2 else None, None, stream())
+        call("mdnvae_cb_norm_bwd", *args, None, amax_dc.data_ptr(), g16, stream())
+    call("mdnvae_cb_norm_bwd", *args, _slot(amax_dc) if p_ == 2 else None, None, g16, stream())
     return dc, ps, gsum, so
 
 
@@ -1680,6 +1685,7 @@ class _ConvEncoderCB(torch.autograd.Function):
         n, nres, parts, (s1, s2, sr), (p1, p2, pr) = ctx.geom
         wmax = ctx.wmax                             # wmax[layer - 1] (layer 0 = stem)
         two = parts == 2
+        g16 = not two                               # bf16 mode: data gradients leave their convolutions as bf16 planes
         sv = ctx.saved_tensors
         G = _CBGeom(n)
         x, raw1, st1, a1, y2, st2, a2, y3, st3 = sv[:9]
@@ -1714,13 +1720,13 @@ class _ConvEncoderCB(torch.autograd.Function):
                 dcb, pd, gs, _ = _cb_norm_bwd(Gs, 0, H, yb, sb, G.pr, False, 192, H, H, 0, G.pp_dr, parts=parts, amax_dc=dmax)
                 gb[Lb] = _colsum(gs)
             gw[Lb] = _cb_wgrad(dcb, aa, B, 192, 192, 1, G.pp_dr, G.pp_r, G.k_r, G.pr, parts, 1.0 / sr, pd, pr, dmax)
-            dap = _cb_conv(dcb, pd, wt[Lb - 1], None, B, 192, 192, 2, H + 2, G.pr, G.pp_dr, parts=parts, amax_a=dmax,
+            dap = _cb_conv(dcb, pd, wt[Lb - 1], None, B, 192, 192, 2, H + 2, G.pr, G.pp_dr, out16=g16, parts=parts, amax_a=dmax,
                            amax_w=wmax[Lb - 1])
             dmax = slot()
             dca, pd, gs, _ = _cb_norm_bwd(dap, 1, G.pr, ya, sa, G.pr, True, 192, H, H, 0, G.pp_dr, parts=parts, amax_dc=dmax)
             gb[La] = _colsum(gs)
             gw[La] = _cb_wgrad(dca, xp, B, 192, 192, 1, G.pp_dr, G.pp_r, G.k_r, G.pr, parts, 1.0 / sr, pd, pr, dmax)
-            dxp = _cb_conv(dca, pd, wt[La - 1], None, B, 192, 192, 2, H + 2, G.pr, G.pp_dr, parts=parts, amax_a=dmax,
+            dxp = _cb_conv(dca, pd, wt[La - 1], None, B, 192, 192, 2, H + 2, G.pr, G.pp_dr, out16=g16, parts=parts, amax_a=dmax,
                            amax_w=wmax[La - 1])
             dmax = slot()
             if k > 0:
@@ -1734,12 +1740,12 @@ class _ConvEncoderCB(torch.autograd.Function):
                                               amax_dc=dmax)
                 gb[2] = _colsum(gs)
         gw[2] = _cb_wgrad(dc3, a2, B, 192, 96, 4, G.pp_d3, G.pp_a2, G.k_3, G.p3, parts, 1.0 / s2, pd, p2, dmax)
-        da2 = _cb_conv(dc3, pd, wt[1], None, B, 192, 96, 3, G.h3, G.p3, G.pp_d3, parts=parts, amax_a=dmax, amax_w=wmax[1])
+        da2 = _cb_conv(dc3, pd, wt[1], None, B, 192, 96, 3, G.h3, G.p3, G.pp_d3, out16=g16, parts=parts, amax_a=dmax, amax_w=wmax[1])
         dmax = slot()
         dc2, pd, gs, _ = _cb_norm_bwd(da2, 2, G.p3, y2, st2, G.p2, True, 96, G.h2, G.h2, 1, G.pp_d2, parts=parts, amax_dc=dmax)
         gb[1] = _colsum(gs)
         gw[1] = _cb_wgrad(dc2, a1, B, 96, 48, 4, G.pp_d2, G.pp_a1, G.k_2, G.p2, parts, 1.0 / s1, pd, p1, dmax)
-        da1 = _cb_conv(dc2, pd, wt[0], None, B, 96, 48, 3, G.h2, G.p2, G.pp_d2, parts=parts, amax_a=dmax, amax_w=wmax[0])
+        da1 = _cb_conv(dc2, pd, wt[0], None, B, 96, 48, 3, G.h2, G.p2, G.pp_d2, out16=g16, parts=parts, amax_a=dmax, amax_w=wmax[0])
         g_r1, _, gs, _ = _cb_norm_bwd(da1, 2, G.p2, raw1, st1, n, True, 48, n, n, 2, 0)
         gb[0] = _colsum(gs)
         stem = _ConvLayer(1, 48, 7, 1, 3, True, n)
