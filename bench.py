@@ -323,7 +323,7 @@ def install_clock(clock):
     """Time every conv launch, every tagged C-ABI call and the library GEMMs of the dense layers by
     their own event pairs."""
     L = ops._ConvLayer
-    orig_fwd, orig_dgrad, orig_wgrad = L.fwd, L.dgrad, L.wgrad
+    orig_fwd, orig_dgrad, orig_wgrad, orig_fwd_stats = L.fwd, L.dgrad, L.wgrad, L.fwd_stats
 
     def flops(ly, B):
         return 2.0 * ly.ks * ly.ks * ly.cin * ly.cout * ly.oh * ly.oh * B
@@ -343,7 +343,10 @@ def install_clock(clock):
         tag = "conv_stem_wgrad_kernel" if self.cin == 1 else wgrad_tag.get(parts, "conv_wgrad_kernel")
         return clock.bracket(tag, flops(self, B), lambda: orig_wgrad(self, x, stats, relu_in, gout, B, parts))
 
-    L.fwd, L.dgrad, L.wgrad = fwd, dgrad, wgrad
+    def fwd_stats(self, x, wf, bias, B):
+        return clock.bracket("conv_stem_kernel", flops(self, B), lambda: orig_fwd_stats(self, x, wf, bias, B))
+
+    L.fwd, L.dgrad, L.wgrad, L.fwd_stats = fwd, dgrad, wgrad, fwd_stats
 
     orig_call = ops.call
 
@@ -377,7 +380,7 @@ def install_clock(clock):
     ops._library_fused_linear = fused
 
     def restore():
-        L.fwd, L.dgrad, L.wgrad = orig_fwd, orig_dgrad, orig_wgrad
+        L.fwd, L.dgrad, L.wgrad, L.fwd_stats = orig_fwd, orig_dgrad, orig_wgrad, orig_fwd_stats
         for mod in patched:
             mod.call = orig_call
         ops._library_gemm = orig_gemm

@@ -366,6 +366,14 @@ int mdnvae_conv_pack_weights(const float* w, int Cout, int Cin, int KS, float* p
 int mdnvae_conv2d(const float* x, const float* in_stats, int relu_in, const float* packed_w, const float* bias,
                   float* out, int B, int Cin, int H, int W, int Cout, int OH, int OW, int KS, int stride, int pad,
                   int reflect, int transposed, void* stream);
+/* The 7x7 single-channel stem (function/VAE_CNN_NN.py:83-86: ReflectionPad2d(3) + Conv2d(1, 48, 7)) with the
+ * InstanceNorm2d statistics of its output planes taken on the way out: stats [B * Cout][2] = {mean,
+ * 1 / sqrt(var + 1e-5)} as mdnvae_plane_stats gives them, without another read of the planes.  Each 256-pixel
+ * tile leaves the mean and the sum of squared deviations of its own pixels (workspace), combined per plane in
+ * double. */
+size_t mdnvae_conv_stem_stats_workspace_floats(int B, int Cout, int OH, int OW);
+int mdnvae_conv_stem_stats(const float* x, const float* packed_w, const float* bias, float* out, int B, int H, int W,
+                           int Cout, int KS, int pad, float* workspace, float* stats, void* stream);
 /* The same convolution / data gradient on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16, fp32
  * accumulation).  parts = 1: both operands rounded to bf16 - the reduced-precision mode of the encoder of
  * function_FC/VAE_CNN_GCN.py:97-137; results differ from mdnvae_conv2d by the rounding of the inputs (2^-9

@@ -662,7 +662,7 @@ template <int WAVES, int WM, int WN>
 __global__ __launch_bounds__(WAVES * 64) void conv_stem_kernel(ConvGeom g, int KS, const float* __restrict__ x,
                                                                const float* __restrict__ wp,
                                                                const float* __restrict__ bias,
-                                                               float* __restrict__ out) {
+                                                               float* __restrict__ out, float* __restrict__ tile_stats) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NT = WAVES * 64;
     constexpr int PT = WAVES * WM * 32;
@@ -717,23 +717,79 @@ __global__ __launch_bounds__(WAVES * 64) void conv_stem_kernel(ConvGeom g, int K
             for (int n = 0; n < WN; ++n)
                 acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], bb[n], acc[m][n], 0, 0, 0);
     }
+    // Write-out.  A lane's accumulators are 16 positions of ONE channel, and the output is channel-major planes: stored
+    // from the registers, every instruction would touch 64 planes with 4 bytes each.  The tile crosses through LDS,
+    // [channel][position], one 32-channel column at a time, and leaves as 1 KiB runs of a plane (16 bytes per lane; the
+    // planes start at 4-byte phases when H W is odd, which the hardware's unaligned 16-byte stores take).
+    typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+    typedef float f4a __attribute__((ext_vector_type(4)));
+    constexpr int ROWP = PT + 4;
+    float* ep = smem;
 #pragma unroll
     for (int n = 0; n < WN; ++n) {
-        const int ch = n0 + n * 32 + l32;
-        if (ch < g.Cout) {
-            const float bv = bias ? bias[ch] : 0.0f;
-            float* oplane = out + ((long)b * g.Cout + ch) * P;
+        __syncthreads();                                   // the slab / the previous column has been read
+        const int chl = n0 + n * 32 + l32;
+        const float bv = (bias && chl < g.Cout) ? bias[chl] : 0.0f;
 #pragma unroll
-            for (int m = 0; m < WM; ++m) {
-                const int pbase = p0 + (wave * WM + m) * 32 + 4 * h;
+        for (int m = 0; m < WM; ++m)
 #pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    const int p = pbase + (j & 3) + 8 * (j >> 2);
-                    if (p < P) oplane[p] = acc[m][n][j] + bv;
+            for (int q = 0; q < 4; ++q)
+                *reinterpret_cast<f4a*>(ep + l32 * ROWP + (wave * WM + m) * 32 + 8 * q + 4 * h) =
+                    f4a{acc[m][n][4 * q] + bv, acc[m][n][4 * q + 1] + bv, acc[m][n][4 * q + 2] + bv, acc[m][n][4 * q + 3] + bv};
+        __syncthreads();
+        static_assert(PT / 4 == 64, "a wave reads back one channel's row of the tile per pass");
+        for (int item = tid; item < 32 * (PT / 4); item += NT) {
+            const int c = item / (PT / 4), q4 = item - c * (PT / 4);
+            const int ch = n0 + n * 32 + c, p = p0 + 4 * q4;
+            if (ch >= g.Cout) continue;                        // (a whole wave: c is the same for its 64 lanes)
+            const f4a v = *reinterpret_cast<const f4a*>(ep + c * ROWP + 4 * q4);
+            float* o = out + ((long)b * g.Cout + ch) * P + p;
+            if (p + 3 < P) {
+                *reinterpret_cast<f4u*>(o) = v;
+            } else {
+                for (int i = 0; i < 4 && p + i < P; ++i) o[i] = v[i];
+            }
+            if (tile_stats) {
+                // this tile's share of the plane's instance-norm statistics: mean and sum of squared deviations of its
+                // own pixels (combined over the tiles of a plane by stem_stats_finalize_kernel)
+                const int cnt = min(PT, P - p0);
+                float sum = 0.0f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) sum += (p + i < P) ? v[i] : 0.0f;
+                const float mean = wave_sum_all(sum) / (float)cnt;
+                float m2 = 0.0f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float d = v[i] - mean;
+                    m2 += (p + i < P) ? d * d : 0.0f;
+                }
+                m2 = wave_sum_all(m2);
+                if (lane == 0) {
+                    float* ts = tile_stats + (((long)b * g.Cout + ch) * gridDim.x + blockIdx.x) * 2;
+                    ts[0] = mean;
+                    ts[1] = m2;
                 }
             }
         }
     }
+}
+
+// stats[plane] = {mean, 1 / sqrt(var + eps)} from the per-tile {mean, sum of squared deviations} of conv_stem_kernel:
+// tiles are combined pairwise in double (mean and M2 of a union from those of its parts), in tile order.
+__global__ __launch_bounds__(256) void stem_stats_finalize_kernel(const float* __restrict__ tile_stats, long nplanes, int ntiles,
+                                                                  int P, int PT, float eps, float* __restrict__ stats) {
+    const long pl = (long)blockIdx.x * 256 + threadIdx.x;
+    if (pl >= nplanes) return;
+    double n = 0.0, mean = 0.0, m2 = 0.0;
+    for (int t = 0; t < ntiles; ++t) {
+        const double nb = (double)min(PT, P - t * PT), mb = tile_stats[(pl * ntiles + t) * 2], sb = tile_stats[(pl * ntiles + t) * 2 + 1];
+        const double tot = n + nb, delta = mb - mean;
+        mean += delta * nb / tot;
+        m2 += sb + delta * delta * n * nb / tot;
+        n = tot;
+    }
+    stats[2 * pl] = (float)mean;
+    stats[2 * pl + 1] = (float)(1.0 / sqrt(m2 / n + (double)eps));
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1444,7 +1500,6 @@ __global__ __launch_bounds__(256) void conv_stem_wgrad_kernel(ConvGeom g, int KS
     const int P = g.SH * g.SW;
     const int b_begin = blockIdx.z * samples_per_group;
     const int b_end = min(g.B, b_begin + samples_per_group);
-    const unsigned m_ptw = magic_of(ptw);
     // per-lane tap offsets for the two tap tiles (taps >= KK read the zero word)
     int toff[2];
 #pragma unroll
@@ -1462,59 +1517,56 @@ __global__ __launch_bounds__(256) void conv_stem_wgrad_kernel(ConvGeom g, int KS
 #pragma unroll
             for (int j = 0; j < 16; ++j) acc[i][jt][j] = 0.0f;
 
-    for (int b = b_begin; b < b_end; ++b) {
-        for (int p0 = 0; p0 < P; p0 += ptw) {
-            const int a0 = fdiv(p0, g.m_sw);
-            const int plast = min(P - 1, p0 + ptw - 1);
-            const int nrows = (fdiv(plast, g.m_sw) - a0) * g.S + g.KHe;
-            const int pr0 = a0 * g.S;
-            const int slab_elems = nrows * g.IWp;
-            __syncthreads();
-            {
-                constexpr int E = 8;
-                const int total = 64 * ptw;
-                for (int base = 0; base < total; base += 256 * E) {
-                    float v[E];
+    // The output-gradient tile of a chunk (Cout planes x ptw pixels) is fetched into registers while the previous chunk's
+    // MFMAs run, and goes to LDS at the top of its own chunk; channels >= Cout and pixels behind the plane stay zero.
+    constexpr int GE = 64;                                  // tile rows; thread t holds pixel t of every row (ptw = 256)
+    float gv[GE];
+    const int nper = (P + ptw - 1) / ptw;
+    const int nchunks = (b_end - b_begin) * nper;
+    auto fetch = [&](int ch) {
+        const int b = b_begin + ch / nper, p0 = (ch % nper) * ptw;
 #pragma unroll
-                    for (int e = 0; e < E; ++e) {
-                        const int idx = base + tid + e * 256;
-                        v[e] = 0.0f;
-                        if (idx < total) {
-                            const int n = fdiv(idx, m_ptw), pp = idx - n * ptw;
-                            if (n < g.Cout && p0 + pp < P) v[e] = gout[((long)b * g.Cout + n) * P + p0 + pp];
-                        }
-                    }
+        for (int e = 0; e < GE; ++e) {
+            const int n = e, pp = tid;                          // ptw = 256 = the threads of the workgroup
+            const bool ok = n < g.Cout && p0 + pp < P;
+            const float t = gout[((long)b * g.Cout + (ok ? n : 0)) * P + (ok ? p0 + pp : 0)];
+            gv[e] = ok ? t : 0.0f;
+        }
+    };
+    if (nchunks > 0) fetch(0);
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int b = b_begin + ch / nper, p0 = (ch % nper) * ptw;
+        const int a0 = fdiv(p0, g.m_sw);
+        const int plast = min(P - 1, p0 + ptw - 1);
+        const int nrows = (fdiv(plast, g.m_sw) - a0) * g.S + g.KHe;
+        const int pr0 = a0 * g.S;
+        const int slab_elems = nrows * g.IWp;
+        __syncthreads();
 #pragma unroll
-                    for (int e = 0; e < E; ++e) {
-                        const int idx = base + tid + e * 256;
-                        if (idx < total) {
-                            const int n = fdiv(idx, m_ptw), pp = idx - n * ptw;
-                            gl[n * gl_stride + pp] = v[e];
-                        }
-                    }
-                }
-            }
-            stage_slab<256, 8>(g, x, nullptr, b, 0, 1, 1, pr0, slab_elems, magic_of(slab_elems), slab, tid);
-            if (tid == 0) slab[zero_at] = 0.0f;
-            __syncthreads();
-            // wave w takes pixel pairs w, w+4, w+8, ...
-            const int npairs = (min(ptw, P - p0) + 1) >> 1;
+        for (int e = 0; e < GE; ++e) {
+            gl[e * gl_stride + tid] = gv[e];
+        }
+        stage_slab<256, 8>(g, x, nullptr, b, 0, 1, 1, pr0, slab_elems, magic_of(slab_elems), slab, tid);
+        if (tid == 0) slab[zero_at] = 0.0f;
+        __syncthreads();
+        if (ch + 1 < nchunks) fetch(ch + 1);
+        // wave w takes pixel pairs w, w+4, w+8, ...
+        const int npairs = (min(ptw, P - p0) + 1) >> 1;
 #pragma unroll 2
-            for (int k = wave; k < npairs; k += 4) {
-                const int pix = min(P - 1, p0 + 2 * k + h);
-                const int a = fdiv(pix, g.m_sw), bb = pix - a * g.SW;
-                const int off = (a - a0) * g.S * g.IWp + bb * g.S;
-                float av[2], bv[2];
+        for (int k = wave; k < npairs; k += 4) {
+            const int pix = min(P - 1, p0 + 2 * k + h);
+            const int a = fdiv(pix, g.m_sw), bb = pix - a * g.SW;
+            const int off = (a - a0) * g.S * g.IWp + bb * g.S;
+            float av[2], bv[2];
 #pragma unroll
-                for (int i = 0; i < 2; ++i) av[i] = gl[(i * 32 + l32) * gl_stride + 2 * k + h];
+            for (int i = 0; i < 2; ++i) av[i] = gl[(i * 32 + l32) * gl_stride + 2 * k + h];
 #pragma unroll
-                for (int jt = 0; jt < 2; ++jt) bv[jt] = slab[toff[jt] >= 0 ? off + toff[jt] : zero_at];
+            for (int jt = 0; jt < 2; ++jt) bv[jt] = slab[toff[jt] >= 0 ? off + toff[jt] : zero_at];
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int jt = 0; jt < 2; ++jt)
-                        acc[i][jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[jt], acc[i][jt], 0, 0, 0);
-            }
+                for (int jt = 0; jt < 2; ++jt)
+                    acc[i][jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[jt], acc[i][jt], 0, 0, 0);
         }
     }
     // add the four waves' tiles: red[wave][n 64][tap 64]
@@ -1718,7 +1770,7 @@ int mdnvae_conv_pack_weights(const float* w, int Cout, int Cin, int KS, float* p
 // Forward convolution (transposed = 0) or data gradient (transposed = 1); bf16: packed_w holds bf16 fragments
 static int conv2d_run(const float* x, const float* in_stats, int relu_in, const void* packed_w_, const float* bias,
                       float* out, int B, int Cin, int H, int W, int Cout, int OH, int OW, int KS, int stride, int pad,
-                      int reflect, int transposed, void* stream, int bf16) {
+                      int reflect, int transposed, void* stream, int bf16, float* tile_stats = nullptr) {
     const float* packed_w = static_cast<const float*>(packed_w_);
     auto launch = [&](const ConvGeom& gg, const float* bb) {
         return bf16 ? launch_conv_bf16(gg, bf16, x, in_stats, static_cast<const char*>(packed_w_), bb, out, (hipStream_t)stream)
@@ -1751,12 +1803,13 @@ static int conv2d_run(const float* x, const float* in_stats, int relu_in, const 
             g.CoutP = round_up(Cout, 64);
             const int rows = (rows_touched(PT, g.SW, g.SH) - 1) * g.S + KS;
             g.slab_stride = rows * g.IWp + 1;
-            const size_t lds = ((size_t)g.slab_stride + (size_t)((KS * KS + 1) & ~1) * WN * 32) * 4;
+            size_t lds = ((size_t)g.slab_stride + (size_t)((KS * KS + 1) & ~1) * WN * 32) * 4;
+            if (lds < (size_t)32 * (PT + 4) * 4) lds = (size_t)32 * (PT + 4) * 4;        // the write-out's [32 channels][PT + 4]
             MV_REQUIRE(lds <= 160 * 1024, E_SHAPE, "mdnvae_conv2d: tile needs %zu bytes of LDS", lds);
             set_lds_limit(reinterpret_cast<const void*>(conv_stem_kernel<WAVES, WM, WN>));
             dim3 grid((OH * OW + PT - 1) / PT, g.CoutP / (WN * 32), B);
             hipLaunchKernelGGL((conv_stem_kernel<WAVES, WM, WN>), grid, dim3(WAVES * 64), lds, st, g, KS, x, packed_w,
-                               bias, out);
+                               bias, out, tile_stats);
             MV_LAUNCH_CHECK("conv_stem_kernel");
             return 0;
         }
@@ -1818,6 +1871,25 @@ int mdnvae_conv2d(const float* x, const float* in_stats, int relu_in, const floa
                   int reflect, int transposed, void* stream) {
     return conv2d_run(x, in_stats, relu_in, packed_w, bias, out, B, Cin, H, W, Cout, OH, OW, KS, stride, pad, reflect,
                       transposed, stream, 0);
+}
+
+size_t mdnvae_conv_stem_stats_workspace_floats(int B, int Cout, int OH, int OW) {
+    return (size_t)B * Cout * ((OH * OW + 255) / 256) * 2;
+}
+
+int mdnvae_conv_stem_stats(const float* x, const float* packed_w, const float* bias, float* out, int B, int H, int W, int Cout,
+                           int KS, int pad, float* workspace, float* stats, void* stream) {
+    MV_REQUIRE(B >= 0 && H >= 1 && W >= 1, E_ARG, "mdnvae_conv_stem_stats: bad size");
+    if (B == 0) return 0;
+    MV_REQUIRE(workspace && stats, E_ARG, "mdnvae_conv_stem_stats: null pointer");
+    const int OH = H + 2 * pad - KS + 1, OW = W + 2 * pad - KS + 1;
+    const int rc = conv2d_run(x, nullptr, 0, packed_w, bias, out, B, 1, H, W, Cout, OH, OW, KS, 1, pad, 1, 0, stream, 0, workspace);
+    if (rc) return rc;
+    const long nplanes = (long)B * Cout;
+    hipLaunchKernelGGL(stem_stats_finalize_kernel, dim3((unsigned)((nplanes + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       workspace, nplanes, (OH * OW + 255) / 256, OH * OW, 256, 1e-5f, stats);
+    MV_LAUNCH_CHECK("stem_stats_finalize_kernel");
+    return 0;
 }
 
 size_t mdnvae_conv_packed_bytes_bf16(int Cout, int Cin, int KS, int transposed, int parts) {

@@ -1282,6 +1282,18 @@ class _ConvLayer:
             call("mdnvae_conv2d", ptr(x), ptr(stats), int(relu_in), ptr(wf), ptr(bias, "conv bias"), ptr(out), *geom, stream())
         return out
 
+    def fwd_stats(self, x, wf, bias, B):
+        """The single-channel stem and the instance-norm statistics of its output planes from one kernel."""
+        if self.cin != 1 or not self.reflect or self.stride != 1:
+            raise RuntimeError("fwd_stats is the stem's product (one input channel, reflection padding, stride 1)")
+        out = torch.empty(B, self.cout, self.oh, self.oh, dtype=torch.float32, device=x.device)
+        st = torch.empty(B * self.cout, 2, dtype=torch.float32, device=x.device)
+        ws = torch.empty(_lib.load().mdnvae_conv_stem_stats_workspace_floats(B, self.cout, self.oh, self.oh), dtype=torch.float32,
+                         device=x.device)
+        call("mdnvae_conv_stem_stats", ptr(x), ptr(wf), ptr(bias, "conv bias"), ptr(out), B, self.h, self.h, self.cout, self.ks,
+             self.pad, ptr(ws), ptr(st), stream())
+        return out, st
+
     def dgrad(self, gout, wb, B, parts=0):
         """Gradient w.r.t. the conv input; for reflection-padded layers on the padded plane."""
         if self.reflect:
@@ -1397,8 +1409,7 @@ class _ConvEncoder(torch.autograd.Function):
         # a normalised activation that only feeds the next convolution is never written: the convolution
         # normalises the raw output of its producer while loading it (statistics from one read of the
         # raw planes); only the residual stream x + block(x) is materialised
-        raw1 = layers[0].fwd(x, None, 0, packed[0][0], bs[0], B, mp[0])
-        st1 = _plane_stats(raw1)
+        raw1, st1 = layers[0].fwd_stats(x, packed[0][0], bs[0], B)
         raw2 = layers[1].fwd(raw1, st1, 1, packed[1][0], bs[1], B, mp[1])
         st2 = _plane_stats(raw2)
         raw3 = layers[2].fwd(raw2, st2, 1, packed[2][0], bs[2], B, mp[2])
@@ -1646,8 +1657,7 @@ class _ConvEncoderCB(torch.autograd.Function):
         s2 = _pow2_below(G.h2) if two else 1.0
         sr = _pow2_below((nres + 1) * G.h3) if two else 1.0
         o16 = not two
-        raw1 = stem.fwd(x, None, 0, wstem, bs[0], B)                                   # [B,48,n,n]
-        st1 = _plane_stats(raw1)
+        raw1, st1 = stem.fwd_stats(x, wstem, bs[0], B)                                 # [B,48,n,n] and its plane statistics
         a1, p1, _, _ = _cb_norm_fwd(raw1, st1, n_nodes, n_nodes, n_nodes, True, 1, G.pp_a1, parts=parts, scale=s1)
         y2 = _cb_conv(a1, p1, wf[0], bs[1], B, 96, 48, 1, G.h2, G.p2, G.pp_a1, out16=o16, parts=parts, out_scale=1.0 / s1, amax_w=wmax[0])
         a2, p2, _, st2 = _cb_norm_fwd(y2, None, G.h2, G.h2, G.p2, True, 1, G.pp_a2, parts=parts, scale=s2)

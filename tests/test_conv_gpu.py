@@ -451,3 +451,23 @@ def test_bf16_mode_trains_like_the_fp32_mode():
                   f"bf16 mode vs fp32 mode; fp32 curve {smooth['fp32'][0]:.4g} -> {smooth['fp32'][-1]:.4g}, "
                   f"bf16 curve {smooth['bf16'][0]:.4g} -> {smooth['bf16'][-1]:.4g}")
     assert float(gap) <= 3e-2, (smooth["fp32"].tolist(), smooth["bf16"].tolist())
+
+
+@pytest.mark.parametrize("n,B", [(87, 3), (68, 2), (20, 1)])
+def test_stem_statistics_taken_in_the_write_out(n, B):
+    """mdnvae_conv_stem_stats: the same planes as the plain stem product, and {mean, rstd} per plane as float64 takes
+    them from those planes (tile-wise means and squared deviations combined in double: 1e-6)."""
+    g = torch.Generator().manual_seed(n)
+    x = torch.randn(B, n * n, generator=g).to(DEV)
+    w = (torch.randn(48, 1, 7, 7, generator=g) / 7.0).to(DEV)
+    b = torch.randn(48, generator=g).to(DEV)
+    stem = ops._ConvLayer(1, 48, 7, 1, 3, True, n)
+    wf, _ = stem.pack(w, DEV, False)
+    plain = stem.fwd(x, None, 0, wf, b, B)
+    out, st = stem.fwd_stats(x, wf, b, B)
+    assert torch.equal(out, plain)
+    p64 = out.double().reshape(B * 48, -1)
+    mean = p64.mean(1)
+    rstd = 1.0 / torch.sqrt(p64.var(1, unbiased=False) + 1e-5)
+    assert float((st[:, 0].double() - mean).abs().max()) <= 1e-6 * float(mean.abs().max() + p64.std())
+    assert float((st[:, 1].double() / rstd - 1).abs().max()) <= 1e-6
