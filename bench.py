@@ -290,6 +290,9 @@ def _cb_tag(base, parts):
     return base if parts == 1 else base[:-1] + _TWO + ">" if base.endswith(">") else base + "<" + _TWO[2:] + ">"
 
 
+# (x, grad_out, workspace, grad_w, B, H, W, Cout, KS, pad): the stem's weight gradient on bf16 operands
+ABI_TAGS["mdnvae_conv_stem_wgrad_bf16"] = ("conv_stem_wgrad_kernel<bf16>", lambda a: 2.0 * a[8] * a[8] * a[7] * a[5] * a[6] * a[4])
+BF16_TAGS.add("conv_stem_wgrad_kernel<bf16>")
 ABI_TAGS.update({
     "mdnvae_cb_conv": (lambda a: _cb_tag(_CB_KIND[a[9]], a[13]),
                        lambda a: 18.0 * a[6] * a[7] * a[8] * (a[10] - (2 if a[9] == 2 else 0)) ** 2),

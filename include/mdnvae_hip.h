@@ -395,6 +395,10 @@ int mdnvae_conv2d_bf16(const float* x, const float* in_stats, int relu_in, const
 int mdnvae_conv2d_wgrad_bf16(const float* x, const float* in_stats, int relu_in, const float* grad_out,
                              float* workspace, float* grad_w, int B, int Cin, int H, int W, int Cout, int OH, int OW,
                              int KS, int stride, int pad, int reflect, int parts, void* stream);
+/* Weight gradient of the 7x7 single-channel stem (function/VAE_CNN_NN.py:83-86) with both operands rounded to bf16
+ * (fp32 accumulation): the bf16 mode's form of mdnvae_conv2d_wgrad(Cin = 1); same workspace, reflection padding. */
+int mdnvae_conv_stem_wgrad_bf16(const float* x, const float* grad_out, float* workspace, float* grad_w, int B, int H,
+                                int W, int Cout, int KS, int pad, void* stream);
 size_t mdnvae_conv_wgrad_workspace_floats(int B, int Cout, int Cin, int KS);
 /* grad_w [Cout,Cin,KS,KS] = sum_{b,pixels} grad_out x pad(act(x)); same x / in_stats / relu_in
  * / padding conventions as the forward call.  3x3 multi-channel or the 7x7 single-channel stem. */

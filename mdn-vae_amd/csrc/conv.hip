@@ -1488,6 +1488,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __r
 // Stem weight gradient (one input channel): D[n][tap] accumulates over pixels.
 // 4 waves split the pixels of each chunk; their accumulators are added through LDS at the end.
 // partial [G][Cout][KK]
+// BF16: both operands rounded to bf16 as they leave LDS, v_mfma_f32_32x32x16_bf16 over 16 consecutive pixels of the chunk
+// (an eighth of the matrix instructions of the fp32 form, whose K is 2 pixels).
+template <bool BF16>
 __global__ __launch_bounds__(256) void conv_stem_wgrad_kernel(ConvGeom g, int KS, const float* __restrict__ x,
                                                               const float* __restrict__ gout, int ptw,
                                                               int samples_per_group, float* __restrict__ partial) {
@@ -1550,6 +1553,36 @@ __global__ __launch_bounds__(256) void conv_stem_wgrad_kernel(ConvGeom g, int KS
         if (tid == 0) slab[zero_at] = 0.0f;
         __syncthreads();
         if (ch + 1 < nchunks) fetch(ch + 1);
+        if constexpr (BF16) {
+            // wave w takes the 16-pixel steps w, w+4, ...; lane half h holds pixels 8h .. 8h+7 of a step: of channel
+            // (32 i + l32) for A, shifted by tap (32 jt + l32) for B
+            const int nsteps = (min(ptw, P - p0) + 15) >> 4;
+            for (int ks = wave; ks < nsteps; ks += 4) {
+                const int pb = 16 * ks + 8 * h;
+                bf16x8 A[2], Bv[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) A[i][j] = (__bf16)gl[(i * 32 + l32) * gl_stride + pb + j];
+                int pix = min(P - 1, p0 + pb);
+                int a = fdiv(pix, g.m_sw), bb = pix - a * g.SW;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int off = (a - a0) * g.S * g.IWp + bb * g.S;
+#pragma unroll
+                    for (int jt = 0; jt < 2; ++jt) Bv[jt][j] = (__bf16)slab[toff[jt] >= 0 ? off + toff[jt] : zero_at];
+                    if (p0 + pb + j + 1 < P) {                  // (pixels behind the plane: A holds zeros there)
+                        if (++bb == g.SW) { bb = 0; ++a; }
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int jt = 0; jt < 2; ++jt)
+                        acc[i][jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[i], Bv[jt], acc[i][jt], 0, 0, 0);
+            }
+            continue;
+        }
         // wave w takes pixel pairs w, w+4, w+8, ...
         const int npairs = (min(ptw, P - p0) + 1) >> 1;
 #pragma unroll 2
@@ -1730,6 +1763,33 @@ static int wgrad_groups(int B, int ntiles) {
     if (G < 1) G = 1;
     if (G > B) G = B;
     return G;
+}
+
+// weight gradient of the single-channel stem; g: geometry as mdnvae_conv2d_wgrad fills it
+static int stem_wgrad_run(ConvGeom g, int KS, const float* x, const float* grad_out, float* workspace, float* grad_w, bool bf16,
+                          hipStream_t st) {
+    const int B = g.B, Cout = g.Cout, OH = g.SH, OW = g.SW, KK = KS * KS;
+    const int Gz0 = wgrad_groups(B, 1);
+    const int spg = (B + Gz0 - 1) / Gz0, Gz = (B + spg - 1) / spg;
+    const int ptw = 256;
+    const int rows = (rows_touched(ptw, OW, OH) - 1) * g.S + KS;
+    g.slab_stride = rows * g.IWp + 2;
+    size_t lds = ((size_t)64 * (ptw + 1) + g.slab_stride) * 4;
+    const size_t red = (size_t)4 * 64 * 65 * 4;
+    if (lds < red) lds = red;
+    MV_REQUIRE(lds <= 160 * 1024, E_SHAPE, "mdnvae_conv2d_wgrad: needs %zu bytes of LDS", lds);
+    if (bf16) {
+        set_lds_limit(reinterpret_cast<const void*>(conv_stem_wgrad_kernel<true>));
+        hipLaunchKernelGGL(conv_stem_wgrad_kernel<true>, dim3(1, 1, Gz), dim3(256), lds, st, g, KS, x, grad_out, ptw, spg, workspace);
+    } else {
+        set_lds_limit(reinterpret_cast<const void*>(conv_stem_wgrad_kernel<false>));
+        hipLaunchKernelGGL(conv_stem_wgrad_kernel<false>, dim3(1, 1, Gz), dim3(256), lds, st, g, KS, x, grad_out, ptw, spg, workspace);
+    }
+    MV_LAUNCH_CHECK("conv_stem_wgrad_kernel");
+    const long n = (long)Cout * KK;
+    hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, workspace, Gz, n, grad_w);
+    MV_LAUNCH_CHECK("sum_partials_kernel");
+    return 0;
 }
 
 }  // namespace mdnvae
@@ -1945,26 +2005,7 @@ int mdnvae_conv2d_wgrad(const float* x, const float* in_stats, int relu_in, cons
     finish_geom(g, KS);
     const int KK = KS * KS;
     hipStream_t st = (hipStream_t)stream;
-    if (Cin == 1) {
-        const int Gz0 = wgrad_groups(B, 1);
-        const int spg = (B + Gz0 - 1) / Gz0, Gz = (B + spg - 1) / spg;
-        const int ptw = 256;
-        const int rows = (rows_touched(ptw, OW, OH) - 1) * stride + KS;
-        g.slab_stride = rows * g.IWp + 2;
-        size_t lds = ((size_t)64 * (ptw + 1) + g.slab_stride) * 4;
-        const size_t red = (size_t)4 * 64 * 65 * 4;
-        if (lds < red) lds = red;
-        MV_REQUIRE(lds <= 160 * 1024, E_SHAPE, "mdnvae_conv2d_wgrad: needs %zu bytes of LDS", lds);
-        set_lds_limit(reinterpret_cast<const void*>(conv_stem_wgrad_kernel));
-        hipLaunchKernelGGL(conv_stem_wgrad_kernel, dim3(1, 1, Gz), dim3(256), lds, st, g, KS, x, grad_out, ptw, spg,
-                           workspace);
-        MV_LAUNCH_CHECK("conv_stem_wgrad_kernel");
-        const long n = (long)Cout * KK;
-        hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, workspace, Gz, n,
-                           grad_w);
-        MV_LAUNCH_CHECK("sum_partials_kernel");
-        return 0;
-    }
+    if (Cin == 1) return stem_wgrad_run(g, KS, x, grad_out, workspace, grad_w, false, st);
     const int ntiles = ((Cout + 63) / 64) * ((Cin + 63) / 64);
     const int Gz0 = wgrad_groups(B, ntiles);
     const int spg = (B + Gz0 - 1) / Gz0, Gz = (B + spg - 1) / spg;
@@ -2042,6 +2083,21 @@ static void launch_wgrad_bf16(const WgradBf16& p, dim3 grid, size_t lds, const f
                               const float* grad_out, float* workspace, hipStream_t st) {
     set_lds_limit(reinterpret_cast<const void*>(conv_wgrad_bf16_kernel<S, PARTS, RW>));
     hipLaunchKernelGGL((conv_wgrad_bf16_kernel<S, PARTS, RW>), grid, dim3(256), lds, st, p, x, stats, grad_out, workspace);
+}
+
+extern "C" int mdnvae_conv_stem_wgrad_bf16(const float* x, const float* grad_out, float* workspace, float* grad_w, int B, int H,
+                                           int W, int Cout, int KS, int pad, void* stream) {
+    MV_REQUIRE(B >= 1 && H >= 1 && W >= 1, E_ARG, "mdnvae_conv_stem_wgrad_bf16: bad size");
+    MV_REQUIRE(x && grad_out && workspace && grad_w, E_ARG, "mdnvae_conv_stem_wgrad_bf16: null pointer");
+    MV_REQUIRE(KS == 7 && Cout <= 64 && pad < H && pad < W, E_SHAPE, "mdnvae_conv_stem_wgrad_bf16: 7x7 stem with at most 64 output channels");
+    ConvGeom g{};
+    g.B = B; g.Cin = 1; g.H = H; g.W = W; g.Cout = Cout;
+    g.OHf = g.SH = H + 2 * pad - KS + 1;
+    g.OWf = g.SW = W + 2 * pad - KS + 1;
+    g.osy = g.osx = 1;
+    g.S = 1; g.pad = pad; g.reflect = 1; g.relu_in = 0; g.KHe = KS;
+    finish_geom(g, KS);
+    return stem_wgrad_run(g, KS, x, grad_out, workspace, grad_w, true, (hipStream_t)stream);
 }
 
 extern "C" int mdnvae_conv2d_wgrad_bf16(const float* x, const float* in_stats, int relu_in, const float* grad_out,

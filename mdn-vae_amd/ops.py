@@ -1321,6 +1321,15 @@ class _ConvLayer:
         return gw
 
 
+def _stem_wgrad_bf16(layer, x, gout, B):
+    """The stem's weight gradient with both operands rounded to bf16 (the bf16 mode)."""
+    ws = torch.empty(_lib.load().mdnvae_conv_wgrad_workspace_floats(B, layer.cout, 1, layer.ks), dtype=torch.float32, device=x.device)
+    gw = torch.empty(layer.cout, 1, layer.ks, layer.ks, dtype=torch.float32, device=x.device)
+    call("mdnvae_conv_stem_wgrad_bf16", ptr(x), ptr(gout), ptr(ws), ptr(gw), B, layer.h, layer.h, layer.cout, layer.ks, layer.pad,
+         stream())
+    return gw
+
+
 def _plane_stats(x):
     B, C, H, W = x.shape
     st = torch.empty(B * C, 2, dtype=torch.float32, device=x.device)
@@ -1624,7 +1633,8 @@ def _pow2_below(v):
 class _ConvEncoderCB(torch.autograd.Function):
     """The encoder of _ConvEncoder with 16-bit operands in the channel-blocked layout: x [B, n*n] -> pooled features.
     parts = 1: bf16 operands (the reduced-precision mode).  parts = 2: every operand as two fp16 parts, three
-    matrix-core products per multiply-add (fp32-accurate): activations carry a fixed power-of-two scale (a normalised
+    matrix-core products per multiply-add (fp32-accurate; there the 7x7 stem and its weight gradient are the fp32
+    kernels of _ConvEncoder, in bf16 mode the stem's weight gradient rounds its operands to bf16): activations carry a fixed power-of-two scale (a normalised
     plane is bounded by sqrt(H W), the residual stream by that times the number of blocks + 1), weights the scale of
     their largest magnitude, gradient operands the scale of theirs, which a probe run of the instance-norm backward
     pass records on the device before the pass proper writes them.  The 7x7 single-channel stem and the max pool are
@@ -1759,7 +1769,7 @@ class _ConvEncoderCB(torch.autograd.Function):
         g_r1, _, gs, _ = _cb_norm_bwd(da1, 2, G.p2, raw1, st1, n, True, 48, n, n, 2, 0)
         gb[0] = _colsum(gs)
         stem = _ConvLayer(1, 48, 7, 1, 3, True, n)
-        gw[0] = stem.wgrad(x.view(B, 1, n, n), None, 0, g_r1, B)
+        gw[0] = stem.wgrad(x.view(B, 1, n, n), None, 0, g_r1, B) if two else _stem_wgrad_bf16(stem, _c(x.view(B, 1, n, n)), g_r1, B)
         grads = []
         for w_, b_ in zip(gw, gb):
             grads += [w_, b_]
@@ -1770,7 +1780,8 @@ def conv_encoder(x, n_nodes, weights_and_biases, parts=0, blocked=False):
     """weights_and_biases: [(weight, bias)] for the stem, the two stride-2 convs and the residual
     block convs, in network order.  parts: 0 = the fp32 matrix instruction; 1..3 = the 3x3 convolutions on
     the bf16 matrix cores with operands split into that many bf16 parts (1: operands rounded to bf16,
-    3: fp32 accuracy); the stem, the norms and the pool are fp32 in every mode.  blocked: activations between
+    3: fp32 accuracy); the stem's forward product, the norms and the pool are fp32 in every mode (the channel-blocked
+    bf16 mode rounds the operands of the stem's weight gradient to bf16 like those of every other product).  blocked: activations between
     the 3x3 convolutions in the channel-blocked 16-bit layout (_ConvEncoderCB) instead of fp32 planes; parts is then
     1 (bf16) or 2 (two fp16 parts per operand, fp32-accurate)."""
     flat = []

@@ -471,3 +471,20 @@ def test_stem_statistics_taken_in_the_write_out(n, B):
     rstd = 1.0 / torch.sqrt(p64.var(1, unbiased=False) + 1e-5)
     assert float((st[:, 0].double() - mean).abs().max()) <= 1e-6 * float(mean.abs().max() + p64.std())
     assert float((st[:, 1].double() / rstd - 1).abs().max()) <= 1e-6
+
+
+@pytest.mark.parametrize("n,B", [(87, 3), (68, 5), (20, 1)])
+def test_stem_weight_gradient_on_bf16_operands(n, B):
+    """mdnvae_conv_stem_wgrad_bf16 against float64 on the bf16-rounded operands (only the fp32 accumulation differs:
+    1e-5 of the largest entry), and close to the fp32 kernel's result (2^-8 relative per product, random)."""
+    g = torch.Generator().manual_seed(n + B)
+    x = torch.randn(B, 1, n, n, generator=g)
+    gout = torch.randn(B, 48, n, n, generator=g)
+    stem = ops._ConvLayer(1, 48, 7, 1, 3, True, n)
+    got = ops._stem_wgrad_bf16(stem, x.to(DEV), gout.to(DEV), B)
+    xr = F.pad(x.to(torch.bfloat16).double(), (3, 3, 3, 3), mode="reflect")
+    w = torch.zeros(48, 1, 7, 7, dtype=torch.float64, requires_grad=True)
+    (F.conv2d(xr, w) * gout.to(torch.bfloat16).double()).sum().backward()
+    assert _rel(got, w.grad) <= 1e-5
+    full = stem.wgrad(x.to(DEV), None, 0, gout.to(DEV), B)
+    assert float((got - full).norm() / full.norm()) <= 1e-2
