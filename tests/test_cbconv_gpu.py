@@ -401,6 +401,43 @@ def test_norm_backward_pass(C, H, relu, gmode, omode, y16):
         assert _rel(total, folded.grad + base.double()) <= 2e-6
 
 
+@pytest.mark.parametrize("C,H,gmode,omode", [(16, 22, 1, 0), (16, 44, 2, 1), (4, 87, 2, 2)])
+def test_norm_backward_pass_with_bf16_gradient_planes(C, H, gmode, omode):
+    """The data gradient arriving as bf16 planes (mdnvae_cb_conv with out16 = 2): the pass gives what it gives on the
+    same values handed over as fp32 -- bit for bit, the planes are only widened on load."""
+    g = torch.Generator().manual_seed(C + H + gmode)
+    B = 2
+    raw = (torch.randn(B, C, H, H, generator=g) * 2 + 0.5)
+    stem = omode == 2
+    if not stem:
+        raw = raw.half().float()
+    pitch_y = H if stem else H + 1
+    Qy = H * H if stem else ops._ru(H * pitch_y, 8)
+    y = raw.to(DEV) if stem else _pitched(raw, pitch_y, Qy).to(DEV)
+    st = ops._plane_stats(raw.to(DEV)) if stem else ops._cb_stats(y, H, H, pitch_y)
+    if not stem:
+        y = y.half()
+    if gmode == 1:
+        pitch_g = H + 2
+        gt = _pitched(torch.randn(B, C, H + 2, H + 2, generator=g), pitch_g, ops._ru((H + 2) * pitch_g, 8))
+        base = torch.randn(B, C, H, H, generator=g).to(DEV)
+    else:
+        oh = (H + 1) // 2
+        pitch_g = oh + 1
+        gt = torch.randn(B, 4 * C, ops._ru(oh * pitch_g, 8), generator=g)
+        base = None
+    gt = gt.to(torch.bfloat16).to(DEV)
+    PP = 0 if stem else ops._ru(((H + 4) * (H + 2) if omode == 0 else (H + 1) * (H + 1)) + 3, 4)
+    outs = []
+    for planes in (gt, gt.float()):
+        dc, _, gsum, total = ops._cb_norm_bwd(planes, gmode, pitch_g, y, st, pitch_y, True, C, H, H, omode, PP, base=base,
+                                              want_sum=base is not None)
+        outs.append((dc.clone(), gsum.clone(), None if total is None else total.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    if base is not None:
+        assert torch.equal(outs[0][2], outs[1][2])
+
+
 def unblock2(buf, part_stride, groups, B, PP, scale):
     """two fp16 parts on the device -> [groups][B][PP][8] float64 (high part + what it left, scale undone)"""
     n = groups * B * PP * 8
