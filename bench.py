@@ -208,7 +208,8 @@ ABI_TAGS = {
     "mdnvae_outer_loss_fwdbwd": ("outer_loss_kernel",
                                  lambda a: 4.0 * a[3] * (a[5] * a[5] + 2 * a[4] * ops.DEC_NP + 4 * a[8])),
     "mdnvae_decoder_fwd": (lambda a: "chain_fwd_mfma_kernel+outer_epilogue_kernel" if a[15] is not None
-                           else ("chain_fwd_rows_kernel" if a[2] >= CHAIN_ROWS_MIN_B else "chain_fwd_mfma_kernel"),
+                           else (("chain_fwd_regs_kernel" if a[6] <= 4 and a[12] is None and a[13] == 0 else "chain_fwd_rows_kernel")
+                                 if a[2] >= CHAIN_ROWS_MIN_B else "chain_fwd_mfma_kernel"),
                            lambda a: _decoder_work(a, 0)),
     "mdnvae_decoder_bwd": (lambda a: "outer_grad_kernel+chain_bwd_mfma_kernel" if a[16] is not None
                            else (("chain_bwd_rows_kernel" if a[3] >= CHAIN_ROWS_MIN_B else "chain_bwd_saved_kernel")

@@ -552,6 +552,122 @@ __global__ __launch_bounds__(256) void chain_fwd_rows_kernel(DecArgs a, const fl
     }
 }
 
+// The chain with its activations in registers (large batches, no dropout, no x_latent).  The product runs transposed,
+// Y^T = W^T X^T: the panel is the A operand, the 16 samples of a wave are the columns.  Register r of lane (c16, g) of
+// output tile ct is then feature 16 ct + 4 g + r of sample c16 -- and that is exactly a B operand of the next layer if
+// its k step (ct, r) is taken to mean "features 16 ct + 4 g + r for g = 0..3": the order of the reduction is free as
+// long as the panel's rows are read in the same order.  Nothing crosses LDS between layers, and no barrier is needed.
+// A workgroup serves one channel (blockIdx.y) and keeps that channel's NL panels in LDS for its whole life (row pitch
+// NP + 4: the four k groups of a read fall on different banks); its waves walk 16-sample tiles independently, several
+// per SIMD, so one wave's MFMA chain hides under another's.
+constexpr int CG_LD = NP + 4;
+constexpr int CG_MAXL = 4;               // panels that fit: 4 x 96 x 100 floats = 150 KB
+
+__global__ __launch_bounds__(512) void chain_fwd_regs_kernel(DecArgs a, const float* __restrict__ z,
+                                                             const float* __restrict__ wt, float* __restrict__ nodes,
+                                                             float* __restrict__ hin) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, nwaves = blockDim.x >> 6;
+    const int c16 = lane & 15, g = lane >> 4;
+    const int r_ch = blockIdx.y;
+    const int N = a.N;
+    {
+        // the channel's panels: 18 16-byte pieces per thread and panel, all requested before the first is stored
+        const float* src = wt + (long)r_ch * a.NL * KP * NP;
+        constexpr int PER = KP * (NP / 4) / 512 + 1;               // 5 pieces of a panel per thread (512 threads)
+        for (int l = 0; l < a.NL; ++l) {
+            f32x4_t v[PER];
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                const int idx = t + i * 512;
+                if (idx < KP * (NP / 4)) v[i] = *reinterpret_cast<const f32x4_t*>(src + (long)l * KP * NP + idx * 4);
+            }
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                const int idx = t + i * 512;
+                const int row = idx / (NP / 4), q = idx - row * (NP / 4);
+                if (idx < KP * (NP / 4)) *reinterpret_cast<f32x4_t*>(smem + (l * KP + row) * CG_LD + 4 * q) = v[i];
+            }
+        }
+    }
+    __syncthreads();
+    // the workgroups of a channel split its 16-sample tiles into even contiguous runs; inside a workgroup wave w takes
+    // tiles w, w + 8, ...: waves w and w + 4 share a SIMD, and between them they get an even share whatever the count
+    const int ntiles = (a.B + CR_ROWS - 1) / CR_ROWS;
+    const int t_lo = (int)((long)ntiles * blockIdx.x / gridDim.x), t_hi = (int)((long)ntiles * (blockIdx.x + 1) / gridDim.x);
+    for (int tile = t_lo + wave; tile < t_hi; tile += nwaves) {
+        const int b = tile * CR_ROWS + c16;
+        const bool live = b < a.B;
+        float x[6][4];
+#pragma unroll
+        for (int kq = 0; kq < 6; ++kq)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int f = 16 * kq + 4 * g + r;
+                const bool ok = live && f < a.L;
+                const float v = z[(long)(ok ? b : 0) * a.L + (ok ? f : 0)];
+                x[kq][r] = f == KP - 1 ? 1.0f : (ok ? v : 0.0f);
+            }
+        for (int l = 0; l < a.NL; ++l) {
+            const int step = r_ch * a.NL + l;
+            if (hin && live) {
+#pragma unroll
+                for (int kq = 0; kq < 6; ++kq)
+                    *reinterpret_cast<f32x4_t*>(hin + ((long)step * a.B + b) * KP + 16 * kq + 4 * g) =
+                        f32x4_t{x[kq][0], x[kq][1], x[kq][2], x[kq][3]};
+            }
+            f32x4_t acc[6];
+#pragma unroll
+            for (int ct = 0; ct < 6; ++ct) acc[ct] = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
+            const float* pan = smem + l * KP * CG_LD + 4 * g * CG_LD + c16;
+            float wv[2][24];
+            auto load_w = [&](int kq, float (&w)[24]) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int ct = 0; ct < 6; ++ct) w[r * 6 + ct] = pan[(16 * kq + r) * CG_LD + ct * 16];
+            };
+            load_w(0, wv[0]);
+#pragma unroll
+            for (int kq = 0; kq < 6; ++kq) {
+                if (kq + 1 < 6) load_w(kq + 1, wv[(kq + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int ct = 0; ct < 6; ++ct)
+                        acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[kq & 1][r * 6 + ct], x[kq][r], acc[ct], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            const bool last = l == a.NL - 1;
+            auto epilogue = [&](auto act_tag) {
+                constexpr int ACT = decltype(act_tag)::value;
+#pragma unroll
+                for (int ct = 0; ct < 6; ++ct)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int n = 16 * ct + 4 * g + r;
+                        float v = act_of<ACT>(acc[ct][r]);
+                        v = n < N ? v : 0.0f;
+                        if (!last && n == KP - 1) v = 1.0f;
+                        x[ct][r] = v;
+                    }
+            };
+            switch (layer_act(a.acts, l)) {
+                case ACT_SIGMOID: epilogue(std::integral_constant<int, ACT_SIGMOID>{}); break;
+                case ACT_TANH: epilogue(std::integral_constant<int, ACT_TANH>{}); break;
+                default: epilogue(std::integral_constant<int, ACT_NONE>{}); break;
+            }
+        }
+        if (live) {
+#pragma unroll
+            for (int kq = 0; kq < 6; ++kq)
+                *reinterpret_cast<f32x4_t*>(nodes + ((long)b * a.R + r_ch) * NP + 16 * kq + 4 * g) =
+                    f32x4_t{x[kq][0], x[kq][1], x[kq][2], x[kq][3]};
+        }
+    }
+}
+
 // out[b][i*N+j] = f(sum_r g_r[i] g_r[j])  (one wave per sample), or in component mode
 // out[b][r][i*N+j] = g_r[i] g_r[j] (one wave per (sample, channel)).  The wave keeps its node
 // vectors in LDS and writes the N*N matrix as one flat run of 16-byte quads (the matrix starts at
@@ -1283,7 +1399,19 @@ int mdnvae_decoder_fwd(const float* z, const float* wt, int B, int N, int L, int
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         MV_REQUIRE(e == hipSuccess, (int)e, "mdnvae_decoder_fwd: cannot raise the LDS limit: %s", hipGetErrorString(e));
     }
-    if (B >= CR_TS * 128) {
+    if (B >= CR_TS * 128 && NL <= CG_MAXL && !drop && xlat_channels == 0) {
+        // large batches of the plain chain: activations in registers, one channel per workgroup
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(chain_fwd_regs_kernel),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        MV_REQUIRE(e == hipSuccess, (int)e, "mdnvae_decoder_fwd: cannot raise the LDS limit: %s", hipGetErrorString(e));
+        const size_t lds = sizeof(float) * (size_t)NL * KP * CG_LD;
+        const int tiles16 = (B + CR_ROWS - 1) / CR_ROWS;
+        int gx = 256 / R;                                   // about one workgroup per CU over the R channels
+        if (gx < 1) gx = 1;
+        if (gx * 8 > tiles16) gx = (tiles16 + 7) / 8;
+        hipLaunchKernelGGL(chain_fwd_regs_kernel, dim3(gx, R), dim3(512), lds, (hipStream_t)stream, a, z, wt, nodes, layer_in);
+        MV_LAUNCH_CHECK("chain_fwd_regs_kernel");
+    } else if (B >= CR_TS * 128) {
         // enough 64-sample tiles for half the chip and more: the wave-per-16-samples form
         {
             const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(chain_fwd_rows_kernel),

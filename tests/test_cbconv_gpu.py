@@ -432,6 +432,8 @@ def test_norm_backward_pass_with_bf16_gradient_planes(C, H, gmode, omode):
     for planes in (gt, gt.float()):
         dc, _, gsum, total = ops._cb_norm_bwd(planes, gmode, pitch_g, y, st, pitch_y, True, C, H, H, omode, PP, base=base,
                                               want_sum=base is not None)
+        if not stem:
+            dc = dc[:(C // 8) * B * PP * 16]             # (the buffer ends in slack for clamped reads, never written)
         outs.append((dc.clone(), gsum.clone(), None if total is None else total.clone()))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     if base is not None:
