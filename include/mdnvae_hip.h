@@ -458,6 +458,10 @@ size_t mdnvae_cb_packed_bytes(int Cout, int Cin, int kind, int parts);
  * amax (MDNVAE_ABSMAX_SLOTS partial maxima of |w| as bit patterns) is read for parts = 2 only. */
 int mdnvae_cb_pack_weights(const float* w, int Cout, int Cin, int kind, int parts, const unsigned* amax,
                            void* packed, void* stream);
+/* The same for n layers (at most 16) in one launch: host arrays of n device pointers / shapes; amax may be NULL
+ * for parts = 1. */
+int mdnvae_cb_pack_weights_batch(int n, const float* const* w, const int* Cout, const int* Cin, const int* kind, int parts,
+                                 const unsigned* const* amax, void* const* packed, void* stream);
 /* Two-part operands (parts = 2; fp32-accurate: three fp16 products per multiply-add, error <= 3 * 2^-22 of sum |a||w|):
  * the accumulators are multiplied by out_scale and divided by the power-of-two scales of the records absmax_act (NULL:
  * the input was written with a fixed scale, whose inverse is out_scale) and absmax_w (the record the weights were packed

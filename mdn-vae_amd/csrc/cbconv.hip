@@ -419,11 +419,10 @@ __global__ __launch_bounds__(512) void cb_conv_kernel(CbConv p, int nblk, int nt
 //           tap (ey, ex); kernel row ky = {py = 0: ey = 0 -> 1;  py = 1: ey = 0 -> 2, ey = 1 -> 0}, same for columns
 // out [N block][chunk][stage][tap in stage][n tile][part][lane][8]: lane = (k half, row in the tile), entry j = reduction
 // index 16 chunk + 8 half + j.  parts = 1: bf16; parts = 2: two fp16 parts of w * scale.
-__global__ __launch_bounds__(256) void cb_pack_weights_kernel(const float* __restrict__ w, int Cout, int Cin, int mode,
-                                                              int nblk, int NT, int nchunk, int SPC, int TPS, int parts,
-                                                              const unsigned* __restrict__ amax, char* __restrict__ out) {
+__device__ __forceinline__ void cb_pack_entry(const float* __restrict__ w, int Cout, int Cin, int mode, int nblk, int NT,
+                                              int nchunk, int SPC, int TPS, int parts, const unsigned* __restrict__ amax,
+                                              char* __restrict__ out, long idx) {
     const long total = (long)nblk * nchunk * SPC * TPS * NT * parts * 512;
-    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= total) return;
     const int j = (int)(idx & 7), ln = (int)((idx >> 3) & 63);
     long r = idx >> 9;
@@ -466,6 +465,28 @@ __global__ __launch_bounds__(256) void cb_pack_weights_kernel(const float* __res
         const _Float16 hi = (_Float16)t;
         reinterpret_cast<_Float16*>(out)[idx] = part == 0 ? hi : (_Float16)(t - (float)hi);
     }
+}
+
+__global__ __launch_bounds__(256) void cb_pack_weights_kernel(const float* __restrict__ w, int Cout, int Cin, int mode,
+                                                              int nblk, int NT, int nchunk, int SPC, int TPS, int parts,
+                                                              const unsigned* __restrict__ amax, char* __restrict__ out) {
+    cb_pack_entry(w, Cout, Cin, mode, nblk, NT, nchunk, SPC, TPS, parts, amax, out, (long)blockIdx.x * 256 + threadIdx.x);
+}
+
+// every layer of an encoder pass in one launch: blockIdx.y picks the layer
+constexpr int CB_PACK_MAX = 16;
+struct CbPackTable {
+    const float* w[CB_PACK_MAX];
+    const unsigned* amax[CB_PACK_MAX];
+    char* out[CB_PACK_MAX];
+    int Cout[CB_PACK_MAX], Cin[CB_PACK_MAX], mode[CB_PACK_MAX], nblk[CB_PACK_MAX], NT[CB_PACK_MAX], nchunk[CB_PACK_MAX],
+        SPC[CB_PACK_MAX], TPS[CB_PACK_MAX];
+    int parts;
+};
+__global__ __launch_bounds__(256) void cb_pack_weights_batch_kernel(CbPackTable t) {
+    const int i = blockIdx.y;
+    cb_pack_entry(t.w[i], t.Cout[i], t.Cin[i], t.mode[i], t.nblk[i], t.NT[i], t.nchunk[i], t.SPC[i], t.TPS[i], t.parts, t.amax[i],
+                  t.out[i], (long)blockIdx.x * 256 + threadIdx.x);
 }
 
 
@@ -1556,6 +1577,33 @@ int mdnvae_cb_pack_weights(const float* w, int Cout, int Cin, int kind, int part
     hipLaunchKernelGGL(cb_pack_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w,
                        Cout, Cin, sh.pmode, nblk, sh.NT, sh.kch / 16, sh.SPC, sh.TPS, parts, amax, static_cast<char*>(packed));
     MV_LAUNCH_CHECK("cb_pack_weights_kernel");
+    return 0;
+}
+
+int mdnvae_cb_pack_weights_batch(int n, const float* const* w, const int* Cout, const int* Cin, const int* kind, int parts,
+                                 const unsigned* const* amax, void* const* packed, void* stream) {
+    MV_REQUIRE(n >= 0 && n <= CB_PACK_MAX, E_ARG, "mdnvae_cb_pack_weights_batch: %d layers (at most %d)", n, CB_PACK_MAX);
+    if (n == 0) return 0;
+    MV_REQUIRE(w && Cout && Cin && kind && packed, E_ARG, "mdnvae_cb_pack_weights_batch: null table");
+    MV_REQUIRE(parts == 1 || amax, E_ARG, "mdnvae_cb_pack_weights_batch: two fp16 parts need the tensors' largest magnitudes");
+    CbPackTable t{};
+    t.parts = parts;
+    long most = 0;
+    for (int i = 0; i < n; ++i) {
+        MV_REQUIRE(w[i] && packed[i] && (parts == 1 || amax[i]), E_ARG, "mdnvae_cb_pack_weights_batch: null pointer (layer %d)", i);
+        const size_t bytes = mdnvae_cb_packed_bytes(Cout[i], Cin[i], kind[i], parts);
+        MV_REQUIRE(bytes > 0, E_SHAPE, "mdnvae_cb_pack_weights_batch: unsupported shape (%d -> %d, kind %d, parts %d)", Cin[i], Cout[i],
+                   kind[i], parts);
+        CbShape sh;
+        cb_shape(kind[i], Cout[i], Cin[i], parts, sh);
+        t.w[i] = w[i]; t.amax[i] = amax ? amax[i] : nullptr; t.out[i] = static_cast<char*>(packed[i]);
+        t.Cout[i] = Cout[i]; t.Cin[i] = Cin[i]; t.mode[i] = sh.pmode;
+        t.nblk[i] = (sh.nout + sh.NT * 32 - 1) / (sh.NT * 32);
+        t.NT[i] = sh.NT; t.nchunk[i] = sh.kch / 16; t.SPC[i] = sh.SPC; t.TPS[i] = sh.TPS;
+        if ((long)(bytes / 2) > most) most = (long)(bytes / 2);
+    }
+    hipLaunchKernelGGL(cb_pack_weights_batch_kernel, dim3((unsigned)((most + 255) / 256), n), dim3(256), 0, (hipStream_t)stream, t);
+    MV_LAUNCH_CHECK("cb_pack_weights_batch_kernel");
     return 0;
 }
 

@@ -1544,6 +1544,31 @@ def _cb_pack(w, kind, dev, parts=1, amax=None):
     return out
 
 
+def _cb_pack_many(ws, kinds, dev, parts=1, amaxes=None):
+    """_cb_pack of several layers, 16 to a launch."""
+    import ctypes
+    if len(ws) > 16:
+        return _cb_pack_many(ws[:16], kinds[:16], dev, parts, None if amaxes is None else amaxes[:16]) + \
+            _cb_pack_many(ws[16:], kinds[16:], dev, parts, None if amaxes is None else amaxes[16:])
+    lib = _lib.load()
+    n = len(ws)
+    ws = [_c(w) for w in ws]
+    outs = []
+    for w, k in zip(ws, kinds):
+        ptr(w, "conv weight")
+        nb = lib.mdnvae_cb_packed_bytes(w.shape[0], w.shape[1], k, parts)
+        if nb == 0:
+            raise RuntimeError(f"channel-blocked convolution: unsupported layer {w.shape[1]} -> {w.shape[0]} (kind {k}, parts {parts})")
+        outs.append(torch.empty(nb, dtype=torch.uint8, device=dev))
+    P, I = ctypes.c_void_p * n, ctypes.c_int * n
+    wp, op = P(*[w.data_ptr() for w in ws]), P(*[o.data_ptr() for o in outs])
+    ap = P(*[a.data_ptr() for a in amaxes]) if amaxes is not None and amaxes[0] is not None else None
+    co, ci, kd = I(*[w.shape[0] for w in ws]), I(*[w.shape[1] for w in ws]), I(*kinds)
+    call("mdnvae_cb_pack_weights_batch", n, _addr(wp), _addr(co), _addr(ci), _addr(kd), parts, None if ap is None else _addr(ap),
+         _addr(op), stream())
+    return outs
+
+
 def _slot(t):
     return None if t is None else t.data_ptr()
 
@@ -1661,7 +1686,7 @@ class _ConvEncoderCB(torch.autograd.Function):
             for i in range(nlayers):
                 wmax[i] = rec[i]
                 _absmax(_c(ws[1 + i]).reshape(ws[1 + i].shape[0], -1), wmax[i], reset=False)
-        wf = [_cb_pack(w, k, dev, parts, wm) for w, k, wm in zip(ws[1:], kinds, wmax)]
+        wf = _cb_pack_many(ws[1:], kinds, dev, parts, wmax)
         # fixed scales of the activation tensors
         s1 = _pow2_below(n_nodes) if two else 1.0
         s2 = _pow2_below(G.h2) if two else 1.0
@@ -1714,7 +1739,7 @@ class _ConvEncoderCB(torch.autograd.Function):
         ws = sv[10 + 6 * nres:]                     # weights of layers 1.. (the two stride-2 layers, then the blocks)
         B, dev = x.shape[0], x.device
         H = G.h3
-        wt = [_cb_pack(w, 3 if i < 2 else 2, dev, parts, wmax[i]) for i, w in enumerate(ws)]
+        wt = _cb_pack_many(list(ws), [3 if i < 2 else 2 for i in range(len(ws))], dev, parts, wmax)
         gfeat = _c(gfeat)
         Gs = torch.empty(B, 192, H, H, dtype=torch.float32, device=dev)
         call("mdnvae_maxpool_bwd", ptr(gfeat), ptr(argmax, "argmax", torch.int32), B * 192, H, H, 8, ptr(Gs), stream())
