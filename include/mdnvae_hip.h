@@ -325,9 +325,13 @@ int mdnvae_split_rows_f16_cols(const float* src, long Kd, long R, long ld, int o
                                void* out_rows, void* out_cols, void* stream);
 /* mdnvae_split_cols_dgrad writing two fp16 parts: the gradient of relu(fc11) / relu(fc12) formed from the next
  * layer's (grad_pre, weight) under the gate (function/MM_Gate.py:157-160), scaled by 2^e(*absmax).  *absmax must
- * bound |gpre . w + dense|: mdnvae_dgrad_bound gives such a bound without forming the product. */
+ * bound |gpre . w + dense|: mdnvae_dgrad_bound gives such a bound without forming the product.  absmax_gpre (the
+ * record of |gpre|, or NULL): with it the product itself runs on the 16-bit matrix cores, both factors as two fp16
+ * parts (gpre scaled by its record, each 64-column slice of w by its own largest magnitude; error <= 3 * 2^-22 of
+ * sum |gpre||w|); without it, on the fp32 matrix instruction. */
 int mdnvae_split_cols_dgrad_f16(const float* gpre, const float* w, const float* dense, const float* gate, long Kd, long R,
-                                long J, long row_tile0, const unsigned* absmax, void* out, void* stream);
+                                long J, long row_tile0, const unsigned* absmax, const unsigned* absmax_gpre, void* out,
+                                void* stream);
 /* absmax = max(absmax, |gpre|max * max_c sum_j |w[j][c]| + |dense|max) for w [J][R]: an upper bound of every entry
  * of gpre . w + dense from the two tensors' largest magnitudes (absmax_gpre, absmax_dense or NULL: arrays
  * mdnvae_absmax filled).  A bound some binades above the true maximum only moves the fp16 split's absolute error

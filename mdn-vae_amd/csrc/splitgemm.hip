@@ -411,6 +411,136 @@ __global__ __launch_bounds__(256) void split_cols_dgrad_kernel(const float* __re
     }
 }
 
+// The same pass with the product itself on the 16-bit matrix cores: gpre and the workgroup's w slice as two fp16 parts
+// each (three v_mfma_f32_16x16x32_f16 per multiply-add, error <= 3 * 2^-22 of sum |g||w|, the level of the fp32
+// product above, at under a quarter of its matrix-pipe time).  gpre is scaled by the power of two of its record
+// (amax_g) and split in registers; the w slice by that of its own largest magnitude (found here: output columns
+// belong to one workgroup, so every slice may carry its own scale), split once per workgroup into B fragments in
+// LDS.  Output: two fp16 parts of the result scaled by the record `amax` (a bound of the result).
+template <int J>
+__global__ __launch_bounds__(256) void split_cols_dgrad_f16x2_kernel(const float* __restrict__ gpre, const float* __restrict__ w,
+                                                                    const float* __restrict__ dense,
+                                                                    const float* __restrict__ gate, int Kd, int R,
+                                                                    int row_tile0, int KS, const unsigned* __restrict__ amax,
+                                                                    const unsigned* __restrict__ amax_g, char* __restrict__ out) {
+    static_assert(J % 32 == 0 && J <= 128, "k steps of 32");
+    constexpr int NK = J / 32;
+    const float f16_scale = sg_pow2_scale(sg_absmax(amax));
+    const float sa = sg_pow2_scale(sg_absmax(amax_g));
+    __shared__ __attribute__((aligned(16))) char bfr[2 * NK * 4 * 64 * 16];      // [part][k step][column tile][lane][8 halves]
+    __shared__ float tile[64][65];
+    __shared__ unsigned wmax[4];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int c16 = lane & 15, g = lane >> 4;
+    const int c0 = blockIdx.y * 64;
+    // this thread's B fragments: (k step, column tile) pairs t / 64 + 4 i, lane t % 64: column c0 + 16 ct + c16, k = 32 ks + 8 g ..
+    float wv[NK][8];
+    unsigned m = 0;
+#pragma unroll
+    for (int i = 0; i < NK; ++i) {
+        const int pair = wave + 4 * i, ks = pair >> 2, ct = pair & 3;
+        const int c = c0 + ct * 16 + c16;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float v = c < R ? w[(long)(32 * ks + 8 * g + j) * R + c] : 0.0f;
+            wv[i][j] = v;
+            m = max(m, __float_as_uint(v) & 0x7fffffffu);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+    if (lane == 0) wmax[wave] = m;
+    __syncthreads();
+    const float sw = sg_pow2_scale(max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3])));
+#pragma unroll
+    for (int i = 0; i < NK; ++i) {
+        const int pair = wave + 4 * i;
+        sg_hfrag hi, lo;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float v = wv[i][j] * sw;
+            hi[j] = (_Float16)v;
+            lo[j] = (_Float16)(v - (float)hi[j]);
+        }
+        *reinterpret_cast<sg_hfrag*>(bfr + (pair * 64 + lane) * 16) = hi;
+        *reinterpret_cast<sg_hfrag*>(bfr + ((NK * 4 + pair) * 64 + lane) * 16) = lo;
+    }
+    const float unscale = 1.0f / (sa * sw);
+    const int nrb = (Kd + 63) / 64;
+    // a wave's 16 rows of gpre: lane (row c16, k group g) holds k = 32 ks + 8 g .. + 7 (rows past the end: the last row)
+    sg_f4 a[NK][2];
+    auto load_a = [&](int rb) {
+        const int row = min(rb * 64 + wave * 16 + c16, Kd - 1);
+#pragma unroll
+        for (int ks = 0; ks < NK; ++ks) {
+            a[ks][0] = *reinterpret_cast<const sg_f4*>(gpre + (long)row * J + 32 * ks + 8 * g);
+            a[ks][1] = *reinterpret_cast<const sg_f4*>(gpre + (long)row * J + 32 * ks + 8 * g + 4);
+        }
+    };
+    load_a(blockIdx.x);
+    const int r = t & 31, q = t >> 5;                    // emit: q = (k step within the 64 rows, half)
+    for (int rb = blockIdx.x; rb < nrb; rb += gridDim.x) {
+        const int r0 = rb * 64;
+        float y[2][8], d[2][8];
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int c = c0 + half * 32 + r;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const long at = (long)min(r0 + q * 8 + e, Kd - 1) * R + (c < R ? c : 0);
+                y[half][e] = gate[at];
+                d[half][e] = dense ? dense[at] : 0.0f;
+            }
+        }
+        __syncthreads();                                 // the B fragments are in; the previous block's emit is done
+        sg_f4 acc[4];
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) acc[ct] = sg_f4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int ks = 0; ks < NK; ++ks) {
+            sg_hfrag ah, al;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float v = a[ks][j >> 2][j & 3] * sa;
+                ah[j] = (_Float16)v;
+                al[j] = (_Float16)(v - (float)ah[j]);
+            }
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) {
+                const sg_hfrag bh = *reinterpret_cast<const sg_hfrag*>(bfr + ((ks * 4 + ct) * 64 + lane) * 16);
+                const sg_hfrag bl = *reinterpret_cast<const sg_hfrag*>(bfr + ((NK * 4 + ks * 4 + ct) * 64 + lane) * 16);
+                acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc[ct], 0, 0, 0);
+                acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc[ct], 0, 0, 0);
+                acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc[ct], 0, 0, 0);
+            }
+        }
+        if (rb + (int)gridDim.x < nrb) load_a(rb + gridDim.x);       // the next block's rows, under the emit
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) tile[wave * 16 + 4 * g + rr][ct * 16 + c16] = acc[ct][rr] * unscale;
+        __syncthreads();
+        const int ks = (r0 >> 4) + (q >> 1), h = q & 1;
+        if (ks < KS) {
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int c = c0 + half * 32 + r;
+                if (c0 + half * 32 < R) {
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float gsum = tile[q * 8 + e][half * 32 + r] + d[half][e];
+                        v[e] = (c < R && r0 + q * 8 + e < Kd && y[half][e] > 0.0f) ? gsum : 0.0f;
+                    }
+                    char* dst = out + ((long)(row_tile0 + blockIdx.y * 2 + half) * KS + ks) * SG_STEP + h * 512 + r * 16;
+                    sg_emit_f16(v, f16_scale, dst);
+                }
+            }
+        }
+    }
+}
+
+
 // An upper bound of |gpre . w + dense| over all entries, from the largest magnitudes of gpre and dense and the
 // largest column sum of |w| [J][R]: amax_out = max(itself, |gpre|max * max_c sum_j |w[j][c]| + |dense|max).  A bound
 // a few binades above the true maximum costs the fp16 split nothing that shows (its absolute error is 2^-29 of
@@ -779,7 +909,8 @@ int mdnvae_split_cols(const float* src, long Kd, long R, long ld, long row_tile0
 }
 
 static int split_cols_dgrad_impl(const float* gpre, const float* w, const float* dense, const float* gate, long Kd, long R,
-                                 long J, int parts, long row_tile0, const unsigned* amax, void* out, void* stream) {
+                                 long J, int parts, long row_tile0, const unsigned* amax, void* out, void* stream,
+                                 const unsigned* amax_g = nullptr) {
     MV_REQUIRE(R >= 0 && Kd >= 0 && row_tile0 >= 0, E_ARG, "mdnvae_split_cols_dgrad: bad shape");
     MV_REQUIRE(J == 64 || J == 128, E_SHAPE, "mdnvae_split_cols_dgrad: the inner dimension must be 64 or 128 (got %ld)", J);
     MV_REQUIRE(parts >= 1 && parts <= 3, E_ARG, "mdnvae_split_cols_dgrad: parts must be 1, 2 or 3");
@@ -791,6 +922,17 @@ static int split_cols_dgrad_impl(const float* gpre, const float* w, const float*
     MV_REQUIRE(cb <= 65535, E_SHAPE, "mdnvae_split_cols_dgrad: shape too large for one launch");
     // three workgroups per CU, each keeping its slice of w for all the row blocks it walks
     const long rb = nrb < (768 + cb - 1) / cb ? nrb : (768 + cb - 1) / cb;
+    if (amax_g) {
+        // both factors as fp16 parts: the product on the 16-bit matrix cores
+        if (J == 64)
+            hipLaunchKernelGGL(split_cols_dgrad_f16x2_kernel<64>, dim3((unsigned)rb, (unsigned)cb), dim3(256), 0, (hipStream_t)stream,
+                               gpre, w, dense, gate, (int)Kd, (int)R, (int)row_tile0, (int)KS, amax, amax_g, (char*)out);
+        else
+            hipLaunchKernelGGL(split_cols_dgrad_f16x2_kernel<128>, dim3((unsigned)rb, (unsigned)cb), dim3(256), 0, (hipStream_t)stream,
+                               gpre, w, dense, gate, (int)Kd, (int)R, (int)row_tile0, (int)KS, amax, amax_g, (char*)out);
+        MV_LAUNCH_CHECK("split_cols_dgrad_f16x2_kernel");
+        return 0;
+    }
 #define DG_LAUNCH(JJ)                                                                                                 \
     hipLaunchKernelGGL(split_cols_dgrad_kernel<JJ>, dim3((unsigned)rb, (unsigned)cb), dim3(256), 0, (hipStream_t)stream, \
                        gpre, w, dense, gate, (int)Kd, (int)R, parts, (int)row_tile0, (int)KS, amax, (char*)out)
@@ -807,9 +949,10 @@ int mdnvae_split_cols_dgrad(const float* gpre, const float* w, const float* dens
 }
 
 int mdnvae_split_cols_dgrad_f16(const float* gpre, const float* w, const float* dense, const float* gate, long Kd, long R,
-                                long J, long row_tile0, const unsigned* absmax, void* out, void* stream) {
+                                long J, long row_tile0, const unsigned* absmax, const unsigned* absmax_gpre, void* out,
+                                void* stream) {
     MV_REQUIRE(absmax, E_ARG, "mdnvae_split_cols_dgrad_f16: the largest-magnitude slot is NULL");
-    return split_cols_dgrad_impl(gpre, w, dense, gate, Kd, R, J, 2, row_tile0, absmax, out, stream);
+    return split_cols_dgrad_impl(gpre, w, dense, gate, Kd, R, J, 2, row_tile0, absmax, out, stream, absmax_gpre);
 }
 
 int mdnvae_dgrad_bound(const unsigned* absmax_gpre, const float* w, long J, long R, const unsigned* absmax_dense, int reset,

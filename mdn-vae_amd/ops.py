@@ -767,7 +767,7 @@ class _SymLinearPair(torch.autograd.Function):
             if gpre_next is not None and f16:
                 # the consuming layer left its data gradient as a product: formed here, under the gate
                 call("mdnvae_split_cols_dgrad_f16", ptr(gpre_next), ptr(w_next), ptr(dense), ptr(y), B, H, gpre_next.shape[1],
-                     i * (H // 32), gmax.data_ptr(), pb.data_ptr(), stream())
+                     i * (H // 32), gmax.data_ptr(), mx[2 * i].data_ptr(), pb.data_ptr(), stream())
             elif gpre_next is not None:
                 call("mdnvae_split_cols_dgrad", ptr(gpre_next), ptr(w_next), ptr(dense), ptr(y), B, H, gpre_next.shape[1],
                      parts, i * (H // 32), pb.data_ptr(), stream())

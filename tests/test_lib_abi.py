@@ -71,7 +71,7 @@ def test_two_part_fp16_and_fused_gradient_entry_points_check_their_arguments_wit
     assert lib.mdnvae_split_cols_f16(None, None, 16, 4, 4, 0, 0, None, None, None) < 0 and b"slot" in lib.mdnvae_last_error()
     assert lib.mdnvae_split_gemm_f16(None, None, None, None, 256, 256, 16, 256, 256, None, None, 0, 0, None, None, 256, 256,
                                      256, -1, None) < 0 and b"slot" in lib.mdnvae_last_error()
-    assert lib.mdnvae_split_cols_dgrad_f16(None, None, None, None, 64, 64, 64, 0, None, None, None) < 0
+    assert lib.mdnvae_split_cols_dgrad_f16(None, None, None, None, 64, 64, 64, 0, None, None, None, None) < 0
     assert b"slot" in lib.mdnvae_last_error()
     assert lib.mdnvae_dgrad_bound(None, None, 64, 64, None, 1, None, None) < 0 and b"null" in lib.mdnvae_last_error()
     assert lib.mdnvae_tri_pack_absmax(None, 4, 87, 3840, None, None, 1, None, None) < 0 and b"slot" in lib.mdnvae_last_error()

@@ -228,9 +228,10 @@ def test_weight_gradient_product_from_two_fp16_parts(B, R, H, accumulate, scale_
     assert float((got[R] - want[R]).abs().max() / want[R].abs().max()) <= 2e-6          # the bias gradient row
 
 
+@pytest.mark.parametrize("f16_product", [False, True])
 @pytest.mark.parametrize("with_dense", [False, True])
 @pytest.mark.parametrize("B,H,J", [(1000, 1024, 128), (130, 512, 64)])
-def test_factored_gradient_operand_in_fp16_parts_and_its_bound(B, H, J, with_dense):
+def test_factored_gradient_operand_in_fp16_parts_and_its_bound(B, H, J, with_dense, f16_product):
     """mdnvae_dgrad_bound bounds |gpre . w + dense| from the factors' magnitudes (never below the true maximum,
     at most J times above it); mdnvae_split_cols_dgrad_f16 under that scale writes the operand
     mdnvae_split_cols_f16 writes from the materialised, gated product - to the rounding of the fp32 product itself."""
@@ -250,8 +251,9 @@ def test_factored_gradient_operand_in_fp16_parts_and_its_bound(B, H, J, with_den
     assert true_max <= bound <= (J + 1) * true_max * 4
     Kp = _up(B, 16)
     got, want = _operand(H, Kp), _operand(H, Kp)
-    call("mdnvae_split_cols_dgrad_f16", ptr(gpre), ptr(w), ptr(dense), ptr(gate), B, H, J, 0, mb.data_ptr(), got.data_ptr(),
-         stream())
+    # the product inside the pass: on the fp32 matrix instruction, or (with gpre's record) from two fp16 parts per factor
+    call("mdnvae_split_cols_dgrad_f16", ptr(gpre), ptr(w), ptr(dense), ptr(gate), B, H, J, 0, mb.data_ptr(),
+         mg.data_ptr() if f16_product else None, got.data_ptr(), stream())
     # the same operand from the float64 product rounded to fp32: parts differ only by the fp32 product's own rounding
     full = prod64.float().contiguous()
     call("mdnvae_split_cols_f16", ptr(full), ptr(gate), B, H, H, 0, 0, mb.data_ptr(), want.data_ptr(), stream())
