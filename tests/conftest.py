@@ -35,8 +35,10 @@ def golden():
 
 def pytest_sessionfinish(session, exitstatus):
     """Achieved errors next to the bars in force, for every gradient check that went through
-    recipe.check_grad / recipe.record in this session (gpurun_out/parity_report.md)."""
+    recipe.check_grad / recipe.record in this session (gpurun_out/parity_report.md; parity_report_cpu.md for a
+    session without a GPU, which only checks the oracle)."""
     import recipe
+    import torch
     if not recipe.REPORT:
         return
     out = os.path.join(ROOT, "gpurun_out")
@@ -44,7 +46,7 @@ def pytest_sessionfinish(session, exitstatus):
     groups = {}
     for tag, what, name, achieved, bar, note, noise in recipe.REPORT:
         groups.setdefault((tag, what, note), []).append((name, achieved, bar, noise))
-    with open(os.path.join(out, "parity_report.md"), "w") as f:
+    with open(os.path.join(out, "parity_report.md" if torch.cuda.is_available() else "parity_report_cpu.md"), "w") as f:
         f.write("| fixture / case | path | checks | worst quantity (by achieved / bar) | achieved | bar in force | "
                 "reference's own fp32 run | measure |\n|---|---|---|---|---|---|---|---|\n")
         for (tag, what, note), rows in sorted(groups.items()):
