@@ -538,3 +538,22 @@ def test_blocked_encoder_against_planar_bf16(variant):
         eb = float((b[2][name] - gref).norm() / gref.norm())
         recipe.record(fix, "blocked bf16 encoder vs fp32 mode, gradient L2", name, ea, 1.5 * eb, note=f"planar bf16: {eb:.1e}")
         assert ea <= 1.5 * eb, (name, ea, eb)
+
+
+@pytest.mark.parametrize("parts", [1, 2])
+def test_batched_weight_packing_equals_one_layer_at_a_time(parts):
+    g = torch.Generator().manual_seed(parts)
+    shapes = [(96, 48, 1), (192, 96, 1), (192, 192, 0), (192, 192, 2), (96, 48, 3), (192, 96, 3)]
+    ws = [(torch.randn(co, ci, 3, 3, generator=g) * (0.1 + i)).to(DEV) for i, (co, ci, _) in enumerate(shapes)]
+    kinds = [k for _, _, k in shapes]
+    recs = None
+    if parts == 2:
+        recs = []
+        for w in ws:
+            rec = torch.zeros(ops.ABSMAX_SLOTS, dtype=torch.int32, device=DEV)
+            ops._absmax(w.reshape(w.shape[0], -1), rec, reset=False)
+            recs.append(rec)
+    many = ops._cb_pack_many(ws, kinds, DEV, parts, recs)
+    for i, (w, k) in enumerate(zip(ws, kinds)):
+        one = ops._cb_pack(w, k, DEV, parts, None if recs is None else recs[i])
+        assert torch.equal(many[i], one), i
