@@ -609,8 +609,8 @@ int mdnvae_fid_accumulate(const float* x, const float* shift, long n, int d, flo
 /* mean [d] = shift + sum/n;  cov [d,d] = (gram - sum sum^T/n)/(n-1), float64. */
 int mdnvae_fid_finalize(const double* gram, const double* sum, const float* shift, double n, int d, double* mean,
                         double* cov, void* stream);
-/* Elementwise steps of the coupled Newton-Schulz square root (float64; the products are library
- * GEMMs issued by the host): t = 1.5 I - 0.5 zy;  out = scale * (a + a^T)/2;
+/* Elementwise steps of the coupled Newton-Schulz square root (float64; the products are
+ * mdnvae_dgemm_sym below): t = 1.5 I - 0.5 zy;  out = scale * (a + a^T)/2;
  * out2 = {trace(a), ||a||_F^2} (above 256 rows summed with float64 atomics: the last bits depend on the
  * order of arrival). */
 int mdnvae_ns_residual(const double* zy, int d, double* t, void* stream);
@@ -628,6 +628,11 @@ int mdnvae_trace_norm(const double* a, int d, double* out2, void* stream);
 /* out[0] = max_i sum_j |a_ij|: with the Frobenius norm, the two bounds of the largest eigenvalue the
  * iteration scales by (it needs the spectrum inside (0, 1]; the tighter bound saves iterations). */
 int mdnvae_inf_norm(const double* a, int d, double* out, void* stream);
+/* y = a x (float64, d x d): the matrix-vector product of a few power-iteration steps, whose Rayleigh quotient sits
+ * just under the largest eigenvalue -- a far tighter scale for the iteration than either norm on covariances of
+ * many features (each factor 2.25 of looseness costs one iteration); in place of the scaling inside scipy's sqrtm at
+ * function/VAE_CNN_NN.py:313. */
+int mdnvae_matvec_f64(const double* a, const double* x, int d, double* y, void* stream);
 /* The step of the iteration that yields a square-root FACTOR (Y with Y Y^T = A; no counterpart in the
  * reference, which calls scipy's sqrtm at function/VAE_CNN_NN.py:313): w = Z Y is symmetric up to rounding,
  * t = 1.5 I - 0.25 (w + w^T), and gap[0] = ||I - w||_F^2 (cleared by the call, summed with float64

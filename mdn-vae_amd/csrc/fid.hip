@@ -283,6 +283,19 @@ __global__ __launch_bounds__(256) void inf_norm_kernel(const double* __restrict_
         atomicMax(reinterpret_cast<unsigned long long*>(out), (unsigned long long)__double_as_longlong(best));
 }
 
+// y = a x for a d x d float64 matrix: one wave per row (power iteration for the scale of the Newton-Schulz iteration)
+__global__ __launch_bounds__(256) void matvec_f64_kernel(const double* __restrict__ a, const double* __restrict__ x, int d,
+                                                         double* __restrict__ y) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= d) return;
+    const double* r = a + (long)row * d;
+    double s = 0.0;
+    for (int j = lane; j < d; j += 64) s += r[j] * x[j];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) y[row] = s;
+}
+
 // t = 1.5 I - 0.25 (w + w^T), and gap[0] += sum of (I - w)^2 over this tile (the caller zeroes gap[0]).  One
 // workgroup per 32 x 32 tile, the mirror tile through LDS.
 __global__ __launch_bounds__(256) void ns_residual_gap_kernel(const double* __restrict__ w, int d, double* __restrict__ t,
@@ -622,6 +635,13 @@ int mdnvae_inf_norm(const double* a, int d, double* out, void* stream) {
     MV_REQUIRE(e == hipSuccess, (int)e, "mdnvae_inf_norm: clearing the result failed: %s", hipGetErrorString(e));
     hipLaunchKernelGGL(inf_norm_kernel, dim3(d < 512 ? (unsigned)d : 512u), dim3(256), 0, st, a, d, out);
     MV_LAUNCH_CHECK("inf_norm_kernel");
+    return 0;
+}
+
+int mdnvae_matvec_f64(const double* a, const double* x, int d, double* y, void* stream) {
+    MV_REQUIRE(d >= 1 && a && x && y && x != y, E_ARG, "mdnvae_matvec_f64: bad argument");
+    hipLaunchKernelGGL(matvec_f64_kernel, dim3((unsigned)((d + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a, x, d, y);
+    MV_LAUNCH_CHECK("matvec_f64_kernel");
     return 0;
 }
 

@@ -115,11 +115,35 @@ def _symmetrize(a, scale, out):
     return out
 
 
-def _scaled(a, who):
-    """(a / s symmetrised with the ridge on its diagonal, s): s = min(Frobenius norm, infinity norm), both
-    upper bounds of the largest eigenvalue, so the spectrum of a / s lies in (0, 1] where the iteration
-    converges; on covariances of many weakly correlated features the infinity norm is several times the
-    tighter, which saves about one iteration per factor 2.25.  (None, 0.0) for a zero matrix."""
+_POWER_STEPS = 10
+_POWER_MARGIN = 1.25
+
+
+def _largest_eigenvalue_estimate(a):
+    """Rayleigh quotient of a symmetric PSD matrix after a few power-iteration steps from a fixed, generic start: a
+    lower bound of the largest eigenvalue that is within a factor (1/d)^(1/(2 steps)) of it at worst (0.65 at
+    d = 4624) and within a per cent on covariances."""
+    d = a.shape[0]
+    i = torch.arange(d, dtype=torch.float64, device=a.device)
+    v = 1.0 + 0.5 * torch.sin(0.7 * i)
+    v /= v.norm()
+    w = torch.empty_like(v)
+    for _ in range(_POWER_STEPS):
+        _lib.call("mdnvae_matvec_f64", _lib.ptr(a, "a", torch.float64), _lib.ptr(v, "v", torch.float64), d,
+                  _lib.ptr(w, "w", torch.float64), _lib.stream())
+        n = w.norm()
+        v, w = w / torch.clamp(n, min=1e-300), v
+    _lib.call("mdnvae_matvec_f64", _lib.ptr(a, "a", torch.float64), _lib.ptr(v, "v", torch.float64), d,
+              _lib.ptr(w, "w", torch.float64), _lib.stream())
+    return float(torch.dot(v, w))
+
+
+def _scaled(a, who, tight=True):
+    """(a / s symmetrised with the ridge on its diagonal, s).  s bounds the largest eigenvalue, so that the spectrum
+    of a / s lies where the iteration converges (it needs eigenvalues below 2; every factor 2.25 of looseness costs
+    an iteration): min(Frobenius norm, infinity norm) are rigorous bounds; tight=True takes 1.25 times a
+    power-iteration estimate when that is smaller -- on the covariance of 4624 weakly correlated features the
+    infinity norm is 8 times the largest eigenvalue, 2.6 iterations per root.  (None, 0.0) for a zero matrix."""
     d = a.shape[0]
     out3 = torch.empty(3, dtype=torch.float64, device=a.device)
     _lib.call("mdnvae_trace_norm", _lib.ptr(a, "a", torch.float64), d, _lib.ptr(out3, "out", torch.float64), _lib.stream())
@@ -130,6 +154,10 @@ def _scaled(a, who):
     s = min(sq ** 0.5, inf)
     if s == 0.0:
         return None, 0.0
+    if tight and d >= 64:
+        rho = _largest_eigenvalue_estimate(a)
+        if np.isfinite(rho) and rho > 0.0:
+            s = min(s, _POWER_MARGIN * rho)
     y = _symmetrize(a, 1.0 / s, torch.empty_like(a))
     # ridge: the iteration's Z = Y^-1 is bounded by 1/sqrt(smallest eigenvalue), so on a singular
     # covariance (fewer samples than features, degenerate features) it amplifies rounding noise
@@ -138,24 +166,52 @@ def _scaled(a, who):
     return y, s
 
 
+def _pad16(a, fill=None):
+    """a [d,d] as the leading block of a matrix whose size is the next multiple of 16 (what the float64 matrix-core
+    kernel takes).  fill=None puts the mean of a's diagonal on the added diagonal: the matrix stays block diagonal,
+    so the leading block of its root is the root of a, and the added directions neither slow the iteration down (as
+    null directions would) nor change the conditioning.  fill=0.0 for a factor of a product."""
+    d = a.shape[0]
+    dp = (d + 15) // 16 * 16
+    if dp == d:
+        return a
+    out = torch.zeros(dp, dp, dtype=a.dtype, device=a.device)
+    out[:d, :d] = a
+    if fill is None:
+        fill = float(a.diagonal().sum()) / d
+        fill = fill if np.isfinite(fill) and fill > 0.0 else 0.0
+    if fill:
+        out.diagonal()[d:] = fill
+    return out
+
+
 def sqrtm_psd(a):
     """Principal square root of a symmetric PSD matrix a [d,d] (float64, device).
 
     Coupled Newton-Schulz: with A scaled by a bound ||A|| of its largest eigenvalue, Y0 = A/||A||, Z0 = I,
-    T = (3I - Z Y)/2, Y <- Y T, Z <- T Z; Y -> sqrt(A/||A||).  Iterates are symmetrised every
-    step (rounding otherwise feeds the unstable antisymmetric mode).  The trace of Y rises
+    T = (3I - Z Y)/2, Y <- Y T, Z <- T Z; Y -> sqrt(A/||A||).  The trace of Y rises
     monotonically while eigen-directions are still converging; the loop ends when its change
     drops to rounding level (1e-15 relative) or, once below 1e-9 relative, stops shrinking:
     from there on Z keeps growing in the null space of a singular A and would amplify rounding
     noise, while directions with eigenvalue < 1e-18 ||A|| contribute < 1e-9 to the trace.
-    Returns (sqrt(A), iterations)."""
+    Every product runs on this library's float64 matrix-core kernel (a size that is not a multiple of 16 as the
+    leading block of a padded matrix, see _pad16).  Returns (sqrt(A), iterations)."""
     d = a.shape[0]
-    y, norm = _scaled(a, "sqrtm_psd")
-    if y is None:
-        return torch.zeros_like(a), 0
-    z = torch.eye(d, dtype=torch.float64, device=a.device)
-    y, iters = _newton_schulz_f64(y, z, d)
-    return _symmetrize(y, norm ** 0.5, torch.empty_like(a)), iters
+    ap = _pad16(a)
+    dp = ap.shape[0]
+    for tight in (True, False):
+        y, norm = _scaled(ap, "sqrtm_psd", tight)
+        if y is None:
+            return torch.zeros_like(a), 0
+        z = torch.eye(dp, dtype=torch.float64, device=a.device)
+        try:
+            y, iters = _newton_schulz_f64(y, z, dp)
+            break
+        except FloatingPointError:
+            if not tight:                                 # the rigorous bounds did not help either
+                raise
+    root = _symmetrize(y, norm ** 0.5, torch.empty_like(ap))
+    return (root if dp == d else root[:d, :d].contiguous()), iters
 
 
 def sqrt_factor(a):
@@ -170,27 +226,39 @@ def sqrt_factor(a):
     of the first, so it goes to I quadratically whatever E was, and Y = a Z^T ends with Y Y^T = a to
     float64 rounding.  Y = sqrt(a) Q with Q = exp(K) orthogonal, K antisymmetric of the size of
     sqrt(a) E; tr(sqrt(a) K) = 0, so the trace is off in second order only.  E is fp32 rounding amplified
-    by the cancellation in Z Y (about sqrt(cond(a)) per step): measured trace error 1e-11 at condition 20,
-    3e-6 at condition 1e3; the fp32 phase diverges near condition 1e6 (FloatingPointError).  Singular or
+    by the cancellation in Z Y (about sqrt(cond(a)) per step).  Only the part of E that does not commute with a
+    matters (an unconverged Z~ is still a polynomial in a), so the fp32 phase hands over as soon as the trace moves
+    by less than 1e-3 per step, before the amplified rounding piles up: measured trace error 1e-14 at condition
+    20, 2e-8 at condition 1e3 (2e-5 with a hand-over at 2e-6, and three more iterations in total); the fp32
+    phase diverges near condition 1e6 (FloatingPointError).  Singular or
     badly conditioned covariances need sqrtm_psd.  Below 512 features this is sqrtm_psd.
     Returns (F, iterations)."""
     d = a.shape[0]
     if d < _FAST_MIN_D:
         return sqrtm_psd(a)
-    a1, norm = _scaled(a, "sqrt_factor")
+    ap = _pad16(a)
+    dp = ap.shape[0]
+    a1, norm = _scaled(ap, "sqrt_factor")
     if a1 is None:
         return torch.zeros_like(a), 0
     out2 = torch.empty(2, dtype=torch.float64, device=a.device)
-    z, fast_iters = _newton_schulz_f32(a1, d)
-    y = torch.matmul(a1, z)
-    w, t = torch.empty_like(a1), torch.empty_like(a1)
+    z, fast_iters = _newton_schulz_f32(a1, dp)
+    # every product is a . b^T on this library's kernel, so each iterate is kept with its transpose (the kernel
+    # writes both): y = a1 z and yt = z a1 (both factors symmetric), then z and y drift apart from symmetry
+    new = lambda: torch.empty_like(a1)
+    y, yt = new(), new()
+    _dgemm(a1, z, y, False, 0, yt)
+    zt = z.clone()
+    w, t, y2, yt2, z2, zt2 = (new() for _ in range(6))
     prev, last_delta, iters = None, None, 0
     for iters in range(1, _MAX_ITERS + 1):
-        torch.matmul(z, y, out=w)
-        _lib.call("mdnvae_ns_residual_gap", _lib.ptr(w, "w", torch.float64), d, _lib.ptr(t, "t", torch.float64),
+        _dgemm(z, yt, w, False)                           # w = z y
+        # t = 1.5 I - 0.25 (w + w^T): symmetric to the bit, so it is its own transpose below
+        _lib.call("mdnvae_ns_residual_gap", _lib.ptr(w, "w", torch.float64), dp, _lib.ptr(t, "t", torch.float64),
                   out2.data_ptr(), _lib.stream())
-        y = torch.matmul(y, t)
-        _lib.call("mdnvae_trace", _lib.ptr(y, "y", torch.float64), d, out2[1:].data_ptr(), _lib.stream())
+        _dgemm(y, t, y2, False, 0, yt2)                   # y <- y t
+        y, y2, yt, yt2 = y2, y, yt2, yt
+        _lib.call("mdnvae_trace", _lib.ptr(y, "y", torch.float64), dp, out2[1:].data_ptr(), _lib.stream())
         gap_sq, tr = out2.tolist()
         if not (np.isfinite(tr) and np.isfinite(gap_sq)):
             raise FloatingPointError("sqrt_factor: Newton-Schulz iteration diverged")
@@ -204,8 +272,20 @@ def sqrt_factor(a):
                 break
             last_delta = delta
         prev = tr
-        z = torch.matmul(t, z)
-    return y.mul_(norm ** 0.5), iters + fast_iters
+        _dgemm(t, zt, z2, False, 0, zt2)                  # z <- t z
+        z, z2, zt, zt2 = z2, z, zt2, zt
+    y.mul_(norm ** 0.5)
+    return (y if dp == d else y[:d, :d].contiguous()), iters + fast_iters
+
+
+def _sandwich(xt, s):
+    """x^T s x for xt = x^T [d,d] and a symmetric s [d,d] on the float64 matrix-core kernel: symmetric by its
+    structure, so the second product computes its upper tiles only."""
+    d = xt.shape[0]
+    xp, sp = _pad16(xt, 0.0), _pad16(_symmetrize(s, 1.0, torch.empty_like(s)), 0.0)
+    m = _dgemm(xp, sp, torch.empty_like(sp), False)
+    inner = _dgemm(m, xp, torch.empty_like(sp), True)
+    return inner if xp.shape[0] == d else inner[:d, :d].contiguous()
 
 
 def _dgemm(a, b, out, upper, epilogue=0, out_t=None):
@@ -218,32 +298,21 @@ def _dgemm(a, b, out, upper, epilogue=0, out_t=None):
 
 
 def _newton_schulz_f64(y, z, d):
-    """Coupled iteration in float64 from the pair (y, z) until the trace of y settles.  With d a multiple of 16 the
-    three products of a step run on this library's float64 matrix-core kernel, the last two at half the work of a
+    """Coupled iteration in float64 from the pair (y, z) until the trace of y settles; d a multiple of 16.  The three
+    products of a step run on this library's float64 matrix-core kernel, the last two at half the work of a
     general product: with T = 1.5 I - 0.5 Z Y taken from the product as computed (not symmetrised),
     T^T Y = 1.5 Y - 0.5 Y Z Y and T Z = 1.5 Z - 0.5 Z Y Z are symmetric by their structure, whether or not the
     rounded Y and Z still commute -- so only their upper tiles are computed and mirrored, which also makes the
     iterates symmetric to the bit.  (Mirroring Y T with T from a symmetrised Z Y diverges at condition 1e6: that
-    product is symmetric only through the commutation.)  Other sizes: library GEMMs, symmetrised every step."""
+    product is symmetric only through the commutation.)"""
     out2 = torch.empty(2, dtype=torch.float64, device=y.device)
-    t = torch.empty_like(y)
-    own = d % 16 == 0
-    tt = torch.empty_like(y) if own else None
+    t, tt = torch.empty_like(y), torch.empty_like(y)
     y2, z2 = torch.empty_like(y), torch.empty_like(y)
     prev, last_delta, iters = None, None, 0
     for iters in range(1, _MAX_ITERS + 1):
-        if own:
-            _dgemm(z, y, t, False, 1, tt)                 # t = 1.5 I - 0.5 z y, and its transpose
-            _dgemm(tt, y, y2, True)
-            _dgemm(t, z, z2, True)
-        else:
-            torch.matmul(z, y, out=y2)
-            _lib.call("mdnvae_ns_residual", _lib.ptr(y2, "zy", torch.float64), d, _lib.ptr(t, "t", torch.float64),
-                      _lib.stream())
-            tmp = torch.matmul(y, t)
-            _symmetrize(tmp, 1.0, y2)
-            torch.matmul(t, z, out=tmp)
-            _symmetrize(tmp, 1.0, z2)
+        _dgemm(z, y, t, False, 1, tt)                     # t = 1.5 I - 0.5 z y, and its transpose
+        _dgemm(tt, y, y2, True)
+        _dgemm(t, z, z2, True)
         y, y2, z, z2 = y2, y, z2, z
         tr = _trace(y, out2)
         if not np.isfinite(tr):
@@ -261,6 +330,7 @@ def _newton_schulz_f64(y, z, d):
 _FAST_MIN_D = 512          # below this a float64 GEMM is too small to be worth avoiding
 _FAST_MAX_ITERS = 40
 _FAST_CHECK_EVERY = 2
+_FAST_STOP = 1e-3          # relative change of the trace at which the fp32 phase hands over
 
 
 def _newton_schulz_f32(y64, d):
@@ -309,7 +379,7 @@ def _newton_schulz_f32(y64, d):
                     raise FloatingPointError("sqrtm_psd: Newton-Schulz iteration diverged")
                 if prev is not None:
                     delta = abs(tr - prev)
-                    if delta <= 2e-6 * abs(tr) or (last_delta is not None and delta >= last_delta and delta < 1e-4 * abs(tr)):
+                    if delta <= _FAST_STOP * abs(tr) or (last_delta is not None and delta >= last_delta and delta < 1e-4 * abs(tr)):
                         stop = True
                     last_delta = delta
                 prev = tr
@@ -330,12 +400,8 @@ def fid_from_stats(mu1, sigma1, mu2, sigma2, device="cuda", mixed=False):
         raise ValueError("fid_from_stats: mean/covariance shapes disagree")
     root_of = sqrt_factor if mixed else sqrtm_psd
     f1, _ = root_of(s1)                          # F1 F1^T = S1: eig(S1 S2) = eig(F1^T S2 F1)
-    if not mixed and d % 16 == 0 and d > 0:
-        # the principal root is symmetric: F1 S2 (S2 symmetric), then (F1 S2) F1, a symmetric product
-        s2s = _symmetrize(s2, 1.0, torch.empty_like(s2))
-        inner = _dgemm(_dgemm(f1, s2s, torch.empty_like(s2), False), f1, torch.empty_like(s2), True)
-    else:
-        inner = torch.matmul(torch.matmul(f1.T, s2), f1)
+    # the eigenvalues of S1 S2 are those of F1^T S2 F1; the principal root is its own transpose
+    inner = _sandwich(f1.T.contiguous() if mixed else f1, s2)
     root, _ = root_of(inner)
     out2 = torch.empty(2, dtype=torch.float64, device=s1.device)
     tr1, tr2, trc = (_trace(m, out2) for m in (s1, s2, root))
