@@ -400,9 +400,12 @@ int mdnvae_conv2d_wgrad_bf16(const float* x, const float* in_stats, int relu_in,
                              float* workspace, float* grad_w, int B, int Cin, int H, int W, int Cout, int OH, int OW,
                              int KS, int stride, int pad, int reflect, int parts, void* stream);
 /* Weight gradient of the 7x7 single-channel stem (function/VAE_CNN_NN.py:83-86) with both operands rounded to bf16
- * (fp32 accumulation): the bf16 mode's form of mdnvae_conv2d_wgrad(Cin = 1); same workspace, reflection padding. */
-int mdnvae_conv_stem_wgrad_bf16(const float* x, const float* grad_out, float* workspace, float* grad_w, int B, int H,
-                                int W, int Cout, int KS, int pad, void* stream);
+ * (fp32 accumulation): the bf16 mode's form of mdnvae_conv2d_wgrad(Cin = 1); same workspace, reflection padding.
+ * grad16 = 0: grad_out is fp32 [B][Cout][OH * OW]; 1: bf16 planes [B][Cout][pitch], pitch = OH * OW rounded up to a
+ * multiple of 8 (as mdnvae_cb_norm_bwd leaves them with omode 3) -- the same result, the rounding having moved into
+ * the producer, at half the bytes. */
+int mdnvae_conv_stem_wgrad_bf16(const float* x, const void* grad_out, float* workspace, float* grad_w, int B, int H,
+                                int W, int Cout, int KS, int pad, int grad16, void* stream);
 size_t mdnvae_conv_wgrad_workspace_floats(int B, int Cout, int Cin, int KS);
 /* grad_w [Cout,Cin,KS,KS] = sum_{b,pixels} grad_out x pad(act(x)); same x / in_stats / relu_in
  * / padding conventions as the forward call.  3x3 multi-channel or the 7x7 single-channel stem. */
@@ -498,8 +501,9 @@ int mdnvae_cb_norm_fwd(const void* y, int y16, float* stats, int compute_stats, 
  *     dc = rstd * (dn - mean(dn) - xh * mean(dn * xh)),  xh = (y - mean) * rstd
  * and the result leaves as the operand of the layer's own data / weight gradient (omode 0: zero
  * border of 2, pitch W + 2, H + 4 rows, for kind 2;  omode 1: zero row / column behind, pitch W + 1,
- * for kind 3) or as fp32 planes [B][C][H * W] (omode 2).  gsum [B * C]: plane sums of dc (the
- * convolution-bias gradient before the sum over the batch).
+ * for kind 3), as fp32 planes [B][C][H * W] (omode 2), or as bf16 planes [B][C][PP] with PP >= H * W a multiple
+ * of 8 (omode 3, with g16 = 2: what mdnvae_conv_stem_wgrad_bf16 reads with grad16 = 1).  gsum [B * C]: plane sums
+ * of dc (the convolution-bias gradient before the sum over the batch; summed before any rounding).
  * parts = 2: dc leaves as two fp16 parts scaled by the power of two of the record absmax_dc, the largest |dc|:
  * run the pass once with absmax_probe (a cleared record; nothing else is written) and again with that record as
  * absmax_dc; the same record goes to the products that read dc.  (The exact maximum keeps all 22 bits of the two

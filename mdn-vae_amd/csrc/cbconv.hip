@@ -17,6 +17,7 @@
 // Stride-2 layers (function/VAE_CNN_NN.py:118,124) read four parity planes (space-to-depth): tap (ky, kx) is plane
 // ((ky+1) & 1, (kx+1) & 1) at block offset (ky > 0, kx > 0), so they run on the stride-1 kernel.  Their data gradient
 // is a 2x2-tap stride-1 convolution of the output gradient that writes the four parity planes of the input gradient.
+#include <type_traits>
 #include "common.h"
 #include "../../include/mdnvae_hip.h"
 
@@ -30,6 +31,7 @@ typedef _Float16 cb_h8 __attribute__((ext_vector_type(8)));
 typedef float cb_acc16 __attribute__((ext_vector_type(16)));
 typedef float cb_f4 __attribute__((ext_vector_type(4)));
 typedef float cb_f4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef __bf16 cb_h4u __attribute__((ext_vector_type(4), aligned(2)));
 typedef unsigned cb_u4 __attribute__((ext_vector_type(4)));
 typedef unsigned cb_u2 __attribute__((ext_vector_type(2)));
 
@@ -1183,7 +1185,9 @@ __global__ __launch_bounds__(NT) void cb_norm_bwd_q_kernel(CbNormBwd p) {
 // planes out, gradient gathered from the four parity planes of its stride-2 consumer).  One workgroup per plane; a
 // thread owns KQ (row, four columns) items, loads them with 16- and 8-byte accesses that consecutive lanes make
 // contiguous, keeps them in registers through the two plane sums, and stores 16 bytes per item.
-template <int KQ, typename GT>
+// OT = __bf16: the result leaves rounded to bf16, planes PP entries apart (a multiple of 8, so that the stem's weight
+// gradient -- which rounds this operand to bf16 in any case -- fetches 16 aligned bytes per 8 pixels).
+template <int KQ, typename GT, typename OT>
 __global__ __launch_bounds__(256) void cb_norm_bwd_plane_kernel(CbNormBwd p) {
     __shared__ float red[12];
     const int ch = blockIdx.x, b = blockIdx.y;
@@ -1250,7 +1254,8 @@ __global__ __launch_bounds__(256) void cb_norm_bwd_plane_kernel(CbNormBwd p) {
     const float m1 = ((red[0] + red[1]) + (red[2] + red[3])) * inv;
     const float m2 = ((red[4] + red[5]) + (red[6] + red[7])) * inv;
     float gs = 0.0f;
-    float* op = reinterpret_cast<float*>(p.dc) + pl * HW;
+    constexpr bool O16 = !std::is_same<OT, float>::value;
+    OT* op = reinterpret_cast<OT*>(p.dc) + pl * (O16 ? (long)p.PP : (long)HW);
 #pragma unroll
     for (int k = 0; k < KQ; ++k) {
         const int it = threadIdx.x + 256 * k;
@@ -1263,11 +1268,15 @@ __global__ __launch_bounds__(256) void cb_norm_bwd_plane_kernel(CbNormBwd p) {
             gs += o[j];
         }
         if (it < nitems && c + 3 < p.W) {
-            *reinterpret_cast<cb_f4u*>(op + r * p.W + c) = cb_f4{o[0], o[1], o[2], o[3]};
+            if constexpr (O16) {
+                *reinterpret_cast<cb_h4u*>(op + r * p.W + c) = cb_h4u{(__bf16)o[0], (__bf16)o[1], (__bf16)o[2], (__bf16)o[3]};
+            } else {
+                *reinterpret_cast<cb_f4u*>(op + r * p.W + c) = cb_f4{o[0], o[1], o[2], o[3]};
+            }
         } else if (it < nitems) {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                if (c + j < p.W) op[r * p.W + c + j] = o[j];
+                if (c + j < p.W) op[r * p.W + c + j] = (OT)o[j];
         }
     }
     if (p.gsum) {
@@ -1760,7 +1769,7 @@ int mdnvae_cb_norm_bwd(const void* g, int gmode, int pitch_g, long Qg, const flo
     MV_REQUIRE(B >= 0 && C >= 1 && H >= 3 && W >= 3, E_SHAPE, "mdnvae_cb_norm_bwd: bad shape");
     if (B == 0) return 0;
     MV_REQUIRE(y && stats && (dc || absmax_probe) && (g || gmode == 3), E_ARG, "mdnvae_cb_norm_bwd: null pointer");
-    MV_REQUIRE(gmode >= 0 && gmode <= 3 && omode >= 0 && omode <= 2, E_ARG, "mdnvae_cb_norm_bwd: gmode %d / omode %d", gmode, omode);
+    MV_REQUIRE(gmode >= 0 && gmode <= 3 && omode >= 0 && omode <= 3, E_ARG, "mdnvae_cb_norm_bwd: gmode %d / omode %d", gmode, omode);
     MV_REQUIRE(gmode != 3 || base, E_ARG, "mdnvae_cb_norm_bwd: no gradient source");
     MV_REQUIRE(parts == 1 || parts == 2, E_ARG, "mdnvae_cb_norm_bwd: parts = %d", parts);
     MV_REQUIRE(B <= 65535, E_SHAPE, "mdnvae_cb_norm_bwd: batch %d exceeds the grid limit", B);
@@ -1772,21 +1781,27 @@ int mdnvae_cb_norm_bwd(const void* g, int gmode, int pitch_g, long Qg, const flo
     a.dc = static_cast<char*>(dc);
     a.part_stride = part_stride; a.PP = PP; a.scale = scale; a.gsum = gsum;
     a.amax_dc = absmax_dc; a.amax_probe = absmax_probe;
-    MV_REQUIRE(parts == 1 || omode == 2 || absmax_dc || absmax_probe, E_ARG,
+    MV_REQUIRE(parts == 1 || omode >= 2 || absmax_dc || absmax_probe, E_ARG,
                "mdnvae_cb_norm_bwd: two fp16 parts need the record of the result's largest magnitude (a probe run)");
     a.opitch = omode == 0 ? W + 2 : (omode == 1 ? W + 1 : W);
     hipStream_t st = (hipStream_t)stream;
-    if (omode == 2) {
-        MV_REQUIRE(!y16, E_ARG, "mdnvae_cb_norm_bwd: fp32 planes out take fp32 planes in");
+    if (omode >= 2) {
+        MV_REQUIRE(!y16, E_ARG, "mdnvae_cb_norm_bwd: plain planes out take fp32 planes in");
+        MV_REQUIRE(omode == 2 || (g16 == 2 && PP >= H * W && PP % 8 == 0), E_ARG,
+                   "mdnvae_cb_norm_bwd: bf16 planes out go with bf16 gradient planes in and a plane pitch (PP = %d) that is a "
+                   "multiple of 8 and holds the %d x %d plane", PP, H, W);
         MV_REQUIRE(H * W <= 32 * 256, E_SHAPE, "mdnvae_cb_norm_bwd: plane of %d entries exceeds %d", H * W, 32 * 256);
         const int items = H * ((W + 3) / 4);
         if (gmode == 2 && !base && !sum_out && items <= 8 * 256 && pitch_g >= (W + 1) / 2 + 1 && Qg >= (long)((H + 1) / 2) * pitch_g) {
-            if (g16) {
-                if (items <= 5 * 256) hipLaunchKernelGGL((cb_norm_bwd_plane_kernel<5, __bf16>), dim3(C, B), dim3(256), 0, st, a);
-                else hipLaunchKernelGGL((cb_norm_bwd_plane_kernel<8, __bf16>), dim3(C, B), dim3(256), 0, st, a);
+            if (omode == 3) {
+                if (items <= 5 * 256) hipLaunchKernelGGL((cb_norm_bwd_plane_kernel<5, __bf16, __bf16>), dim3(C, B), dim3(256), 0, st, a);
+                else hipLaunchKernelGGL((cb_norm_bwd_plane_kernel<8, __bf16, __bf16>), dim3(C, B), dim3(256), 0, st, a);
+            } else if (g16) {
+                if (items <= 5 * 256) hipLaunchKernelGGL((cb_norm_bwd_plane_kernel<5, __bf16, float>), dim3(C, B), dim3(256), 0, st, a);
+                else hipLaunchKernelGGL((cb_norm_bwd_plane_kernel<8, __bf16, float>), dim3(C, B), dim3(256), 0, st, a);
             } else {
-                if (items <= 5 * 256) hipLaunchKernelGGL((cb_norm_bwd_plane_kernel<5, float>), dim3(C, B), dim3(256), 0, st, a);
-                else hipLaunchKernelGGL((cb_norm_bwd_plane_kernel<8, float>), dim3(C, B), dim3(256), 0, st, a);
+                if (items <= 5 * 256) hipLaunchKernelGGL((cb_norm_bwd_plane_kernel<5, float, float>), dim3(C, B), dim3(256), 0, st, a);
+                else hipLaunchKernelGGL((cb_norm_bwd_plane_kernel<8, float, float>), dim3(C, B), dim3(256), 0, st, a);
             }
             MV_LAUNCH_CHECK("cb_norm_bwd_plane_kernel");
             return 0;

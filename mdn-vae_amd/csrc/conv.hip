@@ -1490,14 +1490,19 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __r
 // partial [G][Cout][KK]
 // BF16: both operands rounded to bf16 as they leave LDS, v_mfma_f32_32x32x16_bf16 over 16 consecutive pixels of the chunk
 // (an eighth of the matrix instructions of the fp32 form, whose K is 2 pixels).
-template <bool BF16>
+// G16 (with BF16): the output gradient arrives as bf16 planes `gpitch` entries apart (a multiple of 8): a thread fetches 16
+// aligned bytes = 8 pixels of a channel, the tile sits in LDS as bf16 [64][ptw + 8] and an A fragment is one 16-byte read.
+template <bool BF16, bool G16>
 __global__ __launch_bounds__(256) void conv_stem_wgrad_kernel(ConvGeom g, int KS, const float* __restrict__ x,
-                                                              const float* __restrict__ gout, int ptw,
+                                                              const void* __restrict__ gout_any, int gpitch, int ptw,
                                                               int samples_per_group, float* __restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    static_assert(BF16 || !G16, "bf16 gradient planes feed the bf16 product");
+    const float* gout = static_cast<const float*>(gout_any);
+    const __bf16* gout16 = static_cast<const __bf16*>(gout_any);
     const int KK = KS * KS;
-    const int gl_stride = ptw + 1;
-    float* gl = smem;                          // [64][ptw+1]
+    const int gl_stride = G16 ? (ptw + 8) / 2 : ptw + 1;       // in floats
+    float* gl = smem;                          // [64][ptw+1] fp32, or [64][ptw+8] bf16
     float* slab = smem + 64 * gl_stride;       // [slab_stride] (+ one zero word at the end)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, l32 = lane & 31;
     const int P = g.SH * g.SW;
@@ -1522,18 +1527,38 @@ __global__ __launch_bounds__(256) void conv_stem_wgrad_kernel(ConvGeom g, int KS
 
     // The output-gradient tile of a chunk (Cout planes x ptw pixels) is fetched into registers while the previous chunk's
     // MFMAs run, and goes to LDS at the top of its own chunk; channels >= Cout and pixels behind the plane stay zero.
-    constexpr int GE = 64;                                  // tile rows; thread t holds pixel t of every row (ptw = 256)
+    constexpr int GE = G16 ? 1 : 64;                        // tile rows; thread t holds pixel t of every row (ptw = 256)
     float gv[GE];
+    uint4 gq[G16 ? 8 : 1];                                  // G16: pass e holds pixels 8 (t & 31) .. + 7 of row 8 e + (t >> 5)
     const int nper = (P + ptw - 1) / ptw;
     const int nchunks = (b_end - b_begin) * nper;
     auto fetch = [&](int ch) {
         const int b = b_begin + ch / nper, p0 = (ch % nper) * ptw;
+        if constexpr (G16) {
+            const int pp = p0 + 8 * (tid & 31);
 #pragma unroll
-        for (int e = 0; e < GE; ++e) {
-            const int n = e, pp = tid;                          // ptw = 256 = the threads of the workgroup
-            const bool ok = n < g.Cout && p0 + pp < P;
-            const float t = gout[((long)b * g.Cout + (ok ? n : 0)) * P + (ok ? p0 + pp : 0)];
-            gv[e] = ok ? t : 0.0f;
+            for (int e = 0; e < 8; ++e) {
+                const int n = 8 * e + (tid >> 5);
+                const bool ok = n < g.Cout && pp < P;
+                uint4 t = *reinterpret_cast<const uint4*>(gout16 + ((long)b * g.Cout + (ok ? n : 0)) * gpitch + (ok ? pp : 0));
+                // pixels behind the plane (the pitch's slack holds anything) and rows behind Cout are zero
+                const int left = ok ? P - pp : 0;               // valid pixels of this piece
+                unsigned* w = reinterpret_cast<unsigned*>(&t);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (2 * j >= left) w[j] = 0u;
+                    else if (2 * j + 1 >= left) w[j] &= 0xffffu;
+                }
+                gq[e] = t;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < GE; ++e) {
+                const int n = e, pp = tid;                      // ptw = 256 = the threads of the workgroup
+                const bool ok = n < g.Cout && p0 + pp < P;
+                const float t = gout[((long)b * g.Cout + (ok ? n : 0)) * P + (ok ? p0 + pp : 0)];
+                gv[e] = ok ? t : 0.0f;
+            }
         }
     };
     if (nchunks > 0) fetch(0);
@@ -1545,9 +1570,15 @@ __global__ __launch_bounds__(256) void conv_stem_wgrad_kernel(ConvGeom g, int KS
         const int pr0 = a0 * g.S;
         const int slab_elems = nrows * g.IWp;
         __syncthreads();
+        if constexpr (G16) {
 #pragma unroll
-        for (int e = 0; e < GE; ++e) {
-            gl[e * gl_stride + tid] = gv[e];
+            for (int e = 0; e < 8; ++e)
+                *reinterpret_cast<uint4*>(gl + (8 * e + (tid >> 5)) * gl_stride + 4 * (tid & 31)) = gq[e];
+        } else {
+#pragma unroll
+            for (int e = 0; e < GE; ++e) {
+                gl[e * gl_stride + tid] = gv[e];
+            }
         }
         stage_slab<256, 8>(g, x, nullptr, b, 0, 1, 1, pr0, slab_elems, magic_of(slab_elems), slab, tid);
         if (tid == 0) slab[zero_at] = 0.0f;
@@ -1561,9 +1592,14 @@ __global__ __launch_bounds__(256) void conv_stem_wgrad_kernel(ConvGeom g, int KS
                 const int pb = 16 * ks + 8 * h;
                 bf16x8 A[2], Bv[2];
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < 2; ++i) {
+                    if constexpr (G16) {
+                        A[i] = *reinterpret_cast<const bf16x8*>(gl + (i * 32 + l32) * gl_stride + pb / 2);
+                    } else {
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) A[i][j] = (__bf16)gl[(i * 32 + l32) * gl_stride + pb + j];
+                        for (int j = 0; j < 8; ++j) A[i][j] = (__bf16)gl[(i * 32 + l32) * gl_stride + pb + j];
+                    }
+                }
                 int pix = min(P - 1, p0 + pb);
                 int a = fdiv(pix, g.m_sw), bb = pix - a * g.SW;
 #pragma unroll
@@ -1623,13 +1659,30 @@ __global__ __launch_bounds__(256) void conv_stem_wgrad_kernel(ConvGeom g, int KS
     }
 }
 
+// out[i] = sum_z partial[z][i]: a workgroup takes 16 entries, thread t the slices z = t / 16, + 16, ... of entry t % 16
+// (four running sums), and the 16 partial sums of an entry are added in a fixed order.  grid = ceil(n / 16).
 __global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ partial, int G, long n,
                                                            float* __restrict__ out) {
-    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= n) return;
-    float s = 0.0f;
-    for (int z = 0; z < G; ++z) s += partial[(long)z * n + idx];
-    out[idx] = s;
+    __shared__ float red[16][17];
+    const int e = threadIdx.x & 15, z0 = threadIdx.x >> 4;
+    const long idx = (long)blockIdx.x * 16 + e;
+    float s[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (idx < n) {
+        int z = z0;
+        for (; z + 48 < G; z += 64) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) s[u] += partial[(long)(z + 16 * u) * n + idx];
+        }
+        for (int u = 0; z < G; z += 16, ++u) s[u & 3] += partial[(long)z * n + idx];
+    }
+    red[z0][e] = (s[0] + s[1]) + (s[2] + s[3]);
+    __syncthreads();
+    if (threadIdx.x < 16 && idx < n) {
+        float t = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k][threadIdx.x];
+        out[idx] = t;
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1766,8 +1819,8 @@ static int wgrad_groups(int B, int ntiles) {
 }
 
 // weight gradient of the single-channel stem; g: geometry as mdnvae_conv2d_wgrad fills it
-static int stem_wgrad_run(ConvGeom g, int KS, const float* x, const float* grad_out, float* workspace, float* grad_w, bool bf16,
-                          hipStream_t st) {
+static int stem_wgrad_run(ConvGeom g, int KS, const float* x, const void* grad_out, float* workspace, float* grad_w, bool bf16,
+                          hipStream_t st, int gpitch16 = 0) {
     const int B = g.B, Cout = g.Cout, OH = g.SH, OW = g.SW, KK = KS * KS;
     const int Gz0 = wgrad_groups(B, 1);
     const int spg = (B + Gz0 - 1) / Gz0, Gz = (B + spg - 1) / spg;
@@ -1778,16 +1831,19 @@ static int stem_wgrad_run(ConvGeom g, int KS, const float* x, const float* grad_
     const size_t red = (size_t)4 * 64 * 65 * 4;
     if (lds < red) lds = red;
     MV_REQUIRE(lds <= 160 * 1024, E_SHAPE, "mdnvae_conv2d_wgrad: needs %zu bytes of LDS", lds);
-    if (bf16) {
-        set_lds_limit(reinterpret_cast<const void*>(conv_stem_wgrad_kernel<true>));
-        hipLaunchKernelGGL(conv_stem_wgrad_kernel<true>, dim3(1, 1, Gz), dim3(256), lds, st, g, KS, x, grad_out, ptw, spg, workspace);
+    if (gpitch16) {
+        set_lds_limit(reinterpret_cast<const void*>(conv_stem_wgrad_kernel<true, true>));
+        hipLaunchKernelGGL((conv_stem_wgrad_kernel<true, true>), dim3(1, 1, Gz), dim3(256), lds, st, g, KS, x, grad_out, gpitch16, ptw, spg, workspace);
+    } else if (bf16) {
+        set_lds_limit(reinterpret_cast<const void*>(conv_stem_wgrad_kernel<true, false>));
+        hipLaunchKernelGGL((conv_stem_wgrad_kernel<true, false>), dim3(1, 1, Gz), dim3(256), lds, st, g, KS, x, grad_out, 0, ptw, spg, workspace);
     } else {
-        set_lds_limit(reinterpret_cast<const void*>(conv_stem_wgrad_kernel<false>));
-        hipLaunchKernelGGL(conv_stem_wgrad_kernel<false>, dim3(1, 1, Gz), dim3(256), lds, st, g, KS, x, grad_out, ptw, spg, workspace);
+        set_lds_limit(reinterpret_cast<const void*>(conv_stem_wgrad_kernel<false, false>));
+        hipLaunchKernelGGL((conv_stem_wgrad_kernel<false, false>), dim3(1, 1, Gz), dim3(256), lds, st, g, KS, x, grad_out, 0, ptw, spg, workspace);
     }
     MV_LAUNCH_CHECK("conv_stem_wgrad_kernel");
     const long n = (long)Cout * KK;
-    hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, workspace, Gz, n, grad_w);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, st, workspace, Gz, n, grad_w);
     MV_LAUNCH_CHECK("sum_partials_kernel");
     return 0;
 }
@@ -2085,8 +2141,9 @@ static void launch_wgrad_bf16(const WgradBf16& p, dim3 grid, size_t lds, const f
     hipLaunchKernelGGL((conv_wgrad_bf16_kernel<S, PARTS, RW>), grid, dim3(256), lds, st, p, x, stats, grad_out, workspace);
 }
 
-extern "C" int mdnvae_conv_stem_wgrad_bf16(const float* x, const float* grad_out, float* workspace, float* grad_w, int B, int H,
-                                           int W, int Cout, int KS, int pad, void* stream) {
+extern "C" int mdnvae_conv_stem_wgrad_bf16(const float* x, const void* grad_out, float* workspace, float* grad_w, int B, int H,
+                                           int W, int Cout, int KS, int pad, int grad16, void* stream) {
+    MV_REQUIRE(grad16 == 0 || grad16 == 1, E_ARG, "mdnvae_conv_stem_wgrad_bf16: grad16 = %d", grad16);
     MV_REQUIRE(B >= 1 && H >= 1 && W >= 1, E_ARG, "mdnvae_conv_stem_wgrad_bf16: bad size");
     MV_REQUIRE(x && grad_out && workspace && grad_w, E_ARG, "mdnvae_conv_stem_wgrad_bf16: null pointer");
     MV_REQUIRE(KS == 7 && Cout <= 64 && pad < H && pad < W, E_SHAPE, "mdnvae_conv_stem_wgrad_bf16: 7x7 stem with at most 64 output channels");
@@ -2097,7 +2154,8 @@ extern "C" int mdnvae_conv_stem_wgrad_bf16(const float* x, const float* grad_out
     g.osy = g.osx = 1;
     g.S = 1; g.pad = pad; g.reflect = 1; g.relu_in = 0; g.KHe = KS;
     finish_geom(g, KS);
-    return stem_wgrad_run(g, KS, x, grad_out, workspace, grad_w, true, (hipStream_t)stream);
+    return stem_wgrad_run(g, KS, x, grad_out, workspace, grad_w, true, (hipStream_t)stream,
+                          grad16 ? (g.SH * g.SW + 7) / 8 * 8 : 0);
 }
 
 extern "C" int mdnvae_conv2d_wgrad_bf16(const float* x, const float* in_stats, int relu_in, const float* grad_out,

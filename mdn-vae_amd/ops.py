@@ -1322,11 +1322,15 @@ class _ConvLayer:
 
 
 def _stem_wgrad_bf16(layer, x, gout, B):
-    """The stem's weight gradient with both operands rounded to bf16 (the bf16 mode)."""
+    """The stem's weight gradient with both operands rounded to bf16 (the bf16 mode); gout fp32 [B,C,H,W] or bf16
+    [B,C,pitch] as the instance-norm backward pass leaves it with omode 3."""
     ws = torch.empty(_lib.load().mdnvae_conv_wgrad_workspace_floats(B, layer.cout, 1, layer.ks), dtype=torch.float32, device=x.device)
     gw = torch.empty(layer.cout, 1, layer.ks, layer.ks, dtype=torch.float32, device=x.device)
-    call("mdnvae_conv_stem_wgrad_bf16", ptr(x), ptr(gout), ptr(ws), ptr(gw), B, layer.h, layer.h, layer.cout, layer.ks, layer.pad,
-         stream())
+    g16 = gout.dtype == torch.bfloat16
+    if g16 and gout.shape[-1] != (layer.oh * layer.oh + 7) // 8 * 8:
+        raise RuntimeError("bf16 stem gradient planes must be (output plane rounded up to a multiple of 8) entries apart")
+    call("mdnvae_conv_stem_wgrad_bf16", ptr(x), ptr(gout, "stem output gradient", gout.dtype), ptr(ws), ptr(gw), B, layer.h, layer.h,
+         layer.cout, layer.ks, layer.pad, int(g16), stream())
     return gw
 
 
@@ -1624,13 +1628,17 @@ def _cb_norm_bwd(g, gmode, pitch_g, y, stats, pitch_y, relu, C, H, W, omode, PP,
     if omode == 2:
         dc = torch.empty(B, C, H, W, dtype=torch.float32, device=dev)
         ps = 0
+    elif omode == 3:                     # bf16 planes, PP = H * W rounded up to a multiple of 8 apart
+        PP = (H * W + 7) // 8 * 8
+        dc = torch.empty(B, C, PP, dtype=torch.bfloat16, device=dev)
+        ps = 0
     else:
         dc, ps = _cb_alloc(C // 8, B, PP, dev, parts)
     gsum = torch.empty(B, C, dtype=torch.float32, device=dev)
     so = torch.empty(B, C, H, W, dtype=torch.float32, device=dev) if want_sum else None
     y16 = y.dtype == torch.float16
     g16 = 2 if g is not None and g.dtype == torch.bfloat16 else 0
-    p_ = 1 if omode == 2 else parts
+    p_ = 1 if omode >= 2 else parts
     args = (None if g is None else ptr(g, "gradient planes", g.dtype), gmode, pitch_g, Qg, ptr(base), ptr(so),
             ptr(y, "raw conv output", y.dtype), int(y16), ptr(stats), pitch_y, Qy,
             int(relu), B, C, H, W, omode, dc.data_ptr(), ps, PP, p_, 1.0, ptr(gsum))
@@ -1791,7 +1799,7 @@ class _ConvEncoderCB(torch.autograd.Function):
         gb[1] = _colsum(gs)
         gw[1] = _cb_wgrad(dc2, a1, B, 96, 48, 4, G.pp_d2, G.pp_a1, G.k_2, G.p2, parts, 1.0 / s1, pd, p1, dmax)
         da1 = _cb_conv(dc2, pd, wt[0], None, B, 96, 48, 3, G.h2, G.p2, G.pp_d2, out16=g16, parts=parts, amax_a=dmax, amax_w=wmax[0])
-        g_r1, _, gs, _ = _cb_norm_bwd(da1, 2, G.p2, raw1, st1, n, True, 48, n, n, 2, 0)
+        g_r1, _, gs, _ = _cb_norm_bwd(da1, 2, G.p2, raw1, st1, n, True, 48, n, n, 2 if two else 3, 0)
         gb[0] = _colsum(gs)
         stem = _ConvLayer(1, 48, 7, 1, 3, True, n)
         gw[0] = stem.wgrad(x.view(B, 1, n, n), None, 0, g_r1, B) if two else _stem_wgrad_bf16(stem, _c(x.view(B, 1, n, n)), g_r1, B)

@@ -438,6 +438,12 @@ def test_norm_backward_pass_with_bf16_gradient_planes(C, H, gmode, omode):
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     if base is not None:
         assert torch.equal(outs[0][2], outs[1][2])
+    if stem:
+        # omode 3: the same result rounded to bf16, planes a multiple of 8 apart; plane sums taken before the rounding
+        dc16, _, gsum16, _ = ops._cb_norm_bwd(gt, gmode, pitch_g, y, st, pitch_y, True, C, H, H, 3, 0)
+        assert dc16.dtype == torch.bfloat16 and dc16.shape == (B, C, ops._ru(H * H, 8))
+        assert torch.equal(dc16[:, :, :H * H], outs[0][0].reshape(B, C, H * H).to(torch.bfloat16))
+        assert torch.equal(gsum16, outs[0][1])
 
 
 def unblock2(buf, part_stride, groups, B, PP, scale):

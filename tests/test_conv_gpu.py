@@ -488,3 +488,9 @@ def test_stem_weight_gradient_on_bf16_operands(n, B):
     assert _rel(got, w.grad) <= 1e-5
     full = stem.wgrad(x.to(DEV), None, 0, gout.to(DEV), B)
     assert float((got - full).norm() / full.norm()) <= 1e-2
+    # the same gradient handed over as bf16 planes a multiple of 8 apart (the slack holds NaNs): the rounding has only
+    # moved into the producer, so the result is the same to the bit
+    pitch = (n * n + 7) // 8 * 8
+    g16 = torch.full((B, 48, pitch), float("nan"), dtype=torch.bfloat16)
+    g16[:, :, :n * n] = gout.reshape(B, 48, n * n).to(torch.bfloat16)
+    assert torch.equal(ops._stem_wgrad_bf16(stem, x.to(DEV), g16.to(DEV), B), got)
