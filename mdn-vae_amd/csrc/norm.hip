@@ -275,6 +275,62 @@ __global__ __launch_bounds__(256) void maxpool_fwd_wave_kernel(const float* __re
     }
 }
 
+// K = 8 with 2 x 2 windows (planes of 16 .. 23 rows and columns, the encoder's 22 x 22 and 17 x 17): one wave per plane.
+// Lane l scans row l / 4, columns 4 (l % 4) .. + 3 of the covered 16 x 16 corner -- a wave load touches whole 64-byte
+// row pieces -- and the 16 lanes of a window (lane bit 5 = window row, bit 1 = window column) reduce by exchanges over
+// bits 0, 2, 3, 4.  Same result as the serial scan: the first maximum in row-major order, NaNs never win.
+__global__ __launch_bounds__(256) void maxpool8_plane_kernel(const float* __restrict__ x, long nplanes, int H, int W,
+                                                             float* __restrict__ feat, int* __restrict__ argmax) {
+    const long plane = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (plane >= nplanes) return;
+    const int lane = threadIdx.x & 63;
+    const int first = (lane >> 2) * W + (lane & 3) * 4;
+    const float* p = x + plane * (long)H * W + first;
+    float best = -INFINITY;
+    int bi = first;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float v = p[j];
+        if (v > best) {
+            best = v;
+            bi = first + j;
+        }
+    }
+#pragma unroll
+    for (int o = 1; o <= 16; o = o == 1 ? 4 : o * 2) {
+        const float ov = __shfl_xor(best, o);
+        const int oi = __shfl_xor(bi, o);
+        if (ov > best || (ov == best && oi < bi)) {
+            best = ov;
+            bi = oi;
+        }
+    }
+    if ((lane & 0x1d) == 0) {
+        const long w = plane * 4 + (lane >> 5) * 2 + ((lane >> 1) & 1);
+        feat[w] = best;
+        argmax[w] = bi;
+    }
+}
+
+// its backward: one wave per plane writes the plane, zero except at the four recorded positions
+__global__ __launch_bounds__(256) void maxpool8_bwd_plane_kernel(const float* __restrict__ gfeat, const int* __restrict__ argmax,
+                                                                 long nplanes, int P, float* __restrict__ gx) {
+    const long plane = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (plane >= nplanes) return;
+    const int lane = threadIdx.x & 63;
+    const int4 am = *reinterpret_cast<const int4*>(argmax + plane * 4);
+    const float4 gf = *reinterpret_cast<const float4*>(gfeat + plane * 4);
+    float* o = gx + plane * (long)P;
+    for (int e = lane; e < P; e += 64) {
+        float v = 0.0f;
+        if (e == am.x) v = gf.x;
+        if (e == am.y) v = gf.y;
+        if (e == am.z) v = gf.z;
+        if (e == am.w) v = gf.w;
+        o[e] = v;
+    }
+}
+
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ gfeat, const int* __restrict__ argmax,
                                                           long nplanes, int H, int W, int K, int PH, int PW,
                                                           float* __restrict__ gx) {
@@ -400,7 +456,10 @@ int mdnvae_maxpool_fwd(const float* x, long nplanes, int H, int W, int K, float*
     MV_REQUIRE(x && feat && argmax, E_ARG, "mdnvae_maxpool_fwd: null pointer");
     const int PH = H / K, PW = W / K;
     const long n = nplanes * PH * PW;
-    if (K * K <= 64 && (n + 3) / 4 <= 0x7fffffffL)
+    if (K == 8 && PH == 2 && PW == 2 && (nplanes + 3) / 4 <= 0x7fffffffL)
+        hipLaunchKernelGGL(maxpool8_plane_kernel, dim3((unsigned)((nplanes + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x,
+                           nplanes, H, W, feat, argmax);
+    else if (K * K <= 64 && (n + 3) / 4 <= 0x7fffffffL)
         hipLaunchKernelGGL(maxpool_fwd_wave_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x,
                            nplanes, H, W, K, PH, PW, feat, argmax);
     else
@@ -415,8 +474,12 @@ int mdnvae_maxpool_bwd(const float* grad_feat, const int* argmax, long nplanes, 
     MV_REQUIRE(nplanes >= 0 && K >= 1 && H >= K && W >= K, E_ARG, "mdnvae_maxpool_bwd: bad size");
     if (nplanes == 0) return 0;
     MV_REQUIRE(grad_feat && argmax && grad_x, E_ARG, "mdnvae_maxpool_bwd: null pointer");
-    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(ew_grid(nplanes * H * W)), dim3(256), 0, (hipStream_t)stream, grad_feat,
-                       argmax, nplanes, H, W, K, H / K, W / K, grad_x);
+    if (K == 8 && H / K == 2 && W / K == 2 && (nplanes + 3) / 4 <= 0x7fffffffL)
+        hipLaunchKernelGGL(maxpool8_bwd_plane_kernel, dim3((unsigned)((nplanes + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                           grad_feat, argmax, nplanes, H * W, grad_x);
+    else
+        hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(ew_grid(nplanes * H * W)), dim3(256), 0, (hipStream_t)stream, grad_feat,
+                           argmax, nplanes, H, W, K, H / K, W / K, grad_x);
     MV_LAUNCH_CHECK("maxpool_bwd_kernel");
     return 0;
 }

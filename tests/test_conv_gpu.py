@@ -210,6 +210,43 @@ def test_maxpool_forward_backward():
         assert torch.equal(gx.cpu(), xd.grad.float())
 
 
+@pytest.mark.parametrize("H,K", [(16, 8), (23, 8), (22, 4), (22, 11)])
+def test_maxpool_ties_and_nans(H, K):
+    """All three forward kernels (one wave per plane, one wave per window, serial scan) on planes full of ties and
+    with NaNs: the value and the recorded position are those of the serial row-major scan of each window (first
+    maximum; a NaN never wins; a window of NaNs gives -inf at its first position)."""
+    g = torch.Generator().manual_seed(H * K)
+    nplanes = 7
+    x = torch.randint(0, 4, (nplanes, H, H), generator=g).float()
+    x[torch.rand(nplanes, H, H, generator=g) < 0.05] = float("nan")
+    x[3, :K, :K] = float("nan")
+    PH = H // K
+    feat = torch.empty(nplanes * PH * PH, device=DEV)
+    arg = torch.empty(nplanes * PH * PH, dtype=torch.int32, device=DEV)
+    ops.call("mdnvae_maxpool_fwd", ops.ptr(x.to(DEV)), nplanes, H, H, K, ops.ptr(feat), arg.data_ptr(), ops.stream())
+    xn = x.numpy()
+    want_v, want_i = [], []
+    for p in range(nplanes):
+        for py in range(PH):
+            for px in range(PH):
+                best, bi = -np.inf, (py * K) * H + px * K
+                for dy in range(K):
+                    for dx in range(K):
+                        v = xn[p, py * K + dy, px * K + dx]
+                        if v > best:
+                            best, bi = v, (py * K + dy) * H + px * K + dx
+                want_v.append(best)
+                want_i.append(bi)
+    assert np.array_equal(feat.cpu().numpy(), np.array(want_v, dtype=np.float32))
+    assert np.array_equal(arg.cpu().numpy(), np.array(want_i, dtype=np.int32))
+    cot = torch.randn(nplanes * PH * PH, generator=g)
+    gx = torch.full((nplanes, H, H), float("nan"), device=DEV)
+    ops.call("mdnvae_maxpool_bwd", ops.ptr(cot.to(DEV)), arg.data_ptr(), nplanes, H, H, K, ops.ptr(gx), ops.stream())
+    want = torch.zeros(nplanes, H * H)
+    want.view(-1)[torch.arange(nplanes).repeat_interleave(PH * PH) * H * H + torch.tensor(want_i)] = cot
+    assert torch.equal(gx.cpu().view(nplanes, -1), want)
+
+
 def _check_grads(fix, model, skip_prefix=()):
     for name, p in model.named_parameters():
         if any(name.startswith(s) for s in skip_prefix):
