@@ -624,9 +624,19 @@ int mdnvae_ns_residual(const double* zy, int d, double* t, void* stream);
  * tiles on or above the diagonal are computed only and every value is written to (i, j) and (j, i) -- half the
  * work, and a result symmetric to the bit.  (Not for products that are symmetric only because the factors commute:
  * rounding breaks the commutation, and the mirrored copy keeps the commutator where an average would cancel it.)
- * epilogue 1: c = 1.5 I - 0.5 a b.  c_transposed (upper = 0; may be NULL): the transpose of c, written as well. */
+ * epilogue 1: c = 1.5 I - 0.5 a b.  c_transposed (upper = 0; may be NULL): the transpose of c, written as well.
+ * skip (may be NULL): a device word; the call does nothing if it is non-zero when the kernel starts (state + 4 of
+ * mdnvae_ns_state_step: products queued behind the end of the iteration). */
 int mdnvae_dgemm_sym(const double* a, const double* b, int d, int upper, int epilogue, double* c, double* c_transposed,
-                     void* stream);
+                     const double* skip, void* stream);
+/* The iteration's stopping rule on the device (the reference's sqrtm decides inside scipy; here the host queues
+ * several iterations and reads the state once per batch): called once per iteration with the new Y.  state [8]
+ * (zeroed before the first iteration): [0] previous trace, [1] previous change of the trace, [2] / [3] whether they
+ * exist, [4] 0 running / 1 settled / 2 diverged (a non-finite trace or gap), [5] iterations counted, [6] the last
+ * trace.  Settled: the trace moved by at most 1e-15 relative, or by less than 1e-9 relative and no less than the
+ * step before; or gap (may be NULL; gap[0] = ||I - Z Y||_F^2 from mdnvae_ns_residual_gap) is at most 1e-12.
+ * Calls after the end leave the state as it is. */
+int mdnvae_ns_state_step(const double* y, int d, const double* gap, double* state, void* stream);
 int mdnvae_symmetrize(const double* a, int d, double scale, double* out, void* stream);
 int mdnvae_trace_norm(const double* a, int d, double* out2, void* stream);
 /* out[0] = max_i sum_j |a_ij|: with the Frobenius norm, the two bounds of the largest eigenvalue the

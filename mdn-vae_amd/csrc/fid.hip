@@ -333,6 +333,45 @@ __global__ __launch_bounds__(256) void trace_f64_kernel(const double* __restrict
     if (threadIdx.x == 0) out[0] = t;
 }
 
+// The end-of-iteration rule of the float64 iteration, kept on the device so that the host can queue several iterations
+// and look once.  state: [0] previous trace, [1] previous change, [2] / [3] whether those exist, [4] 0 running /
+// 1 settled / 2 diverged, [5] iterations counted, [6] last trace.  One iteration = one call; calls after the end do nothing.
+// gap (may be null): ||I - Z Y||_F^2 of the step just taken; at or below 1e-12 the step has landed at rounding level.
+__global__ __launch_bounds__(256) void ns_state_step_kernel(const double* __restrict__ y, int d, const double* __restrict__ gap,
+                                                            double* __restrict__ state) {
+    __shared__ double red[4];
+    if (state[4] != 0.0) return;
+    double t = 0.0;
+    for (int i = threadIdx.x; i < d; i += 256) t += y[(long)i * d + i];
+    t = block_sum<256, double>(t, red);
+    if (threadIdx.x != 0) return;
+    state[5] += 1.0;
+    state[6] = t;
+    const double gsq = gap ? gap[0] : 1.0;
+    const bool finite = fabs(t) <= 1.7976931348623157e308 && fabs(gsq) <= 1.7976931348623157e308;     // false for NaN too
+    if (!finite) {
+        state[4] = 2.0;
+        return;
+    }
+    if (gap && gsq <= 1e-12) {
+        state[4] = 1.0;
+        return;
+    }
+    if (state[2] != 0.0) {
+        const double delta = fabs(t - state[0]);
+        // the trace rises monotonically while directions still converge: settled at rounding level, or -- once below
+        // 1e-9 relative -- no longer shrinking (a singular matrix: from there on Z only amplifies rounding noise)
+        if (delta <= 1e-15 * fabs(t) || (state[3] != 0.0 && delta >= state[1] && delta < 1e-9 * fabs(t))) {
+            state[4] = 1.0;
+            return;
+        }
+        state[1] = delta;
+        state[3] = 1.0;
+    }
+    state[0] = t;
+    state[2] = 1.0;
+}
+
 // ---- fp32 steps of the coupled Newton-Schulz iteration on padded matrices [d][ld] (ld a multiple of 32;
 // columns d .. ld-1 are kept zero: they are the k padding of the split-bf16 products that form Z Y, Y T, T Z) ----
 // kind 0: out = 1.5 I - 0.5 a;  kind 1: out = scale (a + a^T) / 2.  One workgroup per 32 x 32 tile; the
@@ -400,8 +439,10 @@ constexpr int DG_T = 128, DG_K = 16, DG_LD = 17;
 
 template <bool UPPER, int EPI>
 __global__ __launch_bounds__(512) void dgemm_nt_kernel(const double* __restrict__ A, const double* __restrict__ B,
-                                                       double* __restrict__ C, double* __restrict__ CT, int d, int nt) {
+                                                       double* __restrict__ C, double* __restrict__ CT, int d, int nt,
+                                                       const double* __restrict__ skip) {
     __shared__ double sm[2][2][DG_T * DG_LD];          // [buffer][A, B][row][k]
+    if (skip && skip[0] != 0.0) return;                // the iteration has ended on the device: the queued rest is void
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave >> 2, wn = wave & 3;           // 2 x 4 waves of 64 x 32: two waves per SIMD, which a lone
                                                        // workgroup needs to keep the matrix pipe busy
@@ -657,7 +698,7 @@ int mdnvae_ns_residual_gap(const double* w, int d, double* t, double* gap, void*
 }
 
 int mdnvae_dgemm_sym(const double* a, const double* b, int d, int upper, int epilogue, double* c, double* c_transposed,
-                     void* stream) {
+                     const double* skip, void* stream) {
     MV_REQUIRE(d >= 0 && d % 16 == 0, E_SHAPE, "mdnvae_dgemm_sym: d = %d is not a multiple of 16", d);
     MV_REQUIRE(epilogue == 0 || epilogue == 1, E_ARG, "mdnvae_dgemm_sym: epilogue %d", epilogue);
     if (d == 0) return 0;
@@ -669,12 +710,12 @@ int mdnvae_dgemm_sym(const double* a, const double* b, int d, int upper, int epi
     hipStream_t st = (hipStream_t)stream;
     if (upper) {
         dim3 grid((unsigned)(nt * (nt + 1) / 2));
-        if (epilogue) hipLaunchKernelGGL((dgemm_nt_kernel<true, 1>), grid, dim3(512), 0, st, a, b, c, c_transposed, d, nt);
-        else hipLaunchKernelGGL((dgemm_nt_kernel<true, 0>), grid, dim3(512), 0, st, a, b, c, c_transposed, d, nt);
+        if (epilogue) hipLaunchKernelGGL((dgemm_nt_kernel<true, 1>), grid, dim3(512), 0, st, a, b, c, c_transposed, d, nt, skip);
+        else hipLaunchKernelGGL((dgemm_nt_kernel<true, 0>), grid, dim3(512), 0, st, a, b, c, c_transposed, d, nt, skip);
     } else {
         dim3 grid((unsigned)(nt * nt));
-        if (epilogue) hipLaunchKernelGGL((dgemm_nt_kernel<false, 1>), grid, dim3(512), 0, st, a, b, c, c_transposed, d, nt);
-        else hipLaunchKernelGGL((dgemm_nt_kernel<false, 0>), grid, dim3(512), 0, st, a, b, c, c_transposed, d, nt);
+        if (epilogue) hipLaunchKernelGGL((dgemm_nt_kernel<false, 1>), grid, dim3(512), 0, st, a, b, c, c_transposed, d, nt, skip);
+        else hipLaunchKernelGGL((dgemm_nt_kernel<false, 0>), grid, dim3(512), 0, st, a, b, c, c_transposed, d, nt, skip);
     }
     MV_LAUNCH_CHECK("dgemm_nt_kernel");
     return 0;
@@ -684,6 +725,13 @@ int mdnvae_trace(const double* a, int d, double* out, void* stream) {
     MV_REQUIRE(d >= 1 && a && out, E_ARG, "mdnvae_trace: bad argument");
     hipLaunchKernelGGL(trace_f64_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, a, d, out);
     MV_LAUNCH_CHECK("trace_f64_kernel");
+    return 0;
+}
+
+int mdnvae_ns_state_step(const double* y, int d, const double* gap, double* state, void* stream) {
+    MV_REQUIRE(d >= 1 && y && state, E_ARG, "mdnvae_ns_state_step: bad argument");
+    hipLaunchKernelGGL(ns_state_step_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, y, d, gap, state);
+    MV_LAUNCH_CHECK("ns_state_step_kernel");
     return 0;
 }
 

@@ -241,40 +241,32 @@ def sqrt_factor(a):
     a1, norm = _scaled(ap, "sqrt_factor")
     if a1 is None:
         return torch.zeros_like(a), 0
-    out2 = torch.empty(2, dtype=torch.float64, device=a.device)
     z, fast_iters = _newton_schulz_f32(a1, dp)
     # every product is a . b^T on this library's kernel, so each iterate is kept with its transpose (the kernel
     # writes both): y = a1 z and yt = z a1 (both factors symmetric), then z and y drift apart from symmetry
     new = lambda: torch.empty_like(a1)
-    y, yt = new(), new()
-    _dgemm(a1, z, y, False, 0, yt)
-    zt = z.clone()
-    w, t, y2, yt2, z2, zt2 = (new() for _ in range(6))
-    prev, last_delta, iters = None, None, 0
-    for iters in range(1, _MAX_ITERS + 1):
-        _dgemm(z, yt, w, False)                           # w = z y
+    ys, yts, zs, zts = [new(), new()], [new(), new()], [z, new()], [z.clone(), new()]     # iterate k in [k % 2]
+    _dgemm(a1, z, ys[0], False, 0, yts[0])
+    w, t = new(), new()
+    state = _IterationState(a.device)
+    gap = torch.empty(1, dtype=torch.float64, device=a.device)
+    iters = 0
+    for k in range(_MAX_ITERS):
+        i, j = k % 2, (k + 1) % 2
+        _dgemm(zs[i], yts[i], w, False, state=state.rec)                   # w = z y
         # t = 1.5 I - 0.25 (w + w^T): symmetric to the bit, so it is its own transpose below
         _lib.call("mdnvae_ns_residual_gap", _lib.ptr(w, "w", torch.float64), dp, _lib.ptr(t, "t", torch.float64),
-                  out2.data_ptr(), _lib.stream())
-        _dgemm(y, t, y2, False, 0, yt2)                   # y <- y t
-        y, y2, yt, yt2 = y2, y, yt2, yt
-        _lib.call("mdnvae_trace", _lib.ptr(y, "y", torch.float64), dp, out2[1:].data_ptr(), _lib.stream())
-        gap_sq, tr = out2.tolist()
-        if not (np.isfinite(tr) and np.isfinite(gap_sq)):
-            raise FloatingPointError("sqrt_factor: Newton-Schulz iteration diverged")
-        # the step just taken squares the gap ||I - W|| (times 3/4): from 1e-6 it lands at rounding level
-        if gap_sq <= 1e-12:
-            break
-        if prev is not None:                     # singular a: the rule of sqrtm_psd
-            delta = abs(tr - prev)
-            if delta <= 1e-15 * abs(tr) or (last_delta is not None and delta >= last_delta
-                                            and delta < 1e-9 * abs(tr)):
+                  gap.data_ptr(), _lib.stream())
+        _dgemm(ys[i], t, ys[j], False, 0, yts[j], state.rec)               # y <- y t
+        # the step just taken squares the gap ||I - W|| (times 3/4): from 1e-6 it lands at rounding level, which
+        # ends the iteration; a singular a ends it by the rule of sqrtm_psd
+        state.step(ys[j], gap)
+        _dgemm(t, zts[i], zs[j], False, 0, zts[j], state.rec)              # z <- t z
+        if (k + 1) % 2 == 0 or k + 1 == _MAX_ITERS:
+            ended, iters = state.look("sqrt_factor")
+            if ended:
                 break
-            last_delta = delta
-        prev = tr
-        _dgemm(t, zt, z2, False, 0, zt2)                  # z <- t z
-        z, z2, zt, zt2 = z2, z, zt2, zt
-    y.mul_(norm ** 0.5)
+    y = ys[iters % 2].mul_(norm ** 0.5)
     return (y if dp == d else y[:d, :d].contiguous()), iters + fast_iters
 
 
@@ -288,13 +280,38 @@ def _sandwich(xt, s):
     return inner if xp.shape[0] == d else inner[:d, :d].contiguous()
 
 
-def _dgemm(a, b, out, upper, epilogue=0, out_t=None):
+def _dgemm(a, b, out, upper, epilogue=0, out_t=None, state=None):
     """out = a b on the float64 matrix instruction (b symmetric; upper: the product is symmetric by its structure and
-    only its upper tiles are computed; out_t also receives the transpose); d must be a multiple of 16."""
+    only its upper tiles are computed; out_t also receives the transpose); d must be a multiple of 16.  state: the
+    record of _IterationState; the product is void once the iteration it belongs to has ended."""
     d = a.shape[0]
     _lib.call("mdnvae_dgemm_sym", _lib.ptr(a, "a", torch.float64), _lib.ptr(b, "b", torch.float64), d, int(upper), int(epilogue),
-              _lib.ptr(out, "out", torch.float64), _lib.ptr(out_t, "out_t", torch.float64), _lib.stream())
+              _lib.ptr(out, "out", torch.float64), _lib.ptr(out_t, "out_t", torch.float64),
+              None if state is None else state[4:].data_ptr(), _lib.stream())
     return out
+
+
+_QUEUE_AHEAD = 4           # iterations queued between two looks at the device's stopping record
+
+
+class _IterationState:
+    """The stopping rule of the float64 iteration, kept on the device (mdnvae_ns_state_step): the host queues
+    _QUEUE_AHEAD iterations at a time and reads the record once per batch; what was queued behind the end of the
+    iteration does nothing (the products and the rule check the record when they start)."""
+
+    def __init__(self, device):
+        self.rec = torch.zeros(8, dtype=torch.float64, device=device)
+
+    def step(self, y, gap=None):
+        _lib.call("mdnvae_ns_state_step", _lib.ptr(y, "y", torch.float64), y.shape[0],
+                  None if gap is None else gap.data_ptr(), self.rec.data_ptr(), _lib.stream())
+
+    def look(self, who):
+        """(ended, iterations counted so far)"""
+        done, iters = self.rec[4:6].tolist()
+        if done == 2.0:
+            raise FloatingPointError(f"{who}: Newton-Schulz iteration diverged")
+        return done != 0.0, int(iters)
 
 
 def _newton_schulz_f64(y, z, d):
@@ -305,26 +322,21 @@ def _newton_schulz_f64(y, z, d):
     rounded Y and Z still commute -- so only their upper tiles are computed and mirrored, which also makes the
     iterates symmetric to the bit.  (Mirroring Y T with T from a symmetrised Z Y diverges at condition 1e6: that
     product is symmetric only through the commutation.)"""
-    out2 = torch.empty(2, dtype=torch.float64, device=y.device)
+    state = _IterationState(y.device)
     t, tt = torch.empty_like(y), torch.empty_like(y)
-    y2, z2 = torch.empty_like(y), torch.empty_like(y)
-    prev, last_delta, iters = None, None, 0
-    for iters in range(1, _MAX_ITERS + 1):
-        _dgemm(z, y, t, False, 1, tt)                     # t = 1.5 I - 0.5 z y, and its transpose
-        _dgemm(tt, y, y2, True)
-        _dgemm(t, z, z2, True)
-        y, y2, z, z2 = y2, y, z2, z
-        tr = _trace(y, out2)
-        if not np.isfinite(tr):
-            raise FloatingPointError("sqrtm_psd: Newton-Schulz iteration diverged")
-        if prev is not None:
-            delta = abs(tr - prev)
-            if delta <= 1e-15 * abs(tr) or (last_delta is not None and delta >= last_delta
-                                            and delta < 1e-9 * abs(tr)):
+    ys, zs = [y, torch.empty_like(y)], [z, torch.empty_like(y)]      # iterate k lives in ys[k % 2], zs[k % 2]
+    iters = 0
+    for k in range(_MAX_ITERS):
+        y, z, y2, z2 = ys[k % 2], zs[k % 2], ys[(k + 1) % 2], zs[(k + 1) % 2]
+        _dgemm(z, y, t, False, 1, tt, state.rec)          # t = 1.5 I - 0.5 z y, and its transpose
+        _dgemm(tt, y, y2, True, state=state.rec)
+        _dgemm(t, z, z2, True, state=state.rec)
+        state.step(y2)
+        if (k + 1) % _QUEUE_AHEAD == 0 or k + 1 == _MAX_ITERS:
+            ended, iters = state.look("sqrtm_psd")
+            if ended:
                 break
-            last_delta = delta
-        prev = tr
-    return y, iters
+    return ys[iters % 2], iters
 
 
 _FAST_MIN_D = 512          # below this a float64 GEMM is too small to be worth avoiding

@@ -131,6 +131,50 @@ def test_eigenvalue_estimate_and_its_fallback(M):
     assert np.linalg.norm(got @ got - a) / np.linalg.norm(a) < 1e-9
 
 
+def test_stopping_rule_on_the_device():
+    """mdnvae_ns_state_step against the rule written out on the host, on trace sequences that end each way: settled
+    at rounding level, stalled below 1e-9, a landed gap, a non-finite trace; calls after the end change nothing, and
+    a product given the ended record leaves its output alone."""
+    from mdnvae_amd import fid, _lib
+
+    def host_rule(traces, gaps):
+        prev = last = None
+        for n, (tr, gap) in enumerate(zip(traces, gaps), 1):
+            if not (np.isfinite(tr) and (gap is None or np.isfinite(gap))):
+                return 2.0, n
+            if gap is not None and gap <= 1e-12:
+                return 1.0, n
+            if prev is not None:
+                delta = abs(tr - prev)
+                if delta <= 1e-15 * abs(tr) or (last is not None and delta >= last and delta < 1e-9 * abs(tr)):
+                    return 1.0, n
+                last = delta
+            prev = tr
+        return 0.0, len(traces)
+
+    cases = [([1.0, 1.5, 1.75, 1.75, 9.0], None), ([1.0, 2.0, 2.0 + 1e-10, 2.0 + 3e-10, 5.0], None),
+             ([1.0, 1.2, 1.3], [1e-3, 1e-13, 1e-30]), ([1.0, float("nan"), 2.0], None), ([1.0, 2.0, 3.0], [1.0, float("inf"), 0.5]),
+             ([1.0, 2.0, 3.0, 4.5], None)]
+    for traces, gaps in cases:
+        state = fid._IterationState("cuda")
+        gap = torch.zeros(1, dtype=torch.float64, device="cuda")
+        for n, tr in enumerate(traces):
+            y = torch.diag(torch.tensor([tr - 0.25, 0.25, 0.0], dtype=torch.float64)).cuda()
+            if gaps is not None:
+                gap.fill_(gaps[n])
+            state.step(y, gap if gaps is not None else None)
+        done, iters = state.rec[4:6].tolist()
+        assert (done, int(iters)) == host_rule(traces, gaps if gaps is not None else [None] * len(traces)), (traces, gaps)
+    ended = fid._IterationState("cuda")
+    ended.rec[4] = 1.0
+    a = torch.eye(16, dtype=torch.float64, device="cuda")
+    out = torch.full((16, 16), 7.0, dtype=torch.float64, device="cuda")
+    fid._dgemm(a, a, out, False, state=ended.rec)
+    assert float(out.min()) == 7.0
+    fid._dgemm(a, a, out, False, state=fid._IterationState("cuda").rec)
+    assert torch.equal(out, a)
+
+
 def _psd(d, floor, rng):
     if floor > 0:
         q, _ = np.linalg.qr(rng.standard_normal((d, d)))
