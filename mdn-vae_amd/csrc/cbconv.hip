@@ -31,6 +31,8 @@ typedef _Float16 cb_h8 __attribute__((ext_vector_type(8)));
 typedef float cb_acc16 __attribute__((ext_vector_type(16)));
 typedef float cb_f4 __attribute__((ext_vector_type(4)));
 typedef float cb_f4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef float cb_f2 __attribute__((ext_vector_type(2)));
+typedef float cb_f2u __attribute__((ext_vector_type(2), aligned(4)));
 typedef __bf16 cb_h4u __attribute__((ext_vector_type(4), aligned(2)));
 typedef unsigned cb_u4 __attribute__((ext_vector_type(4)));
 typedef unsigned cb_u2 __attribute__((ext_vector_type(2)));
@@ -585,9 +587,46 @@ __global__ __launch_bounds__(256) void cb_norm_fwd_kernel(CbNormFwd p) {
         yp[e] = static_cast<const float*>(p.y) + pl * p.Qy;
     }
     const unsigned mop = (unsigned)(0x100000000ull / (unsigned)p.opitch) + 1u;
+    if (p.mode == 1 && !p.skip && !p.stream_out) {
+        // The four parity planes of a position take the four pixels of one 2 x 2 block: both pixels of a block row
+        // come from one 8-byte load per channel, so every byte of y is requested once (two 4-byte loads at stride 8
+        // relied on the first-level cache for the partner and fetched 1.4 times the planes).  A block that ends on
+        // the last column loads one pixel to the left instead and takes the second half.
+        for (int pos = threadIdx.x; pos < p.PP; pos += 256) {
+            const int pr = (int)__umulhi((unsigned)pos, mop), pc = pos - pr * p.opitch;
+            const int r0 = 2 * (pr - 1), c0 = 2 * (pc - 1);
+            const bool inside = pr >= 1 && pc >= 1 && r0 < p.H && c0 < p.W;
+            const bool pair = c0 + 1 < p.W;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int r = r0 + half;
+                const bool ok = inside && r < p.H;
+                const int src = ok ? r * p.pitch_y + (pair ? c0 : c0 - 1) : 0;
+                float v[2][8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const cb_f2 t = *reinterpret_cast<const cb_f2u*>(yp[e] + src);
+                    float t0 = ((pair ? t[0] : t[1]) - mean[e]) * rstd[e];
+                    float t1 = (t[1] - mean[e]) * rstd[e];
+                    if (p.relu) {
+                        t0 = fmaxf(t0, 0.0f);
+                        t1 = fmaxf(t1, 0.0f);
+                    }
+                    v[0][e] = ok ? t0 : 0.0f;
+                    v[1][e] = ok && pair ? t1 : 0.0f;
+                }
+                if (p.act) {
+#pragma unroll
+                    for (int par = 0; par < 2; ++par) {
+                        const long gp = (long)(g8 >> 1) * 8 + (half * 2 + par) * 2 + (g8 & 1);      // [chunk][plane][k half]
+                        cb_store8<PARTS>(v[par], p.scale, p.act + ((gp * p.B + b) * p.PP + pos) * 16, p.part_stride);
+                    }
+                }
+            }
+        }
+        return;
+    }
     const int nplanes = p.mode == 1 ? 4 : 1;
-    // the four parity planes of a position take the four pixels of one 2 x 2 block: they are written from one visit
-    // of the position, so that every line of y is fetched once (a loop over planes outside fetched it four times)
     for (int pos = threadIdx.x; pos < p.PP; pos += 256) {
         const int pr = (int)__umulhi((unsigned)pos, mop), pc = pos - pr * p.opitch;
         for (int plane = 0; plane < nplanes; ++plane) {
