@@ -212,7 +212,8 @@ ABI_TAGS = {
                                  if a[2] >= CHAIN_ROWS_MIN_B else "chain_fwd_mfma_kernel"),
                            lambda a: _decoder_work(a, 0)),
     "mdnvae_decoder_bwd": (lambda a: "outer_grad_kernel+chain_bwd_mfma_kernel" if a[16] is not None
-                           else (("chain_bwd_rows_kernel" if a[3] >= CHAIN_ROWS_MIN_B else "chain_bwd_saved_kernel")
+                           else ((("chain_bwd_regs_kernel" if a[7] <= 4 and a[13] is None and a[14] == 0 and a[-2] is not None
+                                   else "chain_bwd_rows_kernel") if a[3] >= CHAIN_ROWS_MIN_B else "chain_bwd_saved_kernel")
                                  if a[-3] else "chain_bwd_mfma_kernel"),
                            lambda a: _decoder_work(a, 1)),
     "mdnvae_adam_step": ("adam_kernel", lambda a: 28.0 * a[4]),

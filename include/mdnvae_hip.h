@@ -159,8 +159,10 @@ size_t mdnvae_decoder_bwd_rows_floats(int B, int R, int NL);
  * vectors (columns >= N zero), and the walk starts from it.
  * layer_in_saved != 0: layer_in already holds the rows written by mdnvae_decoder_fwd for the same
  * z and weights (used when there is no dropout multiplier; otherwise the chain is recomputed).
- * grad_z_parts (optional, [R,B,L] workspace): lets a small batch (at most 4096 samples) run one
- * workgroup per (tile, channel) on that path; the per-channel parts are added in channel order. */
+ * grad_z_parts (optional, [R,B,L] workspace): lets that path give a workgroup one channel -- a small batch (at
+ * most 4096 samples) runs one workgroup per (tile, channel), a large one (8192 samples and more, at most 4
+ * layers, no x_latent) keeps the channel's panels in LDS and the gradients in registers; the per-channel parts
+ * are added in channel order. */
 int mdnvae_decoder_bwd(const float* z, const float* wt, const float* wn, int B, int N, int L, int R, int NL,
                        int acts, int epi_act, const float* icpt_w, const float* icpt_b, int do_exp,
                        const float* drop, int xlat_channels, int components, const float* grad_out, const float* grad_xlat,

@@ -1199,6 +1199,128 @@ __global__ __launch_bounds__(256) void chain_bwd_rows_kernel(DecArgs a, const fl
     }
 }
 
+// The backward twin of chain_fwd_regs_kernel (large batches, saved layer inputs, no dropout, no x_latent).  With the
+// product transposed, dX^T = W dPre^T, the gradient of a layer's output sits in the accumulators as features
+// 16 ct + 4 g + r of sample c16 -- the layout in which the layer's saved output and the pre-activation gradient are 16
+// contiguous bytes of their rows in memory (no trip through LDS), and, under the permuted reduction order, the B
+// operand of the product with the layer's [n][k] panel.  A workgroup serves one channel and keeps its NL panels in LDS;
+// the latent gradient of a channel goes to dz_parts [R][B][L], which add_parts_kernel sums in channel order.
+__global__ __launch_bounds__(512) void chain_bwd_regs_kernel(DecArgs a, const float* __restrict__ wn,
+                                                             const float* __restrict__ dnode, const float* __restrict__ hin,
+                                                             const float* __restrict__ nodes, float* __restrict__ dz_parts,
+                                                             float* __restrict__ dp) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, nwaves = blockDim.x >> 6;
+    const int c16 = lane & 15, g = lane >> 4;
+    const int r_ch = blockIdx.y;
+    const int N = a.N, NL = a.NL;
+    {
+        const float* src = wn + (long)r_ch * NL * CR_PANEL;
+        constexpr int PER = NP * (KP / 4) / 512 + 1;
+        for (int l = 0; l < NL; ++l) {
+            f32x4_t v[PER];
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                const int idx = t + i * 512;
+                if (idx < NP * (KP / 4)) v[i] = *reinterpret_cast<const f32x4_t*>(src + (long)l * CR_PANEL + idx * 4);
+            }
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                const int idx = t + i * 512;
+                const int row = idx / (KP / 4), q = idx - row * (KP / 4);
+                if (idx < NP * (KP / 4)) *reinterpret_cast<f32x4_t*>(smem + (l * NP + row) * CG_LD + 4 * q) = v[i];
+            }
+        }
+    }
+    __syncthreads();
+    const int ntiles = (a.B + CR_ROWS - 1) / CR_ROWS;
+    const int t_lo = (int)((long)ntiles * blockIdx.x / gridDim.x), t_hi = (int)((long)ntiles * (blockIdx.x + 1) / gridDim.x);
+    for (int tile = t_lo + wave; tile < t_hi; tile += nwaves) {
+        const int b = tile * CR_ROWS + c16;
+        const bool live = b < a.B;
+        const long bb = live ? b : 0;
+        f32x4_t dh[6];
+#pragma unroll
+        for (int ct = 0; ct < 6; ++ct) dh[ct] = *reinterpret_cast<const f32x4_t*>(dnode + (bb * a.R + r_ch) * NP + 16 * ct + 4 * g);
+        // a layer's saved output: the node vectors, or the input rows of the layer above; fetched one layer ahead, under
+        // the product of the layer above
+        f32x4_t hn[6];
+        auto fetch_h = [&](int l) {
+            const float* hsrc = l == NL - 1 ? nodes + (bb * a.R + r_ch) * NP : hin + ((long)(r_ch * NL + l + 1) * a.B + bb) * KP;
+#pragma unroll
+            for (int ct = 0; ct < 6; ++ct) hn[ct] = *reinterpret_cast<const f32x4_t*>(hsrc + 16 * ct + 4 * g);
+        };
+        fetch_h(NL - 1);
+        for (int l = NL - 1; l >= 0; --l) {
+            const int step = r_ch * NL + l;
+            f32x4_t h[6];
+#pragma unroll
+            for (int ct = 0; ct < 6; ++ct) h[ct] = hn[ct];
+            if (l > 0) fetch_h(l - 1);
+            auto slope = [&](auto act_tag) {
+                constexpr int ACT = decltype(act_tag)::value;
+#pragma unroll
+                for (int ct = 0; ct < 6; ++ct)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float v = dh[ct][r] * act_slope(ACT, h[ct][r]);
+                        h[ct][r] = 16 * ct + 4 * g + r < N ? v : 0.0f;
+                    }
+            };
+            switch (layer_act(a.acts, l)) {
+                case ACT_SIGMOID: slope(std::integral_constant<int, ACT_SIGMOID>{}); break;
+                case ACT_TANH: slope(std::integral_constant<int, ACT_TANH>{}); break;
+                default: slope(std::integral_constant<int, ACT_NONE>{}); break;
+            }
+            if (live) {
+#pragma unroll
+                for (int ct = 0; ct < 6; ++ct)
+                    *reinterpret_cast<f32x4_t*>(dp + ((long)step * a.B + b) * NP + 16 * ct + 4 * g) = h[ct];
+            }
+            // gradient of the layer's input: rows of the [n][k] panel are the reduction index, read in the order (ct, r, g)
+            f32x4_t acc[6];
+#pragma unroll
+            for (int it = 0; it < 6; ++it) acc[it] = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
+            const float* pan = smem + l * NP * CG_LD + 4 * g * CG_LD + c16;
+            float wv[2][24];
+            auto load_w = [&](int ct, float (&w)[24]) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int it = 0; it < 6; ++it) w[r * 6 + it] = pan[(16 * ct + r) * CG_LD + it * 16];
+            };
+            load_w(0, wv[0]);
+#pragma unroll
+            for (int ct = 0; ct < 6; ++ct) {
+                if (ct + 1 < 6) load_w(ct + 1, wv[(ct + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int it = 0; it < 6; ++it)
+                        acc[it] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[ct & 1][r * 6 + it], h[ct][r], acc[it], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int it = 0; it < 6; ++it) dh[it] = acc[it];
+        }
+        if (live) {
+            float* dst = dz_parts + ((long)r_ch * a.B + b) * a.L;
+#pragma unroll
+            for (int it = 0; it < 6; ++it) {
+                const int f = 16 * it + 4 * g;
+                if (f + 3 < a.L && (a.L & 3) == 0) {
+                    *reinterpret_cast<f32x4_t*>(dst + f) = dh[it];
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (f + r < a.L) dst[f + r] = dh[it][r];
+                }
+            }
+        }
+    }
+}
+
 // out[i] = sum_p part[p][i] in index order (the per-channel partial latent gradients)
 __global__ __launch_bounds__(256) void add_parts_kernel(const float* __restrict__ part, int parts, long n,
                                                         float* __restrict__ out) {
@@ -1475,6 +1597,24 @@ int mdnvae_decoder_bwd(const float* z, const float* wt, const float* wn, int B, 
     }
     MV_LAUNCH_CHECK("outer_grad_kernel");
     const int ntiles = (B + CH_TS - 1) / CH_TS;
+    if (layer_in_saved && !drop && B >= CR_TS * 128 && NL <= CG_MAXL && xlat_channels == 0 && grad_z_parts) {
+        // large batches of the plain chain: gradients in registers, one channel per workgroup
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(chain_bwd_regs_kernel),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        MV_REQUIRE(e == hipSuccess, (int)e, "mdnvae_decoder_bwd: cannot raise the LDS limit: %s", hipGetErrorString(e));
+        const size_t regs_lds = sizeof(float) * (size_t)NL * NP * CG_LD;
+        const int tiles16 = (B + CR_ROWS - 1) / CR_ROWS;
+        int gx = 256 / R;
+        if (gx < 1) gx = 1;
+        if (gx * 8 > tiles16) gx = (tiles16 + 7) / 8;
+        hipLaunchKernelGGL(chain_bwd_regs_kernel, dim3(gx, R), dim3(512), regs_lds, st, a, wn, node_grad, layer_in, nodes,
+                           grad_z_parts, layer_dpre);
+        MV_LAUNCH_CHECK("chain_bwd_regs_kernel");
+        const long nz = (long)B * L;
+        hipLaunchKernelGGL(add_parts_kernel, dim3((unsigned)((nz + 255) / 256)), dim3(256), 0, st, grad_z_parts, R, nz, grad_z);
+        MV_LAUNCH_CHECK("add_parts_kernel");
+        return 0;
+    }
     if (layer_in_saved && !drop && B >= CR_TS * 128) {
         {
             const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(chain_bwd_rows_kernel),

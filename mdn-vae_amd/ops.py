@@ -1168,9 +1168,8 @@ class _ChainDecoder(torch.autograd.Function):
         hin = saved_hin if saved_hin is not None else torch.empty(RL, B, DEC_KP, dtype=torch.float32, device=dev)
         dp = torch.empty(RL, B, DEC_NP, dtype=torch.float32, device=dev)
         gz = torch.empty_like(z)
-        # small batches: workspace for one partial latent gradient per channel
-        gz_parts = torch.empty(spec.R, B, spec.L, dtype=torch.float32, device=dev) \
-            if (saved_hin is not None and B <= 4096 and spec.R > 1) else None
+        # workspace for one partial latent gradient per channel (the forms that give a workgroup one channel)
+        gz_parts = torch.empty(spec.R, B, spec.L, dtype=torch.float32, device=dev) if saved_hin is not None else None
         ga = torch.empty_like(gout) if icpt_w is not None else None
         if spec.nodes_only:                      # gout is the gradient of the node vectors themselves
             node_grad, gout = gout, None
