@@ -1,7 +1,7 @@
 """profiles/*_counters.csv (tools/profile_bench.sh) -> a table of matrix-pipe utilisation and fabric traffic per kernel."""
 import csv, sys
 
-out = ["# Matrix-pipe utilisation and fabric traffic from rocprofv3 counters (round 3)", "",
+out = ["# Matrix-pipe utilisation and fabric traffic from rocprofv3 counters", "",
        "One `--pmc` pass each for FETCH_SIZE, WRITE_SIZE and the SQ / GRBM counters (`tools/profile_bench.sh`), values per launch.",
        "busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs): share of SIMD-cycles, at the clock actually held, with the",
        "matrix pipe busy.  read = FETCH_SIZE x 2 (the gfx950 correction of the microarchitecture guide), write = WRITE_SIZE, in MB.", "",
