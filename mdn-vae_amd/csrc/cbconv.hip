@@ -1232,55 +1232,55 @@ __global__ __launch_bounds__(256) void cb_norm_bwd_plane_kernel(CbNormBwd p) {
     const int ch = blockIdx.x, b = blockIdx.y;
     const int HW = p.H * p.W;
     const long pl = (long)b * p.C + ch;
-    const int wq = (p.W + 3) >> 2;                      // column quads per row
-    const int nitems = p.H * wq;
-    const unsigned mwq = (unsigned)(0x100000000ull / (unsigned)wq) + 1u;
+    const int wqw = p.W >> 2, tailn = p.W & 3;          // whole column quads per row, columns behind them
+    const int nwhole = p.H * wqw, nitems = nwhole + (tailn ? p.H : 0);
+    const unsigned mwq = (unsigned)(0x100000000ull / (unsigned)wqw) + 1u;
     const float* yp = static_cast<const float*>(p.y) + pl * p.Qy;
     const GT* gq = static_cast<const GT*>(p.g) + ((long)b * 4 * p.C + ch) * p.Qg;       // parity plane k: + k * C * Qg
-    const long gps = (long)p.C * p.Qg;
+    const int gps = p.C * (int)p.Qg;                    // (the host checks that four of these fit 31 bits)
     const float mean = p.stats[2 * pl], rstd = p.stats[2 * pl + 1];
     const float shift = -mean * rstd;
+    // Items: first the whole quads (row, columns 4 q .. 4 q + 3), then one tail item per row for the W % 4 columns behind
+    // them -- so that a wave holds items of one kind (but for one wave at the seam) and neither kind pays for the other's
+    // branches.  Slots behind the last item hold zeros and add nothing to the sums.
+    typedef GT g2u __attribute__((ext_vector_type(2), aligned(sizeof(GT))));
     float dn[KQ][4], xh[KQ][4];
 #pragma unroll
     for (int k = 0; k < KQ; ++k) {
         const int it = threadIdx.x + 256 * k;
-        const int r = (int)__umulhi((unsigned)it, mwq), c = (it - r * wq) * 4;
-        const bool in = it < nitems;
-        const bool whole = in && c + 3 < p.W;
 #pragma unroll
         for (int j = 0; j < 4; ++j) dn[k][j] = xh[k][j] = 0.0f;
-        if (whole) {
-            const cb_f4 t = *reinterpret_cast<const cb_f4u*>(yp + r * p.pitch_y + c);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) xh[k][j] = t[j];
-        } else if (in) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (c + j < p.W) xh[k][j] = yp[r * p.pitch_y + c + j];
-        }
-        if (in) {
+        if (it < nwhole) {
+            const int r = (int)__umulhi((unsigned)it, mwq), c = (it - r * wqw) * 4;
+            const cb_f4 t = *reinterpret_cast<const cb_f4u*>(yp + (unsigned)(r * p.pitch_y + c));
             // columns c, c + 2 come from the even-column plane of this row's parity, c + 1, c + 3 from the odd one
-            const GT* g0 = gq + ((r & 1) * 2) * gps + (r >> 1) * p.pitch_g + (c >> 1);
-            dn[k][0] = (float)g0[0]; dn[k][1] = (float)g0[gps]; dn[k][2] = (float)g0[1]; dn[k][3] = (float)g0[gps + 1];
+            const GT* g0 = gq + (unsigned)(((r & 1) * 2) * gps + (r >> 1) * p.pitch_g + (c >> 1));
+            const g2u ge = *reinterpret_cast<const g2u*>(g0), go = *reinterpret_cast<const g2u*>(g0 + gps);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) xh[k][j] = fmaf(t[j], rstd, shift);
+            dn[k][0] = (float)ge[0]; dn[k][1] = (float)go[0]; dn[k][2] = (float)ge[1]; dn[k][3] = (float)go[1];
+        } else if (it < nitems) {
+            const int r = it - nwhole, c = wqw * 4;
+            const GT* g0 = gq + (unsigned)(((r & 1) * 2) * gps + (r >> 1) * p.pitch_g + (c >> 1));
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                if (j < tailn) {
+                    xh[k][j] = fmaf(yp[(unsigned)(r * p.pitch_y + c + j)], rstd, shift);
+                    dn[k][j] = (float)g0[(j & 1) * gps + (j >> 1)];
+                }
         }
     }
     float s1 = 0.0f, s2 = 0.0f;
 #pragma unroll
-    for (int k = 0; k < KQ; ++k) {
-        const int it = threadIdx.x + 256 * k;
-        const int r = (int)__umulhi((unsigned)it, mwq), c = (it - r * wq) * 4;
+    for (int k = 0; k < KQ; ++k)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const bool ok = it < nitems && c + j < p.W;
-            const float x = ok ? fmaf(xh[k][j], rstd, shift) : 0.0f;
-            float gv = ok ? dn[k][j] : 0.0f;
-            if (p.relu && !(x > 0.0f)) gv = 0.0f;
+            float gv = dn[k][j];
+            if (p.relu && !(xh[k][j] > 0.0f)) gv = 0.0f;
             dn[k][j] = gv;
-            xh[k][j] = x;
             s1 += gv;
-            s2 = fmaf(gv, x, s2);
+            s2 = fmaf(gv, xh[k][j], s2);
         }
-    }
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     s1 = wave_sum_all(s1);
     s2 = wave_sum_all(s2);
@@ -1298,24 +1298,25 @@ __global__ __launch_bounds__(256) void cb_norm_bwd_plane_kernel(CbNormBwd p) {
 #pragma unroll
     for (int k = 0; k < KQ; ++k) {
         const int it = threadIdx.x + 256 * k;
-        const int r = (int)__umulhi((unsigned)it, mwq), c = (it - r * wq) * 4;
         float o[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const bool ok = it < nitems && c + j < p.W;
-            o[j] = ok ? rstd * (dn[k][j] - m1 - xh[k][j] * m2) : 0.0f;
-            gs += o[j];
-        }
-        if (it < nitems && c + 3 < p.W) {
+        for (int j = 0; j < 4; ++j) o[j] = rstd * (dn[k][j] - m1 - xh[k][j] * m2);
+        if (it < nwhole) {
+            const int r = (int)__umulhi((unsigned)it, mwq), c = (it - r * wqw) * 4;
+            gs += (o[0] + o[1]) + (o[2] + o[3]);
             if constexpr (O16) {
-                *reinterpret_cast<cb_h4u*>(op + r * p.W + c) = cb_h4u{(__bf16)o[0], (__bf16)o[1], (__bf16)o[2], (__bf16)o[3]};
+                *reinterpret_cast<cb_h4u*>(op + (unsigned)(r * p.W + c)) = cb_h4u{(__bf16)o[0], (__bf16)o[1], (__bf16)o[2], (__bf16)o[3]};
             } else {
-                *reinterpret_cast<cb_f4u*>(op + r * p.W + c) = cb_f4{o[0], o[1], o[2], o[3]};
+                *reinterpret_cast<cb_f4u*>(op + (unsigned)(r * p.W + c)) = cb_f4{o[0], o[1], o[2], o[3]};
             }
         } else if (it < nitems) {
+            const int r = it - nwhole, c = wqw * 4;
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (c + j < p.W) op[r * p.W + c + j] = (OT)o[j];
+            for (int j = 0; j < 3; ++j)
+                if (j < tailn) {
+                    gs += o[j];
+                    op[(unsigned)(r * p.W + c + j)] = (OT)o[j];
+                }
         }
     }
     if (p.gsum) {
@@ -1831,7 +1832,7 @@ int mdnvae_cb_norm_bwd(const void* g, int gmode, int pitch_g, long Qg, const flo
                    "multiple of 8 and holds the %d x %d plane", PP, H, W);
         MV_REQUIRE(H * W <= 32 * 256, E_SHAPE, "mdnvae_cb_norm_bwd: plane of %d entries exceeds %d", H * W, 32 * 256);
         const int items = H * ((W + 3) / 4);
-        if (gmode == 2 && !base && !sum_out && items <= 8 * 256 && pitch_g >= (W + 1) / 2 + 1 && Qg >= (long)((H + 1) / 2) * pitch_g) {
+        if (gmode == 2 && !base && !sum_out && items <= 8 * 256 && W >= 4 && 4L * C * Qg < (1L << 31) && pitch_g >= (W + 1) / 2 + 1 && Qg >= (long)((H + 1) / 2) * pitch_g) {
             if (omode == 3) {
                 if (items <= 5 * 256) hipLaunchKernelGGL((cb_norm_bwd_plane_kernel<5, __bf16, __bf16>), dim3(C, B), dim3(256), 0, st, a);
                 else hipLaunchKernelGGL((cb_norm_bwd_plane_kernel<8, __bf16, __bf16>), dim3(C, B), dim3(256), 0, st, a);
