@@ -508,8 +508,9 @@ int mdnvae_cb_norm_fwd(const void* y, int y16, float* stats, int compute_stats, 
  * of dc (the convolution-bias gradient before the sum over the batch; summed before any rounding).
  * parts = 2: dc leaves as two fp16 parts scaled by the power of two of the record absmax_dc, the largest |dc|:
  * run the pass once with absmax_probe (a cleared record; nothing else is written) and again with that record as
- * absmax_dc; the same record goes to the products that read dc.  (The exact maximum keeps all 22 bits of the two
- * parts; a bound from the inputs' magnitudes would give away one bit per factor of two it is loose by.) */
+ * absmax_dc; the same record goes to the products that read dc.  (Any record between the largest |dc| and some
+ * 2^6 times it serves: the parts are floating point, and a loose scale only raises the absolute error floor,
+ * 2^-40 of the record.) */
 int mdnvae_cb_norm_bwd(const void* g, int gmode, int pitch_g, long Qg, const float* base, float* sum_out,
                        const void* y, int y16, const float* stats, int pitch_y, long Qy, int relu, int B, int C, int H,
                        int W, int omode, void* dc, long part_stride, int PP, int parts, float scale, float* gsum,
